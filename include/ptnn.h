@@ -1,0 +1,138 @@
+/*
+ * ptnn.h -- C ABI of libptnn.so: the MI355X (gfx950) parallel-tempering Bayesian-FNN sampler.
+ *
+ * The reference (sydney-machine-learning/parallel-tempering-neural-net) has no FFI: its seam is the Python
+ * class ParallelTempering (REG = multicore-pt-regression/pt_timeseries_regression.py:487-875,
+ * CLS = multicore-pt-classification/pt_classification.py:497-897).  This header is the boundary a maintainer
+ * binds with ctypes to replace what that class does by forking one ptReplica process per chain; every entry
+ * point names the reference code it stands in for.  INTEGRATION.md shows the binding.
+ *
+ * Conventions: plain C, no C++ or torch types; return 0 = OK, negative = error (text via ptnn_last_error());
+ * the caller owns every host buffer (C-contiguous float32 / int32, alive for the call only); the library owns
+ * device memory and its stream; a handle is not thread-safe (one host thread per handle, one handle per GPU);
+ * calls are synchronous unless their comment says "asynchronous".
+ */
+#ifndef PTNN_H
+#define PTNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTNN_ABI_VERSION 1
+
+#define PTNN_TASK_REG 0 /* Gaussian likelihood + eta = log tau^2 (REG) */
+#define PTNN_TASK_CLS 1 /* multinomial likelihood on softmax-of-sigmoid outputs (CLS) */
+
+typedef struct ptnn_handle ptnn_handle;
+
+/* Everything ParallelTempering.__init__ / initialize_chains / ptReplica.__init__ fix for a run
+ * (REG:489-527, 639-650, 140-176; CLS:499-535, 648-659, 159-193). */
+typedef struct ptnn_config {
+    int32_t struct_bytes;         /* = sizeof(ptnn_config): ABI guard */
+    int32_t device_id;            /* HIP device ordinal */
+    int32_t task;                 /* PTNN_TASK_REG | PTNN_TASK_CLS */
+    int32_t n_in, n_hidden, n_out;/* topology [I, H, O] (REG:30) */
+    int32_t n_replicas_local;     /* replicas (temperatures) this handle owns */
+    int32_t n_replicas_global;    /* replicas in the whole ladder (== local on one GPU) */
+    int32_t first_global_replica; /* global index of local replica 0 (contiguous block of the ladder) */
+    int32_t n_samples;            /* S = NumSamples per replica = int(NumSample/num_chains) (REG:506) */
+    int32_t swap_interval;        /* REG:496; hand-off trigger differs per task (REG:427 vs CLS:438) */
+    int32_t pt_switch_step;       /* step i at which adapttemp drops to 1 (REG:320), or -1 if 0.6*S is not integral */
+    int32_t use_langevin;         /* use_langevin_gradients (REG:329) */
+    int32_t waves_per_replica;    /* 0 = auto; 1,2,4,8,16: wavefronts of the work-group that owns one replica */
+    float l_prob;                 /* langevin_prob (REG:174); CLS fixes 0.5 (CLS:192) */
+    float learn_rate;             /* SGD step of langevin_gradient (REG:33) */
+    float step_w;                 /* 0.025 (REG:258) */
+    float step_eta;               /* 0.2   (REG:260) */
+    float sigma_squared;          /* 25    (REG:273) */
+    float nu_1, nu_2;             /* 0, 0  (REG:274-275) */
+    uint64_t seed;                /* Philox4x32-10 key; streams are documented in DESIGN.md */
+} ptnn_config;
+
+int ptnn_abi_version(void);
+/* thread-local, valid until the next failing call on this thread */
+const char *ptnn_last_error(void);
+/* 1 if a kernel is compiled for (task, n_in, n_out); n_hidden may be anything in [1, 64] */
+int ptnn_supports(int task, int n_in, int n_hidden, int n_out);
+
+/* replaces ParallelTempering.__init__ + the construction of the ptReplica objects (REG:489, 650) */
+int ptnn_create(const ptnn_config *cfg, ptnn_handle **out);
+int ptnn_destroy(ptnn_handle *h);
+
+/* traindata / testdata (REG:491-492): row-major [n, ncols] float32, columns [x_0..x_{I-1}, y, ...]; copied to HBM */
+int ptnn_set_data(ptnn_handle *h, const float *train, int ntr, const float *test, int nte, int ncols);
+
+/* w0 [R_local, P] (REG:649) and temperatures [R_local] (REG:615-636).  Also runs the chain start-up on the device:
+ * eta0 = log var(fx_train(w0) - y) for REG (REG:270), initial prior and tempered likelihood (REG:280-285). */
+int ptnn_set_state(ptnn_handle *h, const float *w0, const float *temperatures);
+
+/* Advances every local replica by up to n_steps MH steps (ptReplica.run loop body, REG:313-437) and performs the
+ * swap rounds that fall inside (ParallelTempering.swap_procedure + round loop, REG:659-690, 719-752), including the
+ * phantom last round when the chain end is reached.  n_steps < 0 = run to the end.  Single-GPU only
+ * (n_replicas_local == n_replicas_global).  Asynchronous: returns once the work is queued; ptnn_sync waits. */
+int ptnn_run(ptnn_handle *h, int n_steps);
+int ptnn_sync(ptnn_handle *h);
+/* number of MH steps queued so far (0 .. S-1) */
+int ptnn_steps_done(ptnn_handle *h);
+
+/* ---- sharded ladder (one handle per GPU): the pieces of one swap round, driven by the host between collectives ---- */
+/* queue MH steps up to and including the next hand-off step (or the chain end); returns in *handoff 1 when a swap
+ * round is due after it, 2 when the due round is the phantom end-of-chain round, 0 otherwise.  Asynchronous. */
+int ptnn_run_segment(ptnn_handle *h, int *handoff);
+/* device address of the posted scalars L[R_global] (REG:430 / CLS:439); the local block is filled by the segment,
+ * the caller all-gathers the rest in place */
+int ptnn_swap_L_ptr(ptnn_handle *h, int phantom, void **dev_ptr);
+/* overwrite L[R_global] from the host (host-staged transports, tests) */
+int ptnn_swap_set_L(ptnn_handle *h, int phantom, const float *L_host);
+/* run the cascade on L[R_global] (identical on every rank: uniforms are Philox(seed; round, pair)); writes
+ * src[R_global] to the host: slot k receives the (w, eta) of slot src[k] */
+int ptnn_swap_cascade(ptnn_handle *h, int phantom, int32_t *src_host);
+/* device addresses of the (w, eta) row of a local replica in the current (send) and next (receive) state buffers;
+ * row length ptnn_state_row_floats() floats */
+int ptnn_swap_row_ptr(ptnn_handle *h, int local_replica, void **cur_row, void **next_row);
+int ptnn_state_row_floats(ptnn_handle *h);
+/* copy the rows whose source is local, flip the buffers, count the round.  Rows with remote sources must have been
+ * received into next_row before this call. */
+int ptnn_swap_apply(ptnn_handle *h, const int32_t *src_host, int phantom);
+
+/* ---- results ---- */
+/* traces of steps [step0, step0+nsteps) for all local replicas; any pointer may be NULL.
+ * pos_w [R,nsteps,P] (REG:240,408,417); likeh [R,nsteps] = column 0 of likeh_list (REG:391 / CLS:404);
+ * rmse_* / acc_* [R,nsteps] (REG:403-423); accept_count [R,nsteps] = accept_list (REG:380). */
+int ptnn_get_traces(ptnn_handle *h, int step0, int nsteps, float *pos_w, float *likeh, float *rmse_train,
+                    float *rmse_test, float *acc_train, float *acc_test, int32_t *accept_count);
+/* num_swap / total_swap_proposals (REG:501-502, 680-688) */
+int ptnn_get_swap_stats(ptnn_handle *h, int64_t *num_swap, int64_t *total_proposals, int32_t *rounds_done);
+/* src permutation of every completed round, [rounds, R_global] (tests) */
+int ptnn_get_swap_log(ptnn_handle *h, int32_t *src, int max_rounds);
+/* current chain state per local replica: w [R,P], eta [R], likelihood [R] (tempered, possibly stale: Q12),
+ * prior_current [R], num_accepted [R], langevin_count [R]; any pointer may be NULL */
+int ptnn_get_state(ptnn_handle *h, float *w, float *eta, float *likelihood, float *prior, int32_t *num_accepted,
+                   int32_t *langevin_count);
+
+/* ---- the model functions on their own (same device code as the sampler) ---- */
+/* Network.evaluate_proposal + likelihood_func + prior_likelihood for n weight vectors w [n,P] (REG:120-134, 200-221;
+ * CLS:134-153, 209-230); tau_sq [n] (ignored for CLS, may be NULL).  out [n,8] =
+ * {loglik_train (untempered), rmse_train, rmse_test, acc_train, acc_test, prior, loglik_test, 0}. */
+int ptnn_evaluate(ptnn_handle *h, const float *w, const float *tau_sq, int n, float *out);
+/* Network.langevin_gradient(train, w, depth=1) for n weight vectors (REG:99-118, CLS:114-132) */
+int ptnn_langevin_gradient(ptnn_handle *h, const float *w_in, int n, float *w_out);
+/* the random tape of MH step `step` of global replica `replica`: noise [P] normals, scal[3] = {lx, u, n_eta} */
+int ptnn_tape(ptnn_handle *h, int replica, int step, float *noise, float *scal);
+
+/* timing of the dominant kernel, measured with HIP events on the library's stream around every segment launch
+ * since the last reset: launches, total milliseconds */
+int ptnn_kernel_time(ptnn_handle *h, int reset, int64_t *launches, double *total_ms);
+
+/* ---- host-side helper (no GPU): the text dump the result-file layout requires ---- */
+/* np.savetxt(path, data[rows, cols], fmt=fmt) with ' ' between columns and '\n' after rows (REG:454-481, 864-868).
+ * fmt is one printf floating conversion such as "%.18e", "%1.8f", "%1.2f". */
+int ptnn_savetxt(const char *path, const double *data, int64_t rows, int64_t cols, const char *fmt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTNN_H */

@@ -5,7 +5,7 @@ may import this module.  It is used by `tests/`, by `__graft_entry__.smoke()` an
 `cpu_baseline` leg of `bench.py`, always as the checker / the timed CPU stand-in, never as
 the thing that is shipped.
 
-Parity status: PINNED.  `tools/make_fixtures.py` imports the reference's own classes from
+Parity status: PINNED.  `tests/golden/make_fixtures.py` imports the reference's own classes from
 /root/reference (survey container only), drives them with the Philox random tape defined
 below, and stores their outputs in `tests/golden/*.npz|json`; `tests/test_oracle_golden.py`
 checks every function here against those vectors at float64 round-off.
@@ -36,7 +36,7 @@ TASK_CLS = 1   # multinomial likelihood (CLS)
 #             1 = proposal noise for w  (c0 = j//4, element j%4 of the Box-Muller quad)
 #             2 = swap uniforms         (c0 = pair k, c1 = swap round, c2 = 0)
 #             3 = initial weights w0    (c0 = j//4, c1 = 0)
-#   uniform : u = ((x >> 8) + 0.5) * 2^-24   (exact in fp32 and fp64, never 0 or 1)
+#   uniform : u = ((x >> 9) + 0.5) * 2^-23   (23 bits: exact in fp32 and fp64, never 0 or 1)
 #   normals : quad (x0,x1,x2,x3) -> r0 = sqrt(-2 ln u(x0)), n0 = r0 cos(2 pi u(x1)), n1 = r0 sin(2 pi u(x1)),
 #             r1 = sqrt(-2 ln u(x2)), n2 = r1 cos(2 pi u(x3)), n3 = r1 sin(2 pi u(x3))
 # ---------------------------------------------------------------------------------------------
@@ -66,7 +66,8 @@ def philox4x32(c0, c1, c2, c3, seed):
 
 
 def u24(x):
-    return ((np.asarray(x, dtype=np.uint32) >> np.uint32(8)).astype(np.float64) + 0.5) * (1.0 / 16777216.0)
+    """23-bit uniform in (0,1); the name is historical."""
+    return ((np.asarray(x, dtype=np.uint32) >> np.uint32(9)).astype(np.float64) + 0.5) * (1.0 / 8388608.0)
 
 
 def normal_quads(x0, x1, x2, x3):

@@ -1,0 +1,255 @@
+"""ctypes binding of libptnn.so (include/ptnn.h).  No fallback: a missing library or device raises PtnnError."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 1
+TASK_REG, TASK_CLS = 0, 1
+
+
+class PtnnError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_int32), ("device_id", C.c_int32), ("task", C.c_int32),
+        ("n_in", C.c_int32), ("n_hidden", C.c_int32), ("n_out", C.c_int32),
+        ("n_replicas_local", C.c_int32), ("n_replicas_global", C.c_int32), ("first_global_replica", C.c_int32),
+        ("n_samples", C.c_int32), ("swap_interval", C.c_int32), ("pt_switch_step", C.c_int32),
+        ("use_langevin", C.c_int32), ("waves_per_replica", C.c_int32),
+        ("l_prob", C.c_float), ("learn_rate", C.c_float), ("step_w", C.c_float), ("step_eta", C.c_float),
+        ("sigma_squared", C.c_float), ("nu_1", C.c_float), ("nu_2", C.c_float),
+        ("seed", C.c_uint64),
+    ]
+
+
+def library_path():
+    return os.environ.get("PTNN_LIBRARY", os.path.join(_HERE, "libptnn.so"))
+
+
+_lib = None
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_vpp = C.POINTER(C.c_void_p)
+
+# every symbol include/ptnn.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "ptnn_abi_version": (C.c_int, []),
+    "ptnn_last_error": (C.c_char_p, []),
+    "ptnn_supports": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ptnn_create": (C.c_int, [C.POINTER(Config), _vpp]),
+    "ptnn_destroy": (C.c_int, [C.c_void_p]),
+    "ptnn_set_data": (C.c_int, [C.c_void_p, _fp, C.c_int, _fp, C.c_int, C.c_int]),
+    "ptnn_set_state": (C.c_int, [C.c_void_p, _fp, _fp]),
+    "ptnn_run": (C.c_int, [C.c_void_p, C.c_int]),
+    "ptnn_sync": (C.c_int, [C.c_void_p]),
+    "ptnn_steps_done": (C.c_int, [C.c_void_p]),
+    "ptnn_run_segment": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "ptnn_swap_L_ptr": (C.c_int, [C.c_void_p, C.c_int, _vpp]),
+    "ptnn_swap_set_L": (C.c_int, [C.c_void_p, C.c_int, _fp]),
+    "ptnn_swap_cascade": (C.c_int, [C.c_void_p, C.c_int, _ip]),
+    "ptnn_swap_row_ptr": (C.c_int, [C.c_void_p, C.c_int, _vpp, _vpp]),
+    "ptnn_state_row_floats": (C.c_int, [C.c_void_p]),
+    "ptnn_swap_apply": (C.c_int, [C.c_void_p, _ip, C.c_int]),
+    "ptnn_get_traces": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _ip]),
+    "ptnn_get_swap_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _ip]),
+    "ptnn_get_swap_log": (C.c_int, [C.c_void_p, _ip, C.c_int]),
+    "ptnn_get_state": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _ip, _ip]),
+    "ptnn_evaluate": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, _fp]),
+    "ptnn_langevin_gradient": (C.c_int, [C.c_void_p, _fp, C.c_int, _fp]),
+    "ptnn_tape": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp]),
+    "ptnn_kernel_time": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "ptnn_savetxt": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_char_p]),
+}
+
+
+def load_library():
+    """dlopen libptnn.so and declare every prototype.  Loading does not touch the GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise PtnnError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        f"(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError here = header and library out of step
+        fn.restype, fn.argtypes = res, args
+    if lib.ptnn_abi_version() != ABI_VERSION:
+        raise PtnnError(f"libptnn ABI {lib.ptnn_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a, typ=_fp):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+class Sampler:
+    """Thin object wrapper over a ptnn_handle (one GPU, one contiguous block of the ladder)."""
+
+    def __init__(self, **kw):
+        self.lib = load_library()
+        cfg = Config()
+        cfg.struct_bytes = C.sizeof(Config)
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self.P = cfg.n_in * cfg.n_hidden + cfg.n_hidden * cfg.n_out + cfg.n_hidden + cfg.n_out
+        self.R = cfg.n_replicas_local
+        self.S = cfg.n_samples
+        h = C.c_void_p()
+        self._check(self.lib.ptnn_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def _check(self, rc):
+        if rc < 0:
+            raise PtnnError(self.lib.ptnn_last_error().decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ptnn_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_data(self, train, test):
+        tr, te = _f32(train), _f32(test)
+        if tr.ndim != 2 or te.ndim != 2 or tr.shape[1] != te.shape[1]:
+            raise ValueError("train/test must be 2-D with the same number of columns")
+        self._check(self.lib.ptnn_set_data(self.h, _ptr(tr), tr.shape[0], _ptr(te), te.shape[0], tr.shape[1]))
+        self.ntr, self.nte = tr.shape[0], te.shape[0]
+
+    def set_state(self, w0, temperatures):
+        w0, t = _f32(w0), _f32(temperatures)
+        if w0.shape != (self.R, self.P) or t.shape != (self.R,):
+            raise ValueError(f"w0 must be [{self.R},{self.P}], temperatures [{self.R}]")
+        self._check(self.lib.ptnn_set_state(self.h, _ptr(w0), _ptr(t)))
+
+    def run(self, n_steps=-1):
+        self._check(self.lib.ptnn_run(self.h, int(n_steps)))
+
+    def sync(self):
+        self._check(self.lib.ptnn_sync(self.h))
+
+    def steps_done(self):
+        return self.lib.ptnn_steps_done(self.h)
+
+    def run_segment(self):
+        ho = C.c_int(0)
+        self._check(self.lib.ptnn_run_segment(self.h, C.byref(ho)))
+        return ho.value
+
+    def swap_L_ptr(self, phantom):
+        p = C.c_void_p()
+        self._check(self.lib.ptnn_swap_L_ptr(self.h, int(phantom), C.byref(p)))
+        return p.value
+
+    def swap_set_L(self, L, phantom=0):
+        L = _f32(L)
+        if L.shape != (self.cfg.n_replicas_global,):
+            raise ValueError("L must have n_replicas_global entries")
+        self._check(self.lib.ptnn_swap_set_L(self.h, int(phantom), _ptr(L)))
+
+    def swap_cascade(self, phantom):
+        src = np.empty(self.cfg.n_replicas_global, dtype=np.int32)
+        self._check(self.lib.ptnn_swap_cascade(self.h, int(phantom), _ptr(src, _ip)))
+        return src
+
+    def swap_row_ptr(self, local_replica):
+        a, b = C.c_void_p(), C.c_void_p()
+        self._check(self.lib.ptnn_swap_row_ptr(self.h, int(local_replica), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def state_row_floats(self):
+        return self.lib.ptnn_state_row_floats(self.h)
+
+    def swap_apply(self, src, phantom):
+        src = np.ascontiguousarray(src, dtype=np.int32)
+        self._check(self.lib.ptnn_swap_apply(self.h, _ptr(src, _ip), int(phantom)))
+
+    def traces(self, step0=0, nsteps=None, pos_w=True):
+        n = self.S - step0 if nsteps is None else nsteps
+        out = {
+            "pos_w": np.empty((self.R, n, self.P), np.float32) if pos_w else None,
+            "likeh": np.empty((self.R, n), np.float32),
+            "rmse_train": np.empty((self.R, n), np.float32), "rmse_test": np.empty((self.R, n), np.float32),
+            "acc_train": np.empty((self.R, n), np.float32), "acc_test": np.empty((self.R, n), np.float32),
+            "accept": np.empty((self.R, n), np.int32),
+        }
+        self._check(self.lib.ptnn_get_traces(self.h, step0, n, _ptr(out["pos_w"]), _ptr(out["likeh"]),
+                                             _ptr(out["rmse_train"]), _ptr(out["rmse_test"]), _ptr(out["acc_train"]),
+                                             _ptr(out["acc_test"]), _ptr(out["accept"], _ip)))
+        return out
+
+    def swap_stats(self):
+        a, b, r = C.c_int64(), C.c_int64(), C.c_int32()
+        self._check(self.lib.ptnn_get_swap_stats(self.h, C.byref(a), C.byref(b), C.byref(r)))
+        return a.value, b.value, r.value
+
+    def swap_log(self, max_rounds=None):
+        Rg = self.cfg.n_replicas_global
+        cap = max_rounds or (self.S // self.cfg.swap_interval + 2)
+        buf = np.empty((cap, Rg), np.int32)
+        n = self._check(self.lib.ptnn_get_swap_log(self.h, _ptr(buf, _ip), cap))
+        return buf[:n]
+
+    def state(self):
+        w = np.empty((self.R, self.P), np.float32)
+        eta, lik, pri = (np.empty(self.R, np.float32) for _ in range(3))
+        nacc, lg = np.empty(self.R, np.int32), np.empty(self.R, np.int32)
+        self._check(self.lib.ptnn_get_state(self.h, _ptr(w), _ptr(eta), _ptr(lik), _ptr(pri), _ptr(nacc, _ip), _ptr(lg, _ip)))
+        return dict(w=w, eta=eta, likelihood=lik, prior=pri, num_accepted=nacc, langevin_count=lg)
+
+    def evaluate(self, w, tau_sq=None):
+        w = _f32(np.atleast_2d(w))
+        n = w.shape[0]
+        tau = None if tau_sq is None else _f32(np.broadcast_to(np.asarray(tau_sq, dtype=np.float32), (n,)))
+        out = np.empty((n, 8), np.float32)
+        self._check(self.lib.ptnn_evaluate(self.h, _ptr(w), _ptr(tau), n, _ptr(out)))
+        return out
+
+    def langevin_gradient(self, w):
+        w = _f32(np.atleast_2d(w))
+        out = np.empty_like(w)
+        self._check(self.lib.ptnn_langevin_gradient(self.h, _ptr(w), w.shape[0], _ptr(out)))
+        return out
+
+    def tape(self, replica, step):
+        noise, scal = np.empty(self.P, np.float32), np.empty(3, np.float32)
+        self._check(self.lib.ptnn_tape(self.h, int(replica), int(step), _ptr(noise), _ptr(scal)))
+        return noise, scal
+
+    def kernel_time(self, reset=False):
+        n, ms = C.c_int64(), C.c_double()
+        self._check(self.lib.ptnn_kernel_time(self.h, int(reset), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+
+def savetxt(path, array, fmt):
+    """np.savetxt(path, array, fmt=fmt) for 1-D / 2-D float arrays, formatted by the C library (GIL released)."""
+    lib = load_library()
+    a = np.ascontiguousarray(array, dtype=np.float64)
+    if a.ndim == 1:
+        rows, cols = a.shape[0], 1
+    elif a.ndim == 2:
+        rows, cols = a.shape
+    else:
+        raise ValueError("savetxt handles 1-D and 2-D arrays")
+    rc = lib.ptnn_savetxt(os.fsencode(path), a.ctypes.data_as(C.POINTER(C.c_double)), rows, cols, fmt.encode())
+    if rc < 0:
+        raise PtnnError(lib.ptnn_last_error().decode())

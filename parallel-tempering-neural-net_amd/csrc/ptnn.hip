@@ -1,0 +1,621 @@
+// ptnn.hip -- host side of libptnn.so: the C ABI of include/ptnn.h over the gfx950 kernels of ptnn_device.hpp.
+//
+// Replaces, for the hot path only, what the reference does with one forked ptReplica process per chain plus the
+// parent's swap loop (REG = multicore-pt-regression/pt_timeseries_regression.py:223-485, 659-771;
+// CLS = multicore-pt-classification/pt_classification.py:232-494, 668-776).
+#include "ptnn_device.hpp"
+#include "../../include/ptnn.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ptnn;
+
+// ---------------------------------------------------------------------------------------------------------------
+// compiled (task, n_in, n_out) shapes.  n_hidden is a run-time value in [1, 64].
+// REG: the shipped time series have 4 lag inputs (REG:916); 5 and 32 cover BASELINE.json's literal [5,H,1] and the
+// synthetic [32,H,1].  CLS: the reference's problem table (CLS:909-995): iris 4/3, ionosphere 34/2, cancer 9/2,
+// wine 11/10, bank 20/2, pendigit 16/10, chess 6/18.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef PTNN_SHAPES
+#define PTNN_SHAPES(X) X(0, 4, 1) X(0, 5, 1) X(0, 32, 1) X(1, 4, 3) X(1, 34, 2) X(1, 9, 2) X(1, 11, 10) X(1, 20, 2) X(1, 16, 10) X(1, 6, 18)
+#endif
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return fail(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+typedef void (*seg_fn)(const SegParams, int, int);
+typedef void (*model_fn)(const SegParams, int, const float*, const float*, float*, int, int);
+
+struct Shape {
+    int task, I, O;
+    seg_fn seg;
+    model_fn model;
+};
+
+#define X_ENTRY(T, I, O) {T, I, O, &segment_kernel<T, I, O>, &model_kernel<T, I, O>},
+const Shape g_shapes[] = {PTNN_SHAPES(X_ENTRY)};
+#undef X_ENTRY
+
+const Shape* find_shape(int task, int I, int O) {
+    for (const Shape& s : g_shapes)
+        if (s.task == task && s.I == I && s.O == O) return &s;
+    return nullptr;
+}
+
+inline int round_up4(int v) { return (v + 3) & ~3; }
+
+}  // namespace
+
+struct ptnn_handle {
+    ptnn_config cfg{};
+    const Shape* shape = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int P = 0, PS = 0, IPY = 0, FWS = 0, Ntr = 0, Nte = 0, nthreads = 64;
+    size_t seg_lds = 0;
+    bool have_data = false, have_state = false, finalized = false;
+    int cur = 0;            // next MH step index
+    int rounds_done = 0;    // swap rounds counted (including the phantom one)
+    int max_rounds = 0;
+    int flip = 0;           // which state buffer is current
+    // device memory
+    float* d_data = nullptr;
+    float* d_state[2] = {nullptr, nullptr};
+    float *d_rec_w = nullptr, *d_gd_w = nullptr, *d_st_f = nullptr, *d_temps = nullptr;
+    int* d_st_i = nullptr;
+    float *d_L_handoff = nullptr, *d_L_final = nullptr;
+    float *d_pos_w = nullptr, *d_likeh = nullptr, *d_rmse_tr = nullptr, *d_rmse_te = nullptr, *d_acc_tr = nullptr,
+          *d_acc_te = nullptr;
+    int* d_accept = nullptr;
+    int *d_src = nullptr, *d_src_log = nullptr;
+    long long* d_counters = nullptr;
+    // kernel timing (HIP events on our stream)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timing;
+    size_t timing_used = 0;
+    int64_t timed_launches = 0;
+    double timed_ms = 0.0;
+
+    SegParams seg_params() const {
+        SegParams p{};
+        p.H = cfg.n_hidden; p.P = P; p.PS = PS;
+        p.Ntr = Ntr; p.Nte = Nte; p.IPY = IPY; p.FWS = FWS;
+        p.S = cfg.n_samples; p.switch_step = cfg.pt_switch_step; p.use_lg = cfg.use_langevin;
+        p.first_global = cfg.first_global_replica;
+        p.l_prob = cfg.l_prob; p.lr = cfg.learn_rate; p.step_w = cfg.step_w; p.step_eta = cfg.step_eta;
+        p.inv_2sig2 = 1.0f / (2.0f * cfg.sigma_squared);
+        const int I = cfg.n_in, H = cfg.n_hidden, O = cfg.n_out;
+        // part1 of prior_likelihood: REG uses d*h + h + 2 (REG:218), CLS d*h + h + o + h*o (CLS:227)
+        const double cnt = (cfg.task == PTNN_TASK_REG) ? (double)(I * H + H + 2) : (double)(I * H + H + O + H * O);
+        p.prior_c = (float)(-1.0 * (cnt / 2.0) * std::log((double)cfg.sigma_squared));
+        p.nu1 = cfg.nu_1; p.nu2 = cfg.nu_2;
+        p.seed_lo = (uint32_t)(cfg.seed & 0xffffffffull); p.seed_hi = (uint32_t)(cfg.seed >> 32);
+        p.data = d_data; p.w_state = d_state[flip]; p.rec_w = d_rec_w; p.gd_w = d_gd_w;
+        p.st_f = d_st_f; p.st_i = d_st_i; p.temps = d_temps;
+        p.L_handoff = d_L_handoff; p.L_final = d_L_final;
+        p.tr_pos_w = d_pos_w; p.tr_likeh = d_likeh; p.tr_rmse_tr = d_rmse_tr; p.tr_rmse_te = d_rmse_te;
+        p.tr_acc_tr = d_acc_tr; p.tr_acc_te = d_acc_te; p.tr_accept = d_accept;
+        return p;
+    }
+};
+
+namespace {
+
+// Q10: REG hands off after step i when i % si == 0 and i != 0 (REG:427); CLS when (i+1) % si == 0 (CLS:438)
+inline bool swap_trigger(const ptnn_config& c, int i) {
+    if (c.task == PTNN_TASK_REG) return (i % c.swap_interval == 0) && i != 0;
+    return ((i + 1) % c.swap_interval) == 0;
+}
+
+void collect_timing(ptnn_handle* h) {
+    for (size_t k = 0; k < h->timing_used; ++k) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->timing[k].first, h->timing[k].second) == hipSuccess) {
+            h->timed_ms += ms;
+            h->timed_launches += 1;
+        }
+    }
+    h->timing_used = 0;
+}
+
+int launch_segment(ptnn_handle* h, int begin, int n) {
+    if (n <= 0) return 0;
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    if (h->timing_used == h->timing.size()) {
+        if (h->timing.size() >= 4096) {               // keep the pool bounded: drain it (synchronises)
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            collect_timing(h);
+        } else {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            h->timing.emplace_back(a, b);
+        }
+    }
+    auto& ev = h->timing[h->timing_used++];
+    const SegParams p = h->seg_params();
+    HIP_TRY(hipEventRecord(ev.first, h->stream));
+    hipLaunchKernelGGL(h->shape->seg, dim3(h->cfg.n_replicas_local), dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.second, h->stream));
+    return 0;
+}
+
+// mode bit 0 = apply local moves (and flip), bit 1 = count + log, src_out optional
+int launch_swap(ptnn_handle* h, bool phantom, int mode, bool want_src) {
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    SwapParams sp{};
+    sp.R = h->cfg.n_replicas_global; sp.Rl = h->cfg.n_replicas_local; sp.first_global = h->cfg.first_global_replica;
+    sp.PS = h->PS;
+    sp.seed_lo = (uint32_t)(h->cfg.seed & 0xffffffffull); sp.seed_hi = (uint32_t)(h->cfg.seed >> 32);
+    sp.L = phantom ? h->d_L_final : h->d_L_handoff;
+    sp.cur = h->d_state[h->flip]; sp.next = h->d_state[h->flip ^ 1];
+    sp.st_i = h->d_st_i; sp.src_out = want_src ? h->d_src : nullptr;
+    sp.counters = h->d_counters; sp.src_log = h->d_src_log; sp.log_capacity = h->max_rounds;
+    const size_t lds = (size_t)(3 * sp.R + 1) * sizeof(float);
+    hipLaunchKernelGGL(swap_kernel, dim3(sp.Rl), dim3(64), lds, h->stream, sp, h->rounds_done, mode);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int check_ready(ptnn_handle* h) {
+    if (!h) return fail(-1, "null handle");
+    if (!h->have_data) return fail(-1, "ptnn_set_data has not been called");
+    if (!h->have_state) return fail(-1, "ptnn_set_state has not been called");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptnn_abi_version(void) { return PTNN_ABI_VERSION; }
+const char* ptnn_last_error(void) { return g_err.c_str(); }
+
+int ptnn_supports(int task, int n_in, int n_hidden, int n_out) {
+    return (find_shape(task, n_in, n_out) != nullptr && n_hidden >= 1 && n_hidden <= 64) ? 1 : 0;
+}
+
+int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
+    if (!cfg || !out) return fail(-1, "null argument");
+    if (cfg->struct_bytes != (int32_t)sizeof(ptnn_config))
+        return fail(-1, "ptnn_config size mismatch: caller %d, library %d", cfg->struct_bytes, (int)sizeof(ptnn_config));
+    if (cfg->task != PTNN_TASK_REG && cfg->task != PTNN_TASK_CLS) return fail(-1, "unknown task %d", cfg->task);
+    if (cfg->n_in < 1 || cfg->n_hidden < 1 || cfg->n_out < 1) return fail(-1, "bad topology");
+    if (cfg->task == PTNN_TASK_REG && cfg->n_out != 1) return fail(-1, "regression needs n_out == 1");
+    const Shape* sh = find_shape(cfg->task, cfg->n_in, cfg->n_out);
+    if (!sh)
+        return fail(-3, "no gfx950 kernel compiled for task=%d n_in=%d n_out=%d: add it to PTNN_SHAPES and rebuild",
+                    cfg->task, cfg->n_in, cfg->n_out);
+    if (cfg->n_hidden > 64)
+        return fail(-3, "n_hidden=%d > 64: the one-wave-per-replica SGD sweep holds one hidden unit per lane", cfg->n_hidden);
+    if (cfg->n_replicas_local < 1 || cfg->n_replicas_global < 2 || cfg->first_global_replica < 0 ||
+        cfg->first_global_replica + cfg->n_replicas_local > cfg->n_replicas_global)
+        return fail(-1, "bad replica partition: local=%d global=%d first=%d", cfg->n_replicas_local,
+                    cfg->n_replicas_global, cfg->first_global_replica);
+    if (cfg->n_samples < 2) return fail(-1, "n_samples must be >= 2");
+    if (cfg->swap_interval < 1) return fail(-1, "swap_interval must be >= 1 (the reference divides by it, REG:427)");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(-2, "device %d not present (%d devices)", cfg->device_id, ndev);
+    HIP_TRY(hipSetDevice(cfg->device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(-2, "device %d is %s; libptnn is built for gfx950 only", cfg->device_id, prop.gcnArchName);
+
+    ptnn_handle* h = new ptnn_handle();
+    h->cfg = *cfg;
+    h->shape = sh;
+    const int I = cfg->n_in, H = cfg->n_hidden, O = cfg->n_out;
+    h->P = I * H + H * O + H + O;
+    h->PS = round_up4(h->P + 1);
+    h->IPY = round_up4(I + 1);
+    h->FWS = round_up4(I + 1 + O);
+    h->max_rounds = cfg->n_samples / cfg->swap_interval + 2;
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const size_t Rl = cfg->n_replicas_local, R = cfg->n_replicas_global, S = cfg->n_samples;
+    HIP_TRY(hipMalloc(&h->d_state[0], Rl * h->PS * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_state[1], Rl * h->PS * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_rec_w, Rl * h->PS * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_gd_w, Rl * h->PS * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_st_f, Rl * SF_COUNT * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_st_i, Rl * SI_COUNT * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->d_temps, Rl * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_L_handoff, R * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_L_final, R * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_pos_w, Rl * S * h->P * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_likeh, Rl * S * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_rmse_tr, Rl * S * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_rmse_te, Rl * S * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_acc_tr, Rl * S * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_acc_te, Rl * S * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_accept, Rl * S * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->d_src, R * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->d_src_log, (size_t)h->max_rounds * R * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->d_counters, 2 * sizeof(long long)));
+    HIP_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(long long), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_L_handoff, 0, R * sizeof(float), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_L_final, 0, R * sizeof(float), h->stream));
+    HIP_TRY(hipMemsetAsync(h->d_src_log, 0xff, (size_t)h->max_rounds * R * sizeof(int), h->stream));
+    *out = h;
+    return 0;
+}
+
+int ptnn_destroy(ptnn_handle* h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->cfg.device_id);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = {h->d_data, h->d_state[0], h->d_state[1], h->d_rec_w, h->d_gd_w, h->d_st_f, h->d_st_i, h->d_temps,
+                    h->d_L_handoff, h->d_L_final, h->d_pos_w, h->d_likeh, h->d_rmse_tr, h->d_rmse_te, h->d_acc_tr,
+                    h->d_acc_te, h->d_accept, h->d_src, h->d_src_log, h->d_counters};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto& ev : h->timing) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test, int nte, int ncols) {
+    if (!h || !train || !test) return fail(-1, "null argument");
+    const int I = h->cfg.n_in;
+    if (ncols < I + 1) return fail(-1, "data needs at least n_in + 1 = %d columns, got %d", I + 1, ncols);
+    if (ntr < 1 || nte < 1) return fail(-1, "empty data set");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const int Nall = ntr + nte;
+    const int IPY = h->IPY;
+    std::vector<float> packed((size_t)Nall * IPY, 0.0f);
+    for (int n = 0; n < Nall; ++n) {
+        const float* row = (n < ntr) ? train + (size_t)n * ncols : test + (size_t)(n - ntr) * ncols;
+        for (int c = 0; c <= I; ++c) packed[(size_t)n * IPY + c] = row[c];
+        if (h->cfg.task == PTNN_TASK_CLS) {
+            const float y = row[I];
+            if (!(y >= 0.0f) || y >= (float)h->cfg.n_out || y != std::floor(y))
+                return fail(-1, "class label %g in row %d is not an integer in [0, %d)", (double)y, n, h->cfg.n_out);
+        }
+    }
+    // LDS budget: the data set, six state vectors and the packed forward weights live in LDS for the whole launch
+    const size_t lds = lds_floats(Nall, IPY, h->PS, h->cfg.n_hidden, h->FWS) * sizeof(float);
+    if (lds > 160 * 1024)
+        return fail(-3, "replica working set needs %zu B of LDS (> 160 KiB): data %d rows x %d floats, P = %d", lds, Nall,
+                    IPY, h->P);
+    h->seg_lds = lds;
+    h->Ntr = ntr; h->Nte = nte;
+    if (h->d_data) { HIP_TRY(hipFree(h->d_data)); h->d_data = nullptr; }
+    HIP_TRY(hipMalloc(&h->d_data, packed.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(h->d_data, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (lds > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->shape->seg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->shape->model), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    // waves per replica: the row-parallel forward pass uses every wave, the SGD sweep only wave 0
+    int nw = h->cfg.waves_per_replica;
+    if (nw <= 0) {
+        nw = (Nall + 63) / 64;
+        int pow2 = 1;
+        while (pow2 < nw) pow2 <<= 1;
+        nw = std::min(pow2, 8);
+    }
+    if (nw != 1 && nw != 2 && nw != 4 && nw != 8 && nw != 16) return fail(-1, "waves_per_replica must be 1, 2, 4, 8 or 16");
+    h->nthreads = nw * 64;
+    h->have_data = true;
+    return 0;
+}
+
+int ptnn_set_state(ptnn_handle* h, const float* w0, const float* temperatures) {
+    if (!h || !w0 || !temperatures) return fail(-1, "null argument");
+    if (!h->have_data) return fail(-1, "call ptnn_set_data before ptnn_set_state");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const int Rl = h->cfg.n_replicas_local, P = h->P, PS = h->PS, S = h->cfg.n_samples;
+    std::vector<float> st((size_t)Rl * PS, 0.0f), ones((size_t)Rl * PS, 1.0f);
+    for (int r = 0; r < Rl; ++r) std::memcpy(&st[(size_t)r * PS], w0 + (size_t)r * P, P * sizeof(float));
+    HIP_TRY(hipMemcpy(h->d_state[0], st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_state[1], st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_rec_w, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));   // pos_w row 0 = ones (REG:240)
+    HIP_TRY(hipMemset(h->d_gd_w, 0, (size_t)Rl * PS * sizeof(float)));
+    HIP_TRY(hipMemset(h->d_st_f, 0, (size_t)Rl * SF_COUNT * sizeof(float)));
+    HIP_TRY(hipMemset(h->d_st_i, 0, (size_t)Rl * SI_COUNT * sizeof(int)));
+    HIP_TRY(hipMemcpy(h->d_temps, temperatures, Rl * sizeof(float), hipMemcpyHostToDevice));
+    // row 0 of every trace (Q7): pos_w = 1, likeh = -100, the rest 0
+    HIP_TRY(hipMemset(h->d_rmse_tr, 0, (size_t)Rl * S * sizeof(float)));
+    HIP_TRY(hipMemset(h->d_rmse_te, 0, (size_t)Rl * S * sizeof(float)));
+    HIP_TRY(hipMemset(h->d_acc_tr, 0, (size_t)Rl * S * sizeof(float)));
+    HIP_TRY(hipMemset(h->d_acc_te, 0, (size_t)Rl * S * sizeof(float)));
+    HIP_TRY(hipMemset(h->d_accept, 0, (size_t)Rl * S * sizeof(int)));
+    HIP_TRY(hipMemset(h->d_likeh, 0, (size_t)Rl * S * sizeof(float)));
+    std::vector<float> onesP(P, 1.0f);
+    const float m100 = -100.0f;
+    for (int r = 0; r < Rl; ++r) {
+        HIP_TRY(hipMemcpy(h->d_pos_w + (size_t)r * S * P, onesP.data(), P * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->d_likeh + (size_t)r * S, &m100, sizeof(float), hipMemcpyHostToDevice));
+    }
+    h->flip = 0; h->cur = 0; h->rounds_done = 0; h->finalized = false;
+    HIP_TRY(hipMemset(h->d_counters, 0, 2 * sizeof(long long)));
+    h->have_state = true;
+    return 0;
+}
+
+int ptnn_steps_done(ptnn_handle* h) { return h ? h->cur : -1; }
+
+int ptnn_run(ptnn_handle* h, int n_steps) {
+    if (int rc = check_ready(h)) return rc;
+    if (h->cfg.n_replicas_local != h->cfg.n_replicas_global)
+        return fail(-1, "ptnn_run drives a whole ladder on one GPU; use ptnn_run_segment + ptnn_swap_* for a sharded ladder");
+    const int S = h->cfg.n_samples;
+    const int last = S - 1;                                  // steps are i = 0 .. S-2
+    int end = (n_steps < 0) ? last : std::min(last, h->cur + n_steps);
+    while (h->cur < end) {
+        int seg_end = h->cur;
+        while (seg_end < end && !swap_trigger(h->cfg, seg_end)) ++seg_end;
+        const bool handoff = seg_end < end;                  // step seg_end triggers a hand-off
+        const int stop = handoff ? seg_end + 1 : end;
+        if (int rc = launch_segment(h, h->cur, stop - h->cur)) return rc;
+        h->cur = stop;
+        if (handoff) {
+            if (int rc = launch_swap(h, false, 3, false)) return rc;
+            h->flip ^= 1;
+            h->rounds_done += 1;
+        }
+    }
+    if (h->cur == last && !h->finalized) {
+        // Q13: the parent loops int(S/si) rounds; a round beyond the replicas' hand-offs consumes the end-of-chain
+        // vectors, is counted in swap_perc and its result is discarded
+        if (S / h->cfg.swap_interval > h->rounds_done) {
+            if (int rc = launch_swap(h, true, 2, false)) return rc;
+            h->rounds_done += 1;
+        }
+        h->finalized = true;
+    }
+    return 0;
+}
+
+int ptnn_sync(ptnn_handle* h) {
+    if (!h) return fail(-1, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    collect_timing(h);
+    return 0;
+}
+
+int ptnn_run_segment(ptnn_handle* h, int* handoff) {
+    if (int rc = check_ready(h)) return rc;
+    if (!handoff) return fail(-1, "null argument");
+    const int S = h->cfg.n_samples, last = S - 1;
+    *handoff = 0;
+    if (h->cur < last) {
+        int seg_end = h->cur;
+        while (seg_end < last && !swap_trigger(h->cfg, seg_end)) ++seg_end;
+        const bool ho = seg_end < last;
+        const int stop = ho ? seg_end + 1 : last;
+        if (int rc = launch_segment(h, h->cur, stop - h->cur)) return rc;
+        h->cur = stop;
+        if (ho) { *handoff = 1; return 0; }
+    }
+    if (h->cur == last && !h->finalized) {
+        h->finalized = true;
+        if (S / h->cfg.swap_interval > h->rounds_done) *handoff = 2;
+    }
+    return 0;
+}
+
+int ptnn_swap_L_ptr(ptnn_handle* h, int phantom, void** dev_ptr) {
+    if (!h || !dev_ptr) return fail(-1, "null argument");
+    *dev_ptr = phantom ? h->d_L_final : h->d_L_handoff;
+    return 0;
+}
+
+int ptnn_swap_set_L(ptnn_handle* h, int phantom, const float* L_host) {
+    if (!h || !L_host) return fail(-1, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(phantom ? h->d_L_final : h->d_L_handoff, L_host, h->cfg.n_replicas_global * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int ptnn_swap_cascade(ptnn_handle* h, int phantom, int32_t* src_host) {
+    if (!h || !src_host) return fail(-1, "null argument");
+    if (int rc = launch_swap(h, phantom != 0, 0, true)) return rc;
+    HIP_TRY(hipMemcpyAsync(src_host, h->d_src, h->cfg.n_replicas_global * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int ptnn_state_row_floats(ptnn_handle* h) { return h ? h->PS : -1; }
+
+int ptnn_swap_row_ptr(ptnn_handle* h, int local_replica, void** cur_row, void** next_row) {
+    if (!h) return fail(-1, "null handle");
+    if (local_replica < 0 || local_replica >= h->cfg.n_replicas_local) return fail(-1, "replica %d out of range", local_replica);
+    if (cur_row) *cur_row = h->d_state[h->flip] + (size_t)local_replica * h->PS;
+    if (next_row) *next_row = h->d_state[h->flip ^ 1] + (size_t)local_replica * h->PS;
+    return 0;
+}
+
+int ptnn_swap_apply(ptnn_handle* h, const int32_t* src_host, int phantom) {
+    if (int rc = check_ready(h)) return rc;
+    (void)src_host;   // the device recomputes the identical cascade; the host copy only routed the remote rows
+    if (int rc = launch_swap(h, phantom != 0, phantom ? 2 : 3, false)) return rc;
+    if (!phantom) h->flip ^= 1;
+    h->rounds_done += 1;
+    return 0;
+}
+
+int ptnn_get_traces(ptnn_handle* h, int step0, int nsteps, float* pos_w, float* likeh, float* rmse_train,
+                    float* rmse_test, float* acc_train, float* acc_test, int32_t* accept_count) {
+    if (int rc = check_ready(h)) return rc;
+    const int S = h->cfg.n_samples, Rl = h->cfg.n_replicas_local, P = h->P;
+    if (step0 < 0 || nsteps < 0 || step0 + nsteps > S) return fail(-1, "trace range [%d, %d) outside [0, %d)", step0, step0 + nsteps, S);
+    if (nsteps == 0) return 0;
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    collect_timing(h);
+    auto copy2d = [&](void* dst, const void* src_base, size_t elem_bytes, size_t per_step) -> hipError_t {
+        if (!dst) return hipSuccess;
+        const size_t width = (size_t)nsteps * per_step * elem_bytes;
+        const size_t spitch = (size_t)S * per_step * elem_bytes;
+        const char* src = static_cast<const char*>(src_base) + (size_t)step0 * per_step * elem_bytes;
+        return hipMemcpy2D(dst, width, src, spitch, width, Rl, hipMemcpyDeviceToHost);
+    };
+    HIP_TRY(copy2d(pos_w, h->d_pos_w, sizeof(float), P));
+    HIP_TRY(copy2d(likeh, h->d_likeh, sizeof(float), 1));
+    HIP_TRY(copy2d(rmse_train, h->d_rmse_tr, sizeof(float), 1));
+    HIP_TRY(copy2d(rmse_test, h->d_rmse_te, sizeof(float), 1));
+    HIP_TRY(copy2d(acc_train, h->d_acc_tr, sizeof(float), 1));
+    HIP_TRY(copy2d(acc_test, h->d_acc_te, sizeof(float), 1));
+    HIP_TRY(copy2d(accept_count, h->d_accept, sizeof(int), 1));
+    return 0;
+}
+
+int ptnn_get_swap_stats(ptnn_handle* h, int64_t* num_swap, int64_t* total_proposals, int32_t* rounds_done) {
+    if (!h) return fail(-1, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    long long c[2];
+    HIP_TRY(hipMemcpy(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    if (num_swap) *num_swap = c[0];
+    if (total_proposals) *total_proposals = c[1];
+    if (rounds_done) *rounds_done = h->rounds_done;
+    return 0;
+}
+
+int ptnn_get_swap_log(ptnn_handle* h, int32_t* src, int max_rounds) {
+    if (!h || !src) return fail(-1, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int n = std::min(max_rounds, std::min(h->rounds_done, h->max_rounds));
+    if (n > 0) HIP_TRY(hipMemcpy(src, h->d_src_log, (size_t)n * h->cfg.n_replicas_global * sizeof(int), hipMemcpyDeviceToHost));
+    return n;
+}
+
+int ptnn_get_state(ptnn_handle* h, float* w, float* eta, float* likelihood, float* prior, int32_t* num_accepted,
+                   int32_t* langevin_count) {
+    if (int rc = check_ready(h)) return rc;
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int Rl = h->cfg.n_replicas_local, P = h->P, PS = h->PS;
+    std::vector<float> st((size_t)Rl * PS), sf((size_t)Rl * SF_COUNT);
+    std::vector<int> si((size_t)Rl * SI_COUNT);
+    HIP_TRY(hipMemcpy(st.data(), h->d_state[h->flip], st.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sf.data(), h->d_st_f, sf.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(si.data(), h->d_st_i, si.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int r = 0; r < Rl; ++r) {
+        if (w) std::memcpy(w + (size_t)r * P, &st[(size_t)r * PS], P * sizeof(float));
+        if (eta) eta[r] = st[(size_t)r * PS + P];
+        if (likelihood) likelihood[r] = sf[(size_t)r * SF_COUNT + SF_LIK];
+        if (prior) prior[r] = sf[(size_t)r * SF_COUNT + SF_PRIOR];
+        if (num_accepted) num_accepted[r] = si[(size_t)r * SI_COUNT + SI_NACC];
+        if (langevin_count) langevin_count[r] = si[(size_t)r * SI_COUNT + SI_LG_COUNT];
+    }
+    return 0;
+}
+
+static int run_model(ptnn_handle* h, int mode, const float* w_in, const float* tau_sq, int n, float* out, size_t out_floats,
+                     int a0, int a1) {
+    if (!h) return fail(-1, "null handle");
+    if (!h->have_data) return fail(-1, "ptnn_set_data has not been called");
+    if (n < 1) return fail(-1, "n must be >= 1");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    float *d_w = nullptr, *d_tau = nullptr, *d_out = nullptr;
+    const int P = h->P;
+    if (w_in) {
+        HIP_TRY(hipMalloc(&d_w, (size_t)n * P * sizeof(float)));
+        HIP_TRY(hipMemcpy(d_w, w_in, (size_t)n * P * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (tau_sq) {
+        HIP_TRY(hipMalloc(&d_tau, (size_t)n * sizeof(float)));
+        HIP_TRY(hipMemcpy(d_tau, tau_sq, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc(&d_out, out_floats * sizeof(float)));
+    const SegParams p = h->seg_params();
+    hipLaunchKernelGGL(h->shape->model, dim3(n), dim3(h->nthreads), h->seg_lds, h->stream, p, mode, d_w, d_tau, d_out, a0, a1);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out, d_out, out_floats * sizeof(float), hipMemcpyDeviceToHost));
+    if (d_w) (void)hipFree(d_w);
+    if (d_tau) (void)hipFree(d_tau);
+    (void)hipFree(d_out);
+    return 0;
+}
+
+int ptnn_evaluate(ptnn_handle* h, const float* w, const float* tau_sq, int n, float* out) {
+    if (!w || !out) return fail(-1, "null argument");
+    if (h && h->cfg.task == PTNN_TASK_REG && !tau_sq) return fail(-1, "regression needs tau_sq");
+    return run_model(h, 0, w, tau_sq, n, out, (size_t)n * 8, 0, 0);
+}
+
+int ptnn_langevin_gradient(ptnn_handle* h, const float* w_in, int n, float* w_out) {
+    if (!w_in || !w_out) return fail(-1, "null argument");
+    return run_model(h, 1, w_in, nullptr, n, w_out, (size_t)n * (h ? h->P : 0), 0, 0);
+}
+
+int ptnn_tape(ptnn_handle* h, int replica, int step, float* noise, float* scal) {
+    if (!h || !noise || !scal) return fail(-1, "null argument");
+    std::vector<float> buf((size_t)h->P + 3);
+    if (int rc = run_model(h, 2, nullptr, nullptr, 1, buf.data(), buf.size(), replica, step)) return rc;
+    std::memcpy(noise, buf.data(), h->P * sizeof(float));
+    std::memcpy(scal, buf.data() + h->P, 3 * sizeof(float));
+    return 0;
+}
+
+int ptnn_kernel_time(ptnn_handle* h, int reset, int64_t* launches, double* total_ms) {
+    if (!h) return fail(-1, "null handle");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    collect_timing(h);
+    if (launches) *launches = h->timed_launches;
+    if (total_ms) *total_ms = h->timed_ms;
+    if (reset) { h->timed_launches = 0; h->timed_ms = 0.0; }
+    return 0;
+}
+
+int ptnn_savetxt(const char* path, const double* data, int64_t rows, int64_t cols, const char* fmt) {
+    if (!path || !data || !fmt) return fail(-1, "null argument");
+    if (rows < 0 || cols < 1) return fail(-1, "bad shape %lld x %lld", (long long)rows, (long long)cols);
+    // exactly one floating conversion: % [flags] [width] [.precision] (e|E|f|F|g|G)
+    const size_t fl = std::strlen(fmt);
+    bool ok = fl >= 2 && fl < 16 && fmt[0] == '%' && std::strchr("eEfFgG", fmt[fl - 1]) != nullptr;
+    for (size_t k = 1; ok && k + 1 < fl; ++k) ok = std::strchr("0123456789.+- #", fmt[k]) != nullptr;
+    if (!ok) return fail(-1, "unsupported format '%s'", fmt);
+    FILE* f = std::fopen(path, "w");
+    if (!f) return fail(-4, "cannot open %s for writing", path);
+    std::vector<char> buf(1 << 20);
+    size_t used = 0;
+    for (int64_t r = 0; r < rows; ++r) {
+        for (int64_t c = 0; c < cols; ++c) {
+            if (buf.size() - used < 512) {
+                if (std::fwrite(buf.data(), 1, used, f) != used) { std::fclose(f); return fail(-4, "write to %s failed", path); }
+                used = 0;
+            }
+            if (c) buf[used++] = ' ';
+            used += (size_t)std::snprintf(buf.data() + used, 400, fmt, data[r * cols + c]);
+        }
+        buf[used++] = '\n';
+    }
+    const bool wrote = std::fwrite(buf.data(), 1, used, f) == used;
+    if (std::fclose(f) != 0 || !wrote) return fail(-4, "write to %s failed", path);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,729 @@
+// ptnn_device.hpp -- gfx950 (CDNA4, wave64) device code of the parallel-tempering FNN sampler.
+//
+// One work-group owns one replica (one temperature of the ladder).  Wave 0 of the group runs the
+// inherently sequential parts (the row-by-row SGD sweep of Network.langevin_gradient, REG:99-118);
+// all NW waves share the row-parallel parts (evaluate_proposal over train+test rows, REG:120-134,
+// the Philox noise pass and the trace-row store).  Weights, the data set and every per-step
+// vector live in LDS; HBM sees only the trace rows the result-file layout requires.
+//
+// Written for gfx950 only: wave size 64, DPP row operations, v_permlane{16,32}_swap.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptnn {
+
+constexpr int TASK_REG = 0;
+constexpr int TASK_CLS = 1;
+constexpr int WAVE = 64;
+constexpr int MAX_WAVES = 16;
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float LOG_2PI = 1.8378770664093453f;
+
+// Philox4x32-10 streams (specification shared with oracle/ptnn_oracle.py)
+constexpr uint32_t STREAM_STEP = 0, STREAM_WNOISE = 1, STREAM_SWAP = 2, STREAM_INIT = 3;
+
+// per-replica float state (st_f) and int state (st_i) slots
+enum { SF_LIK = 0, SF_PRIOR, SF_TAU_LAST, SF_REC_RMSE_TR, SF_REC_RMSE_TE, SF_REC_ACC_TR, SF_REC_ACC_TE, SF_COUNT = 8 };
+enum { SI_NACC = 0, SI_GD_VALID, SI_LG_COUNT, SI_COUNT = 4 };
+
+struct SegParams {
+    int H, P, PS;            // hidden units, parameters, state row length (P + 1 rounded up to 4)
+    int Ntr, Nte, IPY, FWS;  // rows, data row stride (floats), packed forward row stride (floats)
+    int S, switch_step, use_lg;
+    int first_global;
+    float l_prob, lr, step_w, step_eta;
+    float inv_2sig2, prior_c, nu1, nu2;
+    uint32_t seed_lo, seed_hi;
+    const float* data;       // [Ntr+Nte][IPY]: x_0..x_{I-1}, y, pad
+    float* w_state;          // current (w, eta) rows [Rl][PS]
+    float* rec_w;            // last recorded pos_w row [Rl][PS]
+    float* gd_w;             // cached langevin_gradient(w) [Rl][PS]
+    float* st_f;             // [Rl][SF_COUNT]
+    int* st_i;               // [Rl][SI_COUNT]
+    const float* temps;      // [Rl]
+    float* L_handoff;        // [Rglobal] posted scalar at a hand-off (REG:430 / CLS:439)
+    float* L_final;          // [Rglobal] end-of-chain scalar (REG:442 / CLS:451)
+    float* tr_pos_w;         // [Rl][S][P]
+    float* tr_likeh;         // [Rl][S]
+    float* tr_rmse_tr; float* tr_rmse_te; float* tr_acc_tr; float* tr_acc_te;   // [Rl][S]
+    int* tr_accept;          // [Rl][S]
+};
+
+// ------------------------------------------------------------------------------------------------
+// scalar math on the hardware transcendental units
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_fast(float z) {
+    // 1 / (1 + exp(-z)) as v_mul, v_exp_f32, v_add, v_rcp_f32
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * z));
+}
+__device__ __forceinline__ float expf_fast(float x) { return __builtin_amdgcn_exp2f(LOG2E * x); }
+__device__ __forceinline__ float logf_fast(float x) { return LN2 * __builtin_amdgcn_logf(x); }
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&x)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    x[0] = c0; x[1] = c1; x[2] = c2; x[3] = c3;
+}
+// 23-bit uniform in (0,1): ((x >> 9) + 0.5) * 2^-23, exact in fp32
+__device__ __forceinline__ float u23(uint32_t x) { return fmaf((float)(x >> 9), 1.1920928955078125e-07f, 5.9604644775390625e-08f); }
+// Box-Muller: r = sqrt(-2 ln u1); (r cos 2 pi u2, r sin 2 pi u2).  v_sin/v_cos take revolutions.
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float r = __builtin_amdgcn_sqrtf(-2.0f * LN2 * __builtin_amdgcn_logf(u23(a)));
+    const float t = u23(b);
+    n0 = r * __builtin_amdgcn_cosf(t);
+    n1 = r * __builtin_amdgcn_sinf(t);
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave-wide all-lanes sum over the first 2^NRED lanes' groups: DPP inside a row of 16, permlane swaps across rows
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// after the call every lane of each aligned group of 2^NRED lanes holds that group's sum
+template <int NRED>
+__device__ __forceinline__ float group_allsum(float v) {
+    if (NRED >= 1) v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]   : lane ^ 1
+    if (NRED >= 2) v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]   : lane ^ 2
+    if (NRED >= 3) v += dpp_mov<0x141>(v);   // row_half_mirror       : 7 - lane within 8
+    if (NRED >= 4) v += dpp_mov<0x140>(v);   // row_mirror            : 15 - lane within 16
+    if (NRED >= 5) {                         // rows 0<->1, 2<->3
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+    if (NRED >= 6) {                         // lanes 0-31 <-> 32-63
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_allsum(float v) { return group_allsum<6>(v); }
+
+// ------------------------------------------------------------------------------------------------
+// LDS helpers: N floats from a 16-byte aligned address as ds_read_b128s
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void lds_load(const float* __restrict__ p, float (&v)[N]) {
+    constexpr int N4 = N / 4;
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int k = 0; k < N4; ++k) {
+        const float4 t = p4[k];
+        v[4 * k + 0] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+    }
+#pragma unroll
+    for (int k = 4 * N4; k < N; ++k) v[k] = p[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// R5  Network.langevin_gradient (REG:99-118 / CLS:114-132) on wave 0: lane h owns hidden unit h
+// (column h of W1, row h of W2, B1[h]); B2 and the outputs are replicated in every lane.  Rows are visited
+// in file order, each row is a dependent chain; the next row's inputs are fetched while this one computes.
+// Lanes >= H carry B1 = +1e30 so their hidden activation is exactly 0 and they never contribute or update.
+// ------------------------------------------------------------------------------------------------
+template <int TASK, int I, int O, int NRED>
+__device__ __forceinline__ void sgd_sweep(const float* __restrict__ w_in, float* __restrict__ w_out,
+                                          const float* __restrict__ xy, int IPY, int Ntr, int H, float lr) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const bool act = lane < H;
+    const int hl = act ? lane : 0;
+    const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
+    float w1[I], w2[O], b2[O];
+#pragma unroll
+    for (int i = 0; i < I; ++i) w1[i] = act ? w_in[i * H + hl] : 0.0f;
+#pragma unroll
+    for (int o = 0; o < O; ++o) w2[o] = act ? w_in[oW2 + hl * O + o] : 0.0f;
+    float b1 = act ? w_in[oB1 + hl] : 1.0e30f;
+#pragma unroll
+    for (int o = 0; o < O; ++o) b2[o] = w_in[oB2 + o];
+
+    float xn[I + 1];
+    lds_load<I + 1>(xy, xn);
+    for (int n = 0; n < Ntr; ++n) {
+        float x[I + 1];
+#pragma unroll
+        for (int i = 0; i <= I; ++i) x[i] = xn[i];
+        const int nn = (n + 1 < Ntr) ? n + 1 : n;
+        lds_load<I + 1>(xy + nn * IPY, xn);               // prefetch the next row (wave-uniform address)
+
+        float z = -b1;
+#pragma unroll
+        for (int i = 0; i < I; ++i) z = fmaf(x[i], w1[i], z);
+        const float hid = sigmoidf_fast(z);
+        const float dh = hid * (1.0f - hid);
+        float g = 0.0f;
+        float lod[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            const float s = group_allsum<NRED>(hid * w2[o]);
+            const float out = sigmoidf_fast(s - b2[o]);
+            float t;
+            if (TASK == TASK_CLS) t = ((int)x[I] == o) ? 1.0f : 0.0f;   // one-hot(int(y)) (CLS:73-75)
+            else t = x[I + o];                                           // REG: O == 1
+            const float od = (t - out) * (out * (1.0f - out));
+            g = fmaf(od, w2[o], g);                                      // uses the pre-update W2 (Q4)
+            lod[o] = lr * od;
+        }
+        const float lhd = lr * (g * dh);
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            w2[o] = fmaf(lod[o], hid, w2[o]);
+            b2[o] -= lod[o];
+        }
+#pragma unroll
+        for (int i = 0; i < I; ++i) w1[i] = fmaf(lhd, x[i], w1[i]);
+        b1 -= lhd;
+    }
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < I; ++i) w_out[i * H + lane] = w1[i];
+#pragma unroll
+        for (int o = 0; o < O; ++o) w_out[oW2 + lane * O + o] = w2[o];
+        w_out[oB1 + lane] = b1;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int o = 0; o < O; ++o) w_out[oB2 + o] = b2[o];
+    }
+}
+
+template <int TASK, int I, int O>
+__device__ __forceinline__ void sgd_sweep_dispatch(const float* w_in, float* w_out, const float* xy, int IPY, int Ntr,
+                                                   int H, float lr) {
+    if (H <= 4) sgd_sweep<TASK, I, O, 2>(w_in, w_out, xy, IPY, Ntr, H, lr);
+    else if (H <= 8) sgd_sweep<TASK, I, O, 3>(w_in, w_out, xy, IPY, Ntr, H, lr);
+    else if (H <= 16) sgd_sweep<TASK, I, O, 4>(w_in, w_out, xy, IPY, Ntr, H, lr);
+    else if (H <= 32) sgd_sweep<TASK, I, O, 5>(w_in, w_out, xy, IPY, Ntr, H, lr);
+    else sgd_sweep<TASK, I, O, 6>(w_in, w_out, xy, IPY, Ntr, H, lr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed forward layout: fw[h] = { W1[0..I-1][h], B1[h], W2[h][0..O-1], pad } (FWS floats, 16-B aligned rows),
+// then B2[0..O-1] at fw[H*FWS].  Built by all threads from a flat w.
+// ------------------------------------------------------------------------------------------------
+template <int I, int O>
+__device__ __forceinline__ void build_fw(const float* __restrict__ w, float* __restrict__ fw, int H, int FWS) {
+    const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
+    constexpr int K = I + 1 + O;
+    for (int e = threadIdx.x; e < H * K; e += blockDim.x) {
+        const int h = e / K, c = e - h * K;
+        float v;
+        if (c < I) v = w[c * H + h];
+        else if (c == I) v = w[oB1 + h];
+        else v = w[oW2 + h * O + (c - I - 1)];
+        fw[h * FWS + c] = v;
+    }
+    if (threadIdx.x < O) fw[H * FWS + threadIdx.x] = w[oB2 + threadIdx.x];
+}
+
+// sums produced by one evaluation of (train ++ test) under a weight vector
+struct EvalSums {
+    float a_tr, b_tr, c_tr;   // REG: SSE, -, -      CLS: sum log p(y), sum (pred-y)^2, #correct   (train rows)
+    float a_te, b_te, c_te;   // same for test rows
+};
+
+// R2/R3/R6: one lane per data row; the block's threads stride over train ++ test.  Returns block-wide sums in every
+// thread (wave DPP reduction, then a fixed-order sum of the per-wave partials through LDS).
+template <int TASK, int I, int O>
+__device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, const float* __restrict__ xy, int IPY,
+                                              int FWS, int H, int Ntr, int Nall, float* __restrict__ red) {
+    float a_tr = 0.f, b_tr = 0.f, c_tr = 0.f, a_te = 0.f, b_te = 0.f, c_te = 0.f;
+    constexpr int K = I + 1 + O;
+    float b2[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) b2[o] = fw[H * FWS + o];
+    for (int n = threadIdx.x; n < Nall; n += blockDim.x) {
+        float x[I + 1];
+        lds_load<I + 1>(xy + n * IPY, x);
+        float acc[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) acc[o] = -b2[o];
+        for (int h = 0; h < H; ++h) {
+            float f[K];
+            lds_load<K>(fw + h * FWS, f);                  // wave-uniform address: broadcast reads
+            float z = -f[I];
+#pragma unroll
+            for (int i = 0; i < I; ++i) z = fmaf(x[i], f[i], z);
+            const float hid = sigmoidf_fast(z);
+#pragma unroll
+            for (int o = 0; o < O; ++o) acc[o] = fmaf(hid, f[I + 1 + o], acc[o]);
+        }
+        const float y = x[I];
+        float a, b = 0.f, c = 0.f;
+        if (TASK == TASK_REG) {
+            const float d = y - sigmoidf_fast(acc[0]);
+            a = d * d;
+        } else {
+            float out[O];
+            float best = -1.0f, se = 0.0f, oy = 0.0f;
+            int arg = 0;
+            const int yi = (int)y;
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                out[o] = sigmoidf_fast(acc[o]);
+                if (out[o] > best) { best = out[o]; arg = o; }        // np.argmax: first maximum (CLS:55)
+                se += expf_fast(out[o]);                               // softmax of the sigmoid outputs (Q3)
+                oy = (o == yi) ? out[o] : oy;
+            }
+            a = oy - logf_fast(se);
+            const float dd = (float)arg - y;
+            b = dd * dd;
+            c = ((float)arg == y) ? 1.0f : 0.0f;
+        }
+        if (n < Ntr) { a_tr += a; b_tr += b; c_tr += c; }
+        else { a_te += a; b_te += b; c_te += c; }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    a_tr = wave_allsum(a_tr);
+    a_te = wave_allsum(a_te);
+    if (TASK == TASK_CLS) {
+        b_tr = wave_allsum(b_tr); c_tr = wave_allsum(c_tr);
+        b_te = wave_allsum(b_te); c_te = wave_allsum(c_te);
+    }
+    EvalSums s;
+    if (nw == 1) {
+        s.a_tr = a_tr; s.b_tr = b_tr; s.c_tr = c_tr; s.a_te = a_te; s.b_te = b_te; s.c_te = c_te;
+        return s;
+    }
+    __syncthreads();                                       // red[] may still be read from the previous use
+    if (lane == 0) {
+        float* r = red + wave * 8;
+        r[0] = a_tr; r[1] = b_tr; r[2] = c_tr; r[3] = a_te; r[4] = b_te; r[5] = c_te;
+    }
+    __syncthreads();
+    s.a_tr = s.b_tr = s.c_tr = s.a_te = s.b_te = s.c_te = 0.f;
+    for (int k = 0; k < nw; ++k) {
+        const float* r = red + k * 8;
+        s.a_tr += r[0]; s.b_tr += r[1]; s.c_tr += r[2]; s.a_te += r[3]; s.b_te += r[4]; s.c_te += r[5];
+    }
+    return s;
+}
+
+// block-wide sum of one value per thread, returned in every thread
+__device__ __forceinline__ float block_sum(float s, float* __restrict__ red) {
+    s = wave_allsum(s);
+    const int nw = blockDim.x >> 6;
+    if (nw == 1) return s;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * 8] = s;
+    __syncthreads();
+    float t = 0.f;
+    for (int k = 0; k < nw; ++k) t += red[k * 8];
+    return t;
+}
+
+// fx - y of one row for the O == 1 regression net (chain start-up, REG:266-270)
+template <int I, int O>
+__device__ __forceinline__ float reg_residual(const float* __restrict__ row, const float* __restrict__ fw, int FWS,
+                                              int H) {
+    constexpr int K = I + 1 + O;
+    float x[I + 1];
+    lds_load<I + 1>(row, x);
+    float acc = -fw[H * FWS];
+    for (int h = 0; h < H; ++h) {
+        float f[K];
+        lds_load<K>(fw + h * FWS, f);
+        float z = -f[I];
+#pragma unroll
+        for (int i = 0; i < I; ++i) z = fmaf(x[i], f[i], z);
+        acc = fmaf(sigmoidf_fast(z), f[I + 1], acc);
+    }
+    return sigmoidf_fast(acc) - x[I];
+}
+
+// block-wide sum of squares of a vector in LDS (prior, REG:219)
+__device__ __forceinline__ float block_sumsq(const float* __restrict__ v, int n, float* __restrict__ red) {
+    float s = 0.f;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) s = fmaf(v[j], v[j], s);
+    return block_sum(s, red);
+}
+
+// block-wide sum of squared differences (Langevin proposal ratio, REG:336-346)
+__device__ __forceinline__ float block_sumsq_diff(const float* __restrict__ a, const float* __restrict__ b, int n,
+                                                  float* __restrict__ red) {
+    float s = 0.f;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) { const float d = a[j] - b[j]; s = fmaf(d, d, s); }
+    return block_sum(s, red);
+}
+
+// likelihood / rmse / accuracy from the sums (R6: REG:200-205, CLS:209-222, 200-207); untempered log-likelihood
+template <int TASK>
+__device__ __forceinline__ void finish_eval(const EvalSums& s, int Ntr, int Nte, float eta, float& loglik,
+                                            float& rmse_tr, float& rmse_te, float& acc_tr, float& acc_te) {
+    if (TASK == TASK_REG) {
+        // sum_n [-0.5 log(2 pi tau^2) - 0.5 (y-fx)^2 / tau^2], tau^2 = exp(eta)
+        loglik = -0.5f * (float)Ntr * (LOG_2PI + eta) - 0.5f * s.a_tr * expf_fast(-eta);
+        rmse_tr = __builtin_amdgcn_sqrtf(s.a_tr / (float)Ntr);
+        rmse_te = __builtin_amdgcn_sqrtf(s.a_te / (float)Nte);
+        acc_tr = 0.f;
+        acc_te = 0.f;
+    } else {
+        loglik = s.a_tr;
+        rmse_tr = __builtin_amdgcn_sqrtf(s.b_tr / (float)Ntr);
+        rmse_te = __builtin_amdgcn_sqrtf(s.b_te / (float)Nte);
+        acc_tr = 100.0f * (s.c_tr / (float)Ntr);
+        acc_te = 100.0f * (s.c_te / (float)Nte);
+    }
+}
+
+// R7 prior_likelihood (REG:215-221 / CLS:224-230); prior_c = part1, log tau^2 = eta
+template <int TASK>
+__device__ __forceinline__ float prior_value(const SegParams& p, float sumsq, float eta) {
+    float v = p.prior_c - p.inv_2sig2 * sumsq;
+    if (TASK == TASK_REG) v = v - (1.0f + p.nu1) * eta - p.nu2 * expf_fast(-eta);
+    return v;
+}
+
+// LDS carve-up shared by the kernels
+struct Lds {
+    float* xy; float* w_cur; float* w_prop; float* w_gd; float* w_pgd; float* rec_w; float* noise; float* fw;
+    float* red; float* scal;
+};
+__device__ __forceinline__ Lds carve(float* base, int Nall, int IPY, int PS, int H, int FWS) {
+    Lds l;
+    float* q = base;
+    l.xy = q; q += Nall * IPY;
+    l.w_cur = q; q += PS;
+    l.w_prop = q; q += PS;
+    l.w_gd = q; q += PS;
+    l.w_pgd = q; q += PS;
+    l.rec_w = q; q += PS;
+    l.noise = q; q += PS;
+    l.fw = q; q += (H + 1) * FWS;
+    l.red = q; q += MAX_WAVES * 8;
+    l.scal = q; q += 8;
+    return l;
+}
+__host__ __device__ inline size_t lds_floats(int Nall, int IPY, int PS, int H, int FWS) {
+    return (size_t)Nall * IPY + 6 * (size_t)PS + (size_t)(H + 1) * FWS + MAX_WAVES * 8 + 8;
+}
+
+// random tape of one step: noise[0..P) and scal[0..2] = {lx, u, n_eta}
+__device__ __forceinline__ void tape_step(const SegParams& p, int gid, int step, float* __restrict__ noise,
+                                          float* __restrict__ scal) {
+    const int nq = (p.P + 3) >> 2;
+    for (int q = threadIdx.x; q <= nq; q += blockDim.x) {
+        const bool sc = (q == nq);
+        uint32_t x[4];
+        philox4x32_10(sc ? 0u : (uint32_t)q, (uint32_t)step, (uint32_t)gid, sc ? STREAM_STEP : STREAM_WNOISE, p.seed_lo,
+                      p.seed_hi, x);
+        float n0, n1, n2, n3;
+        box_muller(x[0], x[1], n0, n1);
+        box_muller(x[2], x[3], n2, n3);
+        if (sc) {
+            scal[0] = u23(x[0]);
+            scal[1] = u23(x[1]);
+            scal[2] = n2;
+        } else {
+            *reinterpret_cast<float4*>(noise + 4 * q) = make_float4(n0, n1, n2, n3);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The segment kernel: MH steps [step_begin, step_begin + n_steps) of every local replica; block = replica.
+// step_begin == 0 also performs the chain start-up (REG:266-285).
+// ------------------------------------------------------------------------------------------------
+template <int TASK, int I, int O>
+__global__ void segment_kernel(const SegParams p, const int step_begin, const int n_steps) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int r = blockIdx.x;
+    const int gid = p.first_global + r;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int Nall = p.Ntr + p.Nte;
+    const Lds l = carve(smem, Nall, p.IPY, p.PS, p.H, p.FWS);
+    const int P = p.P, PS = p.PS, H = p.H;
+
+    // stage the data set and this replica's vectors (coalesced)
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.data);
+        float4* dst = reinterpret_cast<float4*>(l.xy);
+        for (int e = tid; e < (Nall * p.IPY) >> 2; e += nthr) dst[e] = src[e];
+    }
+    float* gw = p.w_state + (size_t)r * PS;
+    for (int j = tid; j < PS; j += nthr) {
+        l.w_cur[j] = gw[j];
+        l.rec_w[j] = p.rec_w[(size_t)r * PS + j];
+        l.w_gd[j] = p.gd_w[(size_t)r * PS + j];
+    }
+    __syncthreads();
+
+    const float T = p.temps[r];
+    float eta = (TASK == TASK_REG) ? l.w_cur[P] : 0.0f;
+    float* sf = p.st_f + (size_t)r * SF_COUNT;
+    int* si = p.st_i + (size_t)r * SI_COUNT;
+    float lik, prior_cur, tau_eta_last, rec_rmse_tr, rec_rmse_te, rec_acc_tr, rec_acc_te;
+    int nacc, gd_valid, lg_count;
+
+    if (step_begin == 0) {
+        // R14 chain start-up: eta0 = log var(fx_train(w0) - y) (REG:270), prior (REG:280), tempered likelihood (REG:284)
+        build_fw<I, O>(l.w_cur, l.fw, H, p.FWS);
+        __syncthreads();
+        if (TASK == TASK_REG) {
+            // population variance of the residuals (np.var), two passes over the train rows
+            float s1 = 0.f;
+            for (int n = tid; n < p.Ntr; n += nthr) s1 += reg_residual<I, O>(l.xy + n * p.IPY, l.fw, p.FWS, H);
+            const float mean = block_sum(s1, l.red) / (float)p.Ntr;
+            float s2 = 0.f;
+            for (int n = tid; n < p.Ntr; n += nthr) {
+                const float d = reg_residual<I, O>(l.xy + n * p.IPY, l.fw, p.FWS, H) - mean;
+                s2 = fmaf(d, d, s2);
+            }
+            eta = logf_fast(block_sum(s2, l.red) / (float)p.Ntr);
+        }
+        const EvalSums s0 = eval_rows<TASK, I, O>(l.fw, l.xy, p.IPY, p.FWS, H, p.Ntr, Nall, l.red);
+        float ll, r1, r2, a1, a2;
+        finish_eval<TASK>(s0, p.Ntr, p.Nte, eta, ll, r1, r2, a1, a2);
+        lik = ll / T;
+        const float ss = block_sumsq(l.w_cur, P, l.red);
+        prior_cur = prior_value<TASK>(p, ss, eta);
+        tau_eta_last = eta;
+        rec_rmse_tr = rec_rmse_te = rec_acc_tr = rec_acc_te = 0.f;
+        nacc = 0; gd_valid = 0; lg_count = 0;
+        __syncthreads();
+    } else {
+        lik = sf[SF_LIK]; prior_cur = sf[SF_PRIOR]; tau_eta_last = sf[SF_TAU_LAST];
+        rec_rmse_tr = sf[SF_REC_RMSE_TR]; rec_rmse_te = sf[SF_REC_RMSE_TE];
+        rec_acc_tr = sf[SF_REC_ACC_TR]; rec_acc_te = sf[SF_REC_ACC_TE];
+        nacc = si[SI_NACC]; gd_valid = si[SI_GD_VALID]; lg_count = si[SI_LG_COUNT];
+    }
+
+    const size_t trow = (size_t)r * p.S;
+    for (int i = step_begin; i < step_begin + n_steps; ++i) {
+        // R10 temperature schedule (REG:317-324): tempered until the switch step, canonical afterwards
+        float adapttemp = (p.switch_step >= 0 && i >= p.switch_step) ? 1.0f : T;
+        if (i == p.switch_step) {
+            // re-evaluate the current w with the LAST PROPOSED tau (Q9, REG:322)
+            build_fw<I, O>(l.w_cur, l.fw, H, p.FWS);
+            __syncthreads();
+            const EvalSums sc = eval_rows<TASK, I, O>(l.fw, l.xy, p.IPY, p.FWS, H, p.Ntr, Nall, l.red);
+            float ll, r1, r2, a1, a2;
+            finish_eval<TASK>(sc, p.Ntr, p.Nte, tau_eta_last, ll, r1, r2, a1, a2);
+            lik = ll;                                       // adapttemp == 1
+            __syncthreads();
+        }
+        tape_step(p, gid, i, l.noise, l.scal);
+        __syncthreads();
+        const float lx = l.scal[0], u = l.scal[1], n_eta = l.scal[2];
+        float diff_prop = 0.0f;
+        const bool lg = p.use_lg && (lx < p.l_prob);
+        if (lg) {
+            // Langevin proposal (REG:329-347): w_gd = SGD epoch from w (cached while w is unchanged),
+            // w_proposal = w_gd + step_w * noise, w_prop_gd = SGD epoch from w_proposal
+            if (!gd_valid) {
+                if (tid < WAVE) sgd_sweep_dispatch<TASK, I, O>(l.w_cur, l.w_gd, l.xy, p.IPY, p.Ntr, H, p.lr);
+                gd_valid = 1;
+                __syncthreads();
+            }
+            for (int j = tid; j < P; j += nthr) l.w_prop[j] = fmaf(p.step_w, l.noise[j], l.w_gd[j]);
+            __syncthreads();
+            if (tid < WAVE) sgd_sweep_dispatch<TASK, I, O>(l.w_prop, l.w_pgd, l.xy, p.IPY, p.Ntr, H, p.lr);
+            __syncthreads();
+            // first - second = [-0.5 |w - w_prop_gd|^2 + 0.5 |w_proposal - w_gd|^2] / step_w^2; the second norm is
+            // step_w^2 |noise|^2 exactly in real arithmetic
+            const float d1 = block_sumsq_diff(l.w_cur, l.w_pgd, P, l.red);
+            const float d2 = block_sumsq(l.noise, P, l.red);
+            diff_prop = (-0.5f * d1 / (p.step_w * p.step_w) + 0.5f * d2) / adapttemp;   // Q6
+            lg_count += 1;
+        } else {
+            for (int j = tid; j < P; j += nthr) l.w_prop[j] = fmaf(p.step_w, l.noise[j], l.w_cur[j]);
+            __syncthreads();
+        }
+        float eta_pro = eta;
+        if (TASK == TASK_REG) { eta_pro = fmaf(p.step_eta, n_eta, eta); tau_eta_last = eta_pro; }
+
+        build_fw<I, O>(l.w_prop, l.fw, H, p.FWS);
+        __syncthreads();
+        const EvalSums es = eval_rows<TASK, I, O>(l.fw, l.xy, p.IPY, p.FWS, H, p.Ntr, Nall, l.red);
+        float ll, rm_tr, rm_te, ac_tr, ac_te;
+        finish_eval<TASK>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
+        const float lik_prop = ll / adapttemp;
+        const float ssq = block_sumsq(l.w_prop, P, l.red);
+        const float prior_prop = prior_value<TASK>(p, ssq, eta_pro);
+
+        // R9 Metropolis-Hastings (REG:372-423): NaN -> accept (Q8), overflow -> 1
+        const float logalpha = (lik_prop - lik) + (prior_prop - prior_cur) + diff_prop;
+        const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
+        const bool accept = u < mh;
+        const int acc_before = nacc;
+        if (accept) {
+            nacc += 1;
+            lik = lik_prop;
+            prior_cur = prior_prop;
+            eta = eta_pro;
+            rec_rmse_tr = rm_tr; rec_rmse_te = rm_te;
+            rec_acc_tr = ac_tr; rec_acc_te = ac_te;       // REG: 0 (REG:403-404); CLS: accuracy (CLS:414-415)
+            gd_valid = 0;
+            for (int j = tid; j < P; j += nthr) { const float v = l.w_prop[j]; l.w_cur[j] = v; l.rec_w[j] = v; }
+        }
+        __syncthreads();
+        // trace row i+1 (the only HBM traffic of a step)
+        float* prow = p.tr_pos_w + (trow + i + 1) * (size_t)P;
+        for (int j = tid; j < P; j += nthr) prow[j] = l.rec_w[j];
+        if (tid == 0) {
+            p.tr_likeh[trow + i + 1] = (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp;   // REG:391 / CLS:404
+            p.tr_accept[trow + i + 1] = acc_before;                                            // REG:380
+            p.tr_rmse_tr[trow + i + 1] = rec_rmse_tr;
+            p.tr_rmse_te[trow + i + 1] = rec_rmse_te;
+            p.tr_acc_tr[trow + i + 1] = rec_acc_tr;
+            p.tr_acc_te[trow + i + 1] = rec_acc_te;
+        }
+    }
+
+    // write the chain state back and post the swap scalars
+    __syncthreads();
+    for (int j = tid; j < PS; j += nthr) {
+        gw[j] = (j == P) ? eta : l.w_cur[j];
+        p.rec_w[(size_t)r * PS + j] = l.rec_w[j];
+        p.gd_w[(size_t)r * PS + j] = l.w_gd[j];
+    }
+    if (tid == 0) {
+        sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur; sf[SF_TAU_LAST] = tau_eta_last;
+        sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;
+        sf[SF_REC_ACC_TR] = rec_acc_tr; sf[SF_REC_ACC_TE] = rec_acc_te;
+        si[SI_NACC] = nacc; si[SI_GD_VALID] = gd_valid; si[SI_LG_COUNT] = lg_count;
+        p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;      // Q11
+        p.L_final[gid] = lik;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// R12 swap cascade (REG:659-690, 741-748): one sequential bubble pass over the ladder.  Every block recomputes it
+// (R <= a few thousand scalars), then block b moves the (w, eta) row for local replica b.
+// ------------------------------------------------------------------------------------------------
+struct SwapParams {
+    int R, Rl, first_global, PS;
+    uint32_t seed_lo, seed_hi;
+    const float* L;            // [R] posted scalars
+    const float* cur;          // [Rl][PS]
+    float* next;               // [Rl][PS]
+    int* st_i;                 // [Rl][SI_COUNT]
+    int* src_out;              // [R] (may be null)
+    long long* counters;       // [0] num_swap, [1] total_swap_proposals
+    int* src_log;              // [max_rounds][R] (may be null)
+    int log_capacity;
+};
+
+// sSrc has R + 1 ints: the last one carries the number of accepted swaps
+__device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, float* sL, float* sU, int* sSrc) {
+    const int R = sp.R;
+    for (int k = threadIdx.x; k < R; k += blockDim.x) {
+        sL[k] = sp.L[k];
+        if (k < R - 1) {
+            uint32_t x[4];
+            philox4x32_10((uint32_t)k, (uint32_t)round, 0u, STREAM_SWAP, sp.seed_lo, sp.seed_hi, x);
+            sU[k] = u23(x[0]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0, nsw = 0;
+        for (int k = 0; k < R - 1; ++k) {
+            float d = sL[k + 1] - sL[c];
+            d = (d < 709.0f) ? d : 709.0f;                  // python min(709, nan) == 709
+            const float pr = fminf(1.0f, 0.5f * expf_fast(d));
+            if (sU[k] < pr) { sSrc[k] = k + 1; nsw++; }
+            else { sSrc[k] = c; c = k + 1; }
+        }
+        sSrc[R - 1] = c;
+        sSrc[R] = nsw;
+    }
+    __syncthreads();
+    return sSrc[R];
+}
+
+// mode bit 0: apply the local moves; bit 1: count the round and log it
+__global__ void swap_kernel(const SwapParams sp, const int round, const int mode) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sL = smem;
+    float* sU = smem + sp.R;
+    int* sSrc = reinterpret_cast<int*>(smem + 2 * sp.R);
+    const int nsw = cascade_lds(sp, round, sL, sU, sSrc);
+    const int b = blockIdx.x;
+    if (mode & 1) {
+        const int k = sp.first_global + b;
+        const int s = sSrc[k];
+        const int sl = s - sp.first_global;
+        if (sl >= 0 && sl < sp.Rl) {
+            const float* from = sp.cur + (size_t)sl * sp.PS;
+            float* to = sp.next + (size_t)b * sp.PS;
+            for (int j = threadIdx.x; j < sp.PS; j += blockDim.x) to[j] = from[j];
+        }
+        if (s != k && threadIdx.x == 0) sp.st_i[(size_t)b * SI_COUNT + SI_GD_VALID] = 0;
+    }
+    if (b == 0) {
+        if (sp.src_out) for (int k = threadIdx.x; k < sp.R; k += blockDim.x) sp.src_out[k] = sSrc[k];
+        if (mode & 2) {
+            if (sp.src_log && round < sp.log_capacity)
+                for (int k = threadIdx.x; k < sp.R; k += blockDim.x) sp.src_log[(size_t)round * sp.R + k] = sSrc[k];
+            if (threadIdx.x == 0) { sp.counters[0] += nsw; sp.counters[1] += sp.R - 1; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone model functions (same device code): mode 0 = evaluate, 1 = langevin_gradient, 2 = tape
+// ------------------------------------------------------------------------------------------------
+template <int TASK, int I, int O>
+__global__ void model_kernel(const SegParams p, const int mode, const float* __restrict__ w_in,
+                             const float* __restrict__ tau_sq, float* __restrict__ out, int a0, int a1) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int Nall = p.Ntr + p.Nte;
+    const Lds l = carve(smem, Nall, p.IPY, p.PS, p.H, p.FWS);
+    if (mode == 2) {
+        tape_step(p, a0, a1, l.noise, l.scal);
+        __syncthreads();
+        for (int j = tid; j < p.P; j += nthr) out[j] = l.noise[j];
+        if (tid < 3) out[p.P + tid] = l.scal[tid];
+        return;
+    }
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.data);
+        float4* dst = reinterpret_cast<float4*>(l.xy);
+        for (int e = tid; e < (Nall * p.IPY) >> 2; e += nthr) dst[e] = src[e];
+    }
+    for (int j = tid; j < p.P; j += nthr) l.w_cur[j] = w_in[(size_t)b * p.P + j];
+    __syncthreads();
+    if (mode == 1) {
+        if (tid < WAVE) sgd_sweep_dispatch<TASK, I, O>(l.w_cur, l.w_gd, l.xy, p.IPY, p.Ntr, p.H, p.lr);
+        __syncthreads();
+        for (int j = tid; j < p.P; j += nthr) out[(size_t)b * p.P + j] = l.w_gd[j];
+        return;
+    }
+    build_fw<I, O>(l.w_cur, l.fw, p.H, p.FWS);
+    __syncthreads();
+    const EvalSums s = eval_rows<TASK, I, O>(l.fw, l.xy, p.IPY, p.FWS, p.H, p.Ntr, Nall, l.red);
+    const float eta = (TASK == TASK_REG) ? logf_fast(tau_sq[b]) : 0.0f;
+    float ll, r1, r2, a_tr, a_te;
+    finish_eval<TASK>(s, p.Ntr, p.Nte, eta, ll, r1, r2, a_tr, a_te);
+    const float ss = block_sumsq(l.w_cur, p.P, l.red);
+    const float pr = prior_value<TASK>(p, ss, eta);
+    float ll_te = s.a_te;
+    if (TASK == TASK_REG) ll_te = -0.5f * (float)p.Nte * (LOG_2PI + eta) - 0.5f * s.a_te * expf_fast(-eta);
+    if (tid == 0) {
+        float* o = out + (size_t)b * 8;
+        o[0] = ll; o[1] = r1; o[2] = r2; o[3] = a_tr; o[4] = a_te; o[5] = pr; o[6] = ll_te; o[7] = 0.f;
+    }
+}
+
+}  // namespace ptnn

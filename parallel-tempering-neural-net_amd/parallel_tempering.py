@@ -1,0 +1,233 @@
+"""Host side of the drop-in: the public surface of the reference's `ParallelTempering` class.
+
+Reference: REG = multicore-pt-regression/pt_timeseries_regression.py:487-875,
+           CLS = multicore-pt-classification/pt_classification.py:497-897.
+
+What `main()` touches (REG:995-1007, CLS:1080-1092) is kept: the constructor arguments, `make_directory`,
+`initialize_chains(burn_in)`, `run_chains()` with its 11-tuple, the attributes `num_swap`,
+`total_swap_proposals`, `temperatures`, `NumSamples`, `num_param`, and every file under `path`
+(SURVEY.md section 8b).  What happens in between -- one forked process per replica, queues and events --
+is replaced by libptnn.so: all replicas advance inside one HIP kernel per swap interval and the swap
+cascade is a second kernel; this module only configures the run, fetches the traces and writes the files.
+"""
+import math
+import os
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import _lib, ladder, philox
+
+TASK_REG, TASK_CLS = _lib.TASK_REG, _lib.TASK_CLS
+
+
+def _text_round(a, fmt):
+    """Values as np.loadtxt would read them back from np.savetxt(..., fmt=fmt) (show_results re-reads the files)."""
+    a = np.asarray(a, dtype=np.float64)
+    return np.char.mod(fmt, a.reshape(-1)).astype(np.float64).reshape(a.shape)
+
+
+class ParallelTemperingBase:
+    task = None                       # set by the two drop-in subclasses
+    rmse_fmt = None                   # REG '%1.8f' (REG:462-464), CLS '%1.2f' (CLS:473-475)
+
+    def __init__(self, use_langevin_gradients, learn_rate, traindata, testdata, topology, num_chains, maxtemp,
+                 NumSample, swap_interval, langevin_prob, path, *, seed=None, device=None, waves_per_replica=0,
+                 write_files=True, io_threads=None):
+        # FNN chain variables (REG:491-494)
+        self.traindata = traindata
+        self.testdata = testdata
+        self.topology = topology
+        self.num_param = (topology[0] * topology[1]) + (topology[1] * topology[2]) + topology[1] + topology[2]
+        # parallel tempering variables (REG:496-507)
+        self.swap_interval = swap_interval
+        self.path = path
+        self.maxtemp = maxtemp
+        self.langevin_prob = langevin_prob
+        self.num_swap = 0
+        self.total_swap_proposals = 0
+        self.num_chains = num_chains
+        self.chains = []
+        self.temperatures = []
+        self.NumSamples = int(NumSample / self.num_chains)
+        self.sub_sample_size = max(1, int(0.05 * self.NumSamples))
+        self.geometric = True
+        self.learn_rate = learn_rate
+        self.use_langevin_gradients = use_langevin_gradients
+        # build-specific knobs (keyword only; defaults reproduce the reference's behaviour)
+        if seed is None:
+            seed = int.from_bytes(os.urandom(8), "little")       # the reference never seeds its generators
+        self.seed = int(seed)
+        self.device = int(os.environ.get("PTNN_DEVICE", "0")) if device is None else int(device)
+        self.waves_per_replica = int(waves_per_replica)
+        self.write_files = bool(write_files)
+        self.io_threads = io_threads or min(16, os.cpu_count() or 1)
+        self.timings = {}
+        self._sampler = None
+        self._w0 = None
+
+    # ------------------------------------------------------------------ ladder (REG:529-636)
+    def default_beta_ladder(self, ndim, ntemps, Tmax):
+        return ladder.default_beta_ladder(ndim, ntemps=ntemps, Tmax=Tmax)
+
+    def assign_temperatures(self):
+        if self.geometric:
+            betas = self.default_beta_ladder(2, ntemps=self.num_chains, Tmax=self.maxtemp)
+            for i in range(0, self.num_chains):
+                self.temperatures.append(np.inf if betas[i] == 0 else float(1.0 / betas[i]))
+        else:                                   # linear spacing branch (REG:629-636), unreachable from main()
+            tmpr_rate = self.maxtemp / self.num_chains
+            temp = 1
+            for i in range(0, self.num_chains):
+                self.temperatures.append(temp)
+                temp += tmpr_rate
+
+    # ------------------------------------------------------------------ initialize_chains (REG:639-650)
+    def initialize_chains(self, burn_in):
+        self.burn_in = burn_in
+        self.assign_temperatures()
+        self.minlim_param = np.repeat([-100], self.num_param)
+        self.maxlim_param = np.repeat([100], self.num_param)
+        # w0 per chain: the reference draws np.random.randn(num_param) in the parent (REG:649); here the
+        # draws come from Philox stream 3 keyed by (seed, chain) so that a run is reproducible from `seed`
+        self._w0 = np.stack([philox.initial_weights(self.seed, r, self.num_param) for r in range(self.num_chains)])
+        self._configure()
+
+    def set_initial_weights(self, w0):
+        """Override the initial weights (tests / resuming from a known state); shape [num_chains, num_param]."""
+        w0 = np.asarray(w0, dtype=np.float64)
+        if w0.shape != (self.num_chains, self.num_param):
+            raise ValueError("w0 must be [num_chains, num_param]")
+        self._w0 = w0
+        if self._sampler is not None:
+            self._sampler.set_state(self._w0, self.temperatures)
+
+    def _pt_switch_step(self):
+        # `i == pt_samples` with pt_samples = samples * 0.6 compares an int with a float (REG:301,320): it fires
+        # only when the product is integral in double arithmetic
+        pt_samples = self.NumSamples * 0.6
+        return int(pt_samples) if pt_samples == int(pt_samples) else -1
+
+    def _configure(self):
+        I, H, O = (int(v) for v in self.topology)
+        S = self.NumSamples
+        if self.swap_interval < 1:
+            raise ZeroDivisionError("integer division or modulo by zero")      # `i % self.swap_interval` (REG:427)
+        train = np.asarray(self.traindata, dtype=np.float64)
+        test = np.asarray(self.testdata, dtype=np.float64)
+        if train.ndim != 2 or train.shape[1] <= I:
+            raise IndexError(f"index {I} is out of bounds for axis 1 with size {train.shape[1] if train.ndim == 2 else 0}")
+        lib = _lib.load_library()
+        if not lib.ptnn_supports(self.task, I, H, O):
+            raise _lib.PtnnError(f"no gfx950 kernel for task={self.task} topology={[I, H, O]} in {_lib.library_path()}: "
+                                 f"add X({self.task}, {I}, {O}) to PTNN_SHAPES (csrc/ptnn.hip) and rebuild; n_hidden <= 64")
+        self._sampler = _lib.Sampler(
+            device_id=self.device, task=self.task, n_in=I, n_hidden=H, n_out=O,
+            n_replicas_local=self.num_chains, n_replicas_global=self.num_chains, first_global_replica=0,
+            n_samples=S, swap_interval=int(self.swap_interval), pt_switch_step=self._pt_switch_step(),
+            use_langevin=1 if self.use_langevin_gradients is True else 0, waves_per_replica=self.waves_per_replica,
+            l_prob=float(self.langevin_prob), learn_rate=float(self.learn_rate), step_w=0.025, step_eta=0.2,
+            sigma_squared=25.0, nu_1=0.0, nu_2=0.0, seed=self.seed)
+        self._sampler.set_data(train, test)
+        self._sampler.set_state(self._w0, self.temperatures)
+
+    # ------------------------------------------------------------------ run_chains (REG:694-771)
+    def run_chains(self):
+        if self._sampler is None:
+            raise RuntimeError("call initialize_chains(burn_in) before run_chains()")
+        S = self.NumSamples
+        open(self.path + '/num_exchange.txt', 'a').close()                      # REG:704: opened, never written
+        t0 = time.perf_counter()
+        self._sampler.run(-1)
+        self._sampler.sync()
+        t1 = time.perf_counter()
+        self.num_swap, self.total_swap_proposals, self.rounds = self._sampler.swap_stats()
+        tr = self._sampler.traces()
+        t2 = time.perf_counter()
+        if self.write_files:
+            self._write_chain_files(tr)
+        t3 = time.perf_counter()
+        out = self.show_results(tr)
+        t4 = time.perf_counter()
+        nlaunch, kms = self._sampler.kernel_time()
+        self.timings = dict(sampling_s=t1 - t0, fetch_s=t2 - t1, chain_files_s=t3 - t2, show_results_s=t4 - t3,
+                            segment_launches=nlaunch, segment_kernel_ms=kms,
+                            samples_per_s=self.num_chains * (S - 1) / max(t1 - t0, 1e-12))
+        pos_w, fx_train, fx_test, rmse_train, rmse_test, acc_train, acc_test, likelihood_vec, accept_vec, accept = out
+        swap_perc = self.num_swap * 100 / self.total_swap_proposals            # ZeroDivisionError when no round ran (REG:769)
+        return (pos_w, fx_train, fx_test, rmse_train, rmse_test, acc_train, acc_test, likelihood_vec, swap_perc,
+                accept_vec, accept)
+
+    # ------------------------------------------------------------------ per-chain files (REG:454-481)
+    def _chain_file_jobs(self, tr):
+        S = self.NumSamples
+        jobs = []
+        for r, T in enumerate(self.temperatures):
+            tn = str(T)
+            likeh = np.zeros((S, 2))
+            likeh[:, 0] = tr["likeh"][r]
+            likeh[0, 1] = -100.0                                                 # row 0 = [-100, -100] (REG:293)
+            acc_ratio = int(self._final_accepted[r]) / (S * 1.0) * 100                 # REG:447
+            jobs += [
+                (f'{self.path}/posterior/pos_w/chain_{tn}.txt', tr["pos_w"][r], '%.18e'),
+                (f'{self.path}/predictions/rmse_test_chain_{tn}.txt', tr["rmse_test"][r], self.rmse_fmt),
+                (f'{self.path}/predictions/rmse_train_chain_{tn}.txt', tr["rmse_train"][r], self.rmse_fmt),
+                (f'{self.path}/predictions/acc_test_chain_{tn}.txt', tr["acc_test"][r], '%1.2f'),
+                (f'{self.path}/predictions/acc_train_chain_{tn}.txt', tr["acc_train"][r], '%1.2f'),
+                (f'{self.path}/posterior/pos_likelihood/chain_{tn}.txt', likeh, '%1.4f'),
+                (f'{self.path}/posterior/accept_list/chain_{tn}_accept.txt', np.array([acc_ratio]), '%1.4f'),
+                (f'{self.path}/posterior/accept_list/chain_{tn}.txt', tr["accept"][r], '%1.4f'),
+            ]
+        return jobs
+
+    def _write_chain_files(self, tr):
+        # accept_list[i+1] holds the count BEFORE step i (REG:380); the percentage file uses the final count
+        self._final_accepted = self._sampler.state()["num_accepted"]
+        jobs = self._chain_file_jobs(tr)
+        with ThreadPoolExecutor(max_workers=self.io_threads) as ex:
+            list(ex.map(lambda j: _lib.savetxt(*j), jobs))
+
+    # ------------------------------------------------------------------ show_results (REG:775-871 / CLS:780-893)
+    def _likelihood_rows(self, burnin):
+        raise NotImplementedError
+
+    def show_results(self, tr=None):
+        if tr is None:
+            tr = self._sampler.traces()
+        S, R, P = self.NumSamples, self.num_chains, self.num_param
+        burnin = int(S * self.burn_in)
+        # the reference re-reads the per-chain text files, so every value below has been through their format
+        pos_w = tr["pos_w"][:, burnin:, :].astype(np.float64)                    # '%.18e' round-trips exactly
+        rmse_train = _text_round(tr["rmse_train"][:, burnin:], self.rmse_fmt)
+        rmse_test = _text_round(tr["rmse_test"][:, burnin:], self.rmse_fmt)
+        acc_train = _text_round(tr["acc_train"][:, burnin:], '%1.2f')
+        acc_test = _text_round(tr["acc_test"][:, burnin:], '%1.2f')
+        accept_list = tr["accept"].astype(np.float64)
+        lo = self._likelihood_rows(burnin)
+        likelihood_rep = np.zeros((R, S - lo, 2))
+        likelihood_rep[:, :, 0] = _text_round(tr["likeh"][:, lo:], '%1.4f')
+        if lo == 0:
+            likelihood_rep[:, 0, 1] = -100.0
+        accept_percent = np.zeros((R, 1))                                        # never filled (REG:780,860)
+
+        fx_train_all = np.zeros((R, S - burnin, np.asarray(self.traindata).shape[0]))
+        fx_test_all = np.zeros((R, S - burnin, np.asarray(self.testdata).shape[0]))
+        posterior = pos_w.transpose(2, 0, 1).reshape(P, -1)
+        likelihood_vec = likelihood_rep.transpose(2, 0, 1).reshape(2, -1)
+        rmse_train = rmse_train.reshape(R * (S - burnin), 1)
+        acc_train = acc_train.reshape(R * (S - burnin), 1)
+        rmse_test = rmse_test.reshape(R * (S - burnin), 1)
+        acc_test = acc_test.reshape(R * (S - burnin), 1)
+        accept_vec = accept_list
+        accept = np.sum(accept_percent) / R
+        if self.write_files:
+            _lib.savetxt(self.path + '/likelihood.txt', likelihood_vec.T, '%1.5f')
+            _lib.savetxt(self.path + '/accept_list.txt', accept_list, '%1.2f')
+            _lib.savetxt(self.path + '/acceptpercent.txt', np.array([accept]), '%1.2f')
+        return (posterior, fx_train_all, fx_test_all, rmse_train, rmse_test, acc_train, acc_test, likelihood_vec.T,
+                accept_vec, accept)
+
+    def make_directory(self, directory):
+        if not os.path.exists(directory):
+            os.makedirs(directory)

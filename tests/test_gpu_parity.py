@@ -1,0 +1,289 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes -> libptnn.so), against the CPU oracle on the same
+seeded inputs and against the golden vectors the reference itself produced.  Run on a real MI355X: pytest -m gpu."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import parity
+from parity import orc
+
+pytestmark = pytest.mark.gpu
+
+DS = None
+
+
+def ds():
+    global DS
+    if DS is None:
+        DS = parity.datasets()
+    return DS
+
+
+FUNC_CASES = {"reg_sunspot_4_5_1": "sunspot", "reg_mackey_4_10_1": "mackey", "cls_iris_4_12_3": "iris",
+              "cls_ions_34_50_2": "ions"}
+
+
+def test_library_is_the_hip_build():
+    import ptnn_amd
+    lib = ptnn_amd.load_library()
+    assert lib.ptnn_abi_version() == 1
+    assert lib.ptnn_supports(0, 4, 5, 1) == 1 and lib.ptnn_supports(1, 34, 50, 2) == 1
+    assert lib.ptnn_supports(0, 4, 65, 1) == 0 and lib.ptnn_supports(0, 7, 5, 1) == 0
+
+
+@pytest.mark.parametrize("waves", [1, 4])
+def test_random_tape_matches_spec(waves):
+    d = ds()
+    for topo, task, name in (((4, 5, 1), 0, "sunspot"), ((34, 50, 2), 1, "ions")):
+        s = parity.make_sampler(task, topo, d[name + "_train"], d[name + "_test"], R_local=2, R_global=2, first=0, S=10,
+                                si=100, use_lg=False, lr=0.1, seed=0x1234567890ABCDEF, waves=waves)
+        tape = orc.PhiloxTape(0x1234567890ABCDEF)
+        P = orc.num_param(topo)
+        for rep, step in ((0, 0), (1, 7), (63, 9999), (1023, 123456)):
+            noise, scal = s.tape(rep, step)
+            lx, u, n_eta = tape.step_scalars(rep, step)
+            assert scal[0] == np.float32(lx) and scal[1] == np.float32(u)      # 23-bit uniforms are exact
+            ref = tape.w_noise(rep, step, P)
+            # v_sin/v_cos/v_log/v_sqrt vs libm: absolute error of a standard normal
+            np.testing.assert_allclose(noise, ref, rtol=0, atol=2e-5)
+            assert abs(scal[2] - n_eta) < 2e-5
+        s.close()
+
+
+@pytest.mark.parametrize("key", list(FUNC_CASES))
+@pytest.mark.parametrize("waves", [1, 8])
+def test_model_functions_against_reference_vectors(key, waves):
+    """F1-F3: evaluate_proposal + likelihood_func + prior_likelihood + langevin_gradient vs values computed by the
+    reference's own Network / ptReplica methods (tests/golden/functions_*.npz)."""
+    g = parity.golden(f"functions_{key}.npz")
+    topo = tuple(int(v) for v in g["topology"])
+    task = int(g["task"])
+    d = ds()
+    train, test = d[FUNC_CASES[key] + "_train"], d[FUNC_CASES[key] + "_test"]
+    for lr in (0.1, 0.01):
+        s = parity.make_sampler(task, topo, train, test, R_local=2, R_global=2, first=0, S=10, si=100, use_lg=True, lr=lr,
+                                seed=1, waves=waves)
+        for wi in range(3):
+            w = g[f"w{wi}"]
+            out = s.langevin_gradient(w)[0]
+            np.testing.assert_allclose(out, g[f"lg{wi}_lr{lr}"], rtol=1e-4, atol=2e-5)
+            if lr == 0.1:
+                if task == 0:
+                    for tau in (0.01, 0.1):
+                        ev = s.evaluate(w, tau)[0]
+                        lik_T1, rm = g[f"lik{wi}_T1.0_tau{tau}"]
+                        np.testing.assert_allclose(ev[0], lik_T1, rtol=2e-5, atol=1e-3)
+                        np.testing.assert_allclose(ev[1], rm, rtol=1e-5)
+                        np.testing.assert_allclose(ev[2], g[f"liktest{wi}_T1.0_tau{tau}"][1], rtol=1e-5)
+                        np.testing.assert_allclose(ev[6], g[f"liktest{wi}_T1.0_tau{tau}"][0], rtol=2e-5, atol=1e-3)
+                        np.testing.assert_allclose(ev[5], g[f"prior{wi}_tau{tau}"], rtol=2e-6, atol=1e-4)
+                else:
+                    ev = s.evaluate(w)[0]
+                    lik, rm, acc = g[f"lik{wi}_T1.0"]
+                    np.testing.assert_allclose(ev[0], lik, rtol=2e-5, atol=1e-3)
+                    np.testing.assert_allclose([ev[1], ev[3]], [rm, acc], rtol=1e-5)
+                    lik_te, rm_te, acc_te = g[f"liktest{wi}_T1.0"]
+                    np.testing.assert_allclose([ev[2], ev[4]], [rm_te, acc_te], rtol=1e-5)
+                    np.testing.assert_allclose(ev[6], lik_te, rtol=2e-5, atol=1e-3)
+                    np.testing.assert_allclose(ev[5], g[f"prior{wi}"], rtol=2e-6, atol=1e-4)
+        s.close()
+
+
+TRAJ = ["reg_rw", "reg_lg", "reg_lg_mackey", "cls_rw", "cls_lg", "cls_rw_ions", "reg_rw_noswitch"]
+
+
+@pytest.mark.parametrize("key", TRAJ)
+@pytest.mark.parametrize("waves", [1, 4])
+def test_single_replica_trajectory(key, waves):
+    """F4: one chain (no swaps) against the trace the reference's ptReplica.run produced on the same random tape."""
+    g = parity.golden(f"trajectory_{key}.npz")
+    topo = tuple(int(v) for v in g["topology"])
+    task, S, gid, seed = int(g["task"]), int(g["S"]), int(g["gid"]), int(g["seed"])
+    d = ds()
+    dname = str(g["dataset"])
+    train, test = d[dname + "_train"], d[dname + "_test"]
+    w0 = g["w0"].astype(np.float32)
+    # oracle on the fp32-rounded start (so both sides start from the same numbers) with log alpha recorded
+    tape = orc.PhiloxTape(seed)
+    rep = orc.Replica(task, topo, train, test, w0.astype(np.float64), float(g["T"]), S, bool(g["use_lg"]), 0.5,
+                      float(g["lr"]), tape, gid)
+    la, lu = np.zeros(S), np.zeros(S)
+    for i in range(S - 1):
+        rep.step(i)
+        la[i], lu[i] = rep.last_logalpha, np.log(rep.last_u)
+    s = parity.make_sampler(task, topo, train, test, R_local=1, R_global=8, first=gid, S=S, si=10 * S,
+                            use_lg=bool(g["use_lg"]), lr=float(g["lr"]), seed=seed, waves=waves)
+    s.set_state(w0[None, :], np.array([float(g["T"])], dtype=np.float32))
+    while s.steps_done() < S - 1:
+        assert s.run_segment() == 0
+    s.sync()
+    tr = s.traces()
+    first = parity.compare_replica_trace(tr, 0, rep, key + " ")
+    if first is not None:
+        i = first - 2
+        assert i >= 20, f"diverged at step {i}"
+        assert abs(la[i] - lu[i]) < parity.LOGALPHA_SLACK, f"decision flipped at step {i} with margin {abs(la[i] - lu[i])}"
+    else:
+        st = s.state()
+        assert int(st["num_accepted"][0]) == rep.num_accepted
+        np.testing.assert_allclose(st["w"][0], rep.w, rtol=parity.RTOL, atol=2e-5)
+        np.testing.assert_allclose(st["likelihood"][0], rep.likelihood, rtol=5e-5, atol=5e-3)
+        np.testing.assert_allclose(st["prior"][0], rep.prior_current, rtol=1e-5, atol=1e-3)
+        # the reference's own trace (float64 start) must also agree wherever its decisions match the oracle's
+        same = int(np.argmax(rep.accept_list != g["accept_list"])) if np.any(rep.accept_list != g["accept_list"]) else S
+        np.testing.assert_allclose(tr["pos_w"][0, :max(same - 1, 1)], g["pos_w"][:max(same - 1, 1)], rtol=1e-4, atol=5e-5)
+    s.close()
+
+
+SWAPTRAJ = ["reg", "reg_nophantom", "cls", "cls_nophantom"]
+
+
+@pytest.mark.parametrize("key", SWAPTRAJ)
+def test_full_pt_run_with_swaps(key):
+    """F6: whole ladder with swap rounds (cascade, stale likelihood, trigger index, phantom round) vs the oracle, which
+    test_oracle_golden pins to the reference's multi-process run_chains on this tape."""
+    g = parity.golden(f"swap_trajectory_{key}.npz")
+    topo = tuple(int(v) for v in g["topology"])
+    task, R, seed, si = int(g["task"]), int(g["R"]), int(g["seed"]), int(g["si"])
+    d = ds()
+    dname = str(g["dataset"])
+    train, test = d[dname + "_train"], d[dname + "_test"]
+    pt = orc.PTOracle(task, topo, train, test, R, int(g["maxtemp"]), int(g["NumSample"]), si, use_lg=bool(g["use_lg"]),
+                      l_prob=0.5, lr=float(g["lr"]), seed=seed)
+    S = pt.S
+    w0 = np.stack([rep.w for rep in pt.replicas]).astype(np.float32)
+    for rep, w in zip(pt.replicas, w0):
+        rep.__init__(task, topo, pt.train, pt.test, w.astype(np.float64), rep.T, S, bool(g["use_lg"]), 0.5, float(g["lr"]),
+                     pt.tape, rep.gid)
+    o = parity.OracleRun(pt).run()
+    s = parity.make_sampler(task, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=bool(g["use_lg"]),
+                            lr=float(g["lr"]), seed=seed)
+    s.set_state(w0, np.array(pt.temperatures, dtype=np.float32))
+    s.run(-1)
+    s.sync()
+    tr = s.traces()
+    nsw, tot, rounds = s.swap_stats()
+    assert tot == pt.total_swap_proposals == int(g["total_swap_proposals"])
+    assert rounds == pt.rounds_done
+    log = s.swap_log()
+    assert log.shape == (rounds, R)
+    for row in log:
+        assert sorted(row.tolist()) == list(range(R))
+    firsts = [parity.compare_replica_trace(tr, r, pt.replicas[r], f"{key} r{r} ") for r in range(R)]
+    diverged = [f for f in firsts if f is not None]
+    if not diverged and all((log[k] == np.array(pt.src_log[k])).all() for k in range(rounds)):
+        assert nsw == pt.num_swap == int(g["num_swap"])
+    else:
+        # a decision flipped somewhere: it must have been a coin toss inside the fp32 noise
+        for r, f in enumerate(firsts):
+            if f is not None:
+                i = f - 2
+                # replicas are coupled through swaps: only the EARLIEST divergence is attributable
+                if f == min(diverged):
+                    assert abs(o.logalpha[r, i] - o.logu[r, i]) < parity.LOGALPHA_SLACK
+    s.close()
+
+
+def test_swap_cascade_vectors():
+    """F5 on the device: scripted L vectors (ties, +-inf, nan, differences > 709) through the cascade kernel against
+    the oracle's closed form (pinned to the reference's swap_procedure) with the same Philox uniforms."""
+    d = ds()
+    cases = json.load(open(os.path.join(parity.GOLDEN, "swap_cascade.json")))
+    tape = orc.PhiloxTape(4242)
+    samplers = {}
+    for c in cases:
+        L = np.array([float(x) for x in c["L"]], dtype=np.float32)
+        R = len(L)
+        if R not in samplers:
+            samplers[R] = parity.make_sampler(0, (4, 5, 1), d["sunspot_train"], d["sunspot_test"], R_local=1, R_global=R,
+                                              first=0, S=10, si=100, use_lg=False, lr=0.1, seed=4242)
+        s = samplers[R]
+        s.swap_set_L(L)
+        src = s.swap_cascade(0)                      # round counter stays 0: the cascade alone does not count a round
+        u = tape.swap_uniforms(0, R - 1)
+        ref, _ = orc.swap_cascade([float(x) for x in L], u)
+        assert src.tolist() == ref, c["tag"]
+        assert sorted(src.tolist()) == list(range(R))
+    for s in samplers.values():
+        s.close()
+
+
+def test_chunked_run_equals_one_shot():
+    """ptnn_run in arbitrary chunks must queue exactly the same segments and swap rounds as one call."""
+    d = ds()
+    R, S, si = 8, 103, 5
+    tape = orc.PhiloxTape(9)
+    w0 = np.stack([tape.w_init(r, 31) for r in range(R)]).astype(np.float32)
+    T = np.array(orc.temperature_ladder(R, 2), dtype=np.float32)
+    res = []
+    for chunks in ([-1], [1, 2, 3, 4, 5, 6, 7, 8, 9, 200], [50, 50, 50]):
+        s = parity.make_sampler(0, (4, 5, 1), d["sunspot_train"], d["sunspot_test"], R_local=R, R_global=R, first=0, S=S,
+                                si=si, use_lg=True, lr=0.1, seed=9)
+        s.set_state(w0, T)
+        for c in chunks:
+            s.run(c)
+        s.sync()
+        assert s.steps_done() == S - 1
+        res.append((s.traces(), s.swap_stats(), s.swap_log().copy()))
+        s.close()
+    for tr, st, log in res[1:]:
+        assert st == res[0][1]
+        assert (log == res[0][2]).all()
+        for k in tr:
+            assert (tr[k] == res[0][0][k]).all(), k
+    nsw, tot, rounds = res[0][1]
+    assert rounds == S // si and tot == rounds * (R - 1)
+    assert sum(int(row[k] == k + 1) for row in res[0][2] for k in range(R - 1)) == nsw
+
+
+def test_invariants_at_full_size():
+    """BASELINE config shape (Sunspot, 64 replicas, Langevin p = 0.5) at S = 1000: size-independent properties."""
+    d = ds()
+    R, S, si = 64, 1000, 10
+    s = parity.make_sampler(0, (4, 5, 1), d["sunspot_train"], d["sunspot_test"], R_local=R, R_global=R, first=0, S=S, si=si,
+                            use_lg=True, lr=0.1, seed=5)
+    tape = orc.PhiloxTape(5)
+    w0 = np.stack([tape.w_init(r, 31) for r in range(R)]).astype(np.float32)
+    s.set_state(w0, np.array(orc.temperature_ladder(R, 2), dtype=np.float32))
+    s.run(-1)
+    s.sync()
+    tr = s.traces()
+    acc = tr["accept"].astype(np.int64)
+    step = np.diff(acc, axis=1)
+    assert ((step == 0) | (step == 1)).all() and (acc[:, 0] == 0).all() and (acc[:, 1] == 0).all()
+    # pos_w row i+1 differs from row i exactly when step i was accepted (accept_list[i+2] - accept_list[i+1] == 1)
+    # accept_list[i+1] = count before step i  =>  step i accepted  <=>  acc[i+2] - acc[i+1] == 1 (i <= S-3)
+    changed = np.any(tr["pos_w"][:, 1:S - 1, :] != tr["pos_w"][:, 0:S - 2, :], axis=2)
+    accepted = (acc[:, 2:] - acc[:, 1:-1]) == 1
+    assert (changed == accepted).all()
+    assert (tr["pos_w"][:, 0, :] == 1).all() and (tr["likeh"][:, 0] == -100).all()
+    assert np.isfinite(tr["pos_w"]).all() and np.isfinite(tr["likeh"]).all()
+    assert (tr["acc_train"] == 0).all() and (tr["rmse_train"][:, 0] == 0).all()
+    nsw, tot, rounds = s.swap_stats()
+    assert rounds == S // si and tot == rounds * (R - 1) and 0 <= nsw <= tot
+    for row in s.swap_log():
+        assert sorted(row.tolist()) == list(range(R))
+    st = s.state()
+    assert (st["num_accepted"] >= acc[:, -1]).all() and (st["num_accepted"] - acc[:, -1] <= 1).all()
+    assert (st["langevin_count"] > 0.35 * S).all() and (st["langevin_count"] < 0.65 * S).all()
+    # determinism: the same seed reproduces the run bit for bit
+    s2 = parity.make_sampler(0, (4, 5, 1), d["sunspot_train"], d["sunspot_test"], R_local=R, R_global=R, first=0, S=S, si=si,
+                             use_lg=True, lr=0.1, seed=5, waves=1)
+    s2.set_state(w0, np.array(orc.temperature_ladder(R, 2), dtype=np.float32))
+    s2.run(-1)
+    s2.sync()
+    tr2 = s2.traces()
+    s3 = parity.make_sampler(0, (4, 5, 1), d["sunspot_train"], d["sunspot_test"], R_local=R, R_global=R, first=0, S=S, si=si,
+                             use_lg=True, lr=0.1, seed=5)
+    s3.set_state(w0, np.array(orc.temperature_ladder(R, 2), dtype=np.float32))
+    s3.run(-1)
+    s3.sync()
+    tr3 = s3.traces()
+    assert (tr3["pos_w"] == tr["pos_w"]).all() and (tr3["accept"] == tr["accept"]).all()
+    s.close(); s2.close(); s3.close()
+
+
+def test_smoke_entry():
+    parity.run_smoke_check()
