@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- MCMC samples/sec (all replicas) + swap-accept rate on the BASELINE.json workload.
+
+Workload (N = 1): Sunspot one-step-ahead regression, FNN [4,5,1], 64 replicas, Langevin-gradient proposals with
+probability 0.5 (lr 0.1), maxtemp 2, swap interval 100 -- the configuration BASELINE.json's metric is quoted on.
+A bench "step" is one swap interval: 100 MH steps of every replica (one launch of the fused segment kernel) plus the
+swap round.  Inputs (data set, weights, traces) are resident in HBM when the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling, 64 replicas per GPU on a ladder of 64 N
+temperatures, one RCCL all-gather + point-to-point row exchange per swap round (distributed.py).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TOPO = (4, 5, 1)
+R_PER_GPU = 64
+SWAP_INTERVAL = 100
+L_PROB, LR, MAXTEMP = 0.5, 0.1, 2
+SEED = 1
+P = TOPO[0] * TOPO[1] + TOPO[1] * TOPO[2] + TOPO[1] + TOPO[2]
+# mandatory HBM traffic of one MH step of one replica = the trace row the result files require,
+# 4 (P + 7) bytes (pos_w row + likeh + 2 rmse + 2 acc + accept count); a swap round adds 4 (P + 2) per replica
+B_STEP = 4 * (P + 7)
+B_SWAP = 4 * (P + 2)
+# flop per step (Sunspot [4,5,1]): F_RW = 42 811, F_LGextra = 105 082
+F_STEP = 42811 + L_PROB * 105082
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_TFLOPS = 157.3
+
+
+def load_sunspot():
+    path = os.path.join(ROOT, "tests", "golden", "datasets.npz")
+    if os.path.exists(path):
+        d = np.load(path)
+        return d["sunspot_train"], d["sunspot_test"], "sunspot series shipped as tests/golden/datasets.npz (298/198 rows x 4 lags)"
+    # same shape, synthetic: a noisy quasi-periodic series in [0,1] embedded with window 5 / stride 2
+    rng = np.random.default_rng(0)
+    t = np.arange(1000)
+    s = 0.5 + 0.35 * np.sin(2 * np.pi * t / 44.0) * np.sin(2 * np.pi * t / 400.0) + 0.05 * rng.standard_normal(1000)
+    s = (s - s.min()) / (s.max() - s.min())
+    rows = np.stack([s[2 * k:2 * k + 5] for k in range(496)])
+    return rows[:298], rows[298:], "synthetic sunspot-shaped series (298/198 rows x 4 lags)"
+
+
+def switch_step(S):
+    pt = S * 0.6
+    return int(pt) if pt == int(pt) else -1
+
+
+def make_sampler(train, test, R_local, R_global, first, S, device, use_lg=True):
+    import ptnn_amd
+    from ptnn_amd import _lib, ladder, philox
+    s = _lib.Sampler(device_id=device, task=_lib.TASK_REG, n_in=TOPO[0], n_hidden=TOPO[1], n_out=TOPO[2],
+                     n_replicas_local=R_local, n_replicas_global=R_global, first_global_replica=first, n_samples=S,
+                     swap_interval=SWAP_INTERVAL, pt_switch_step=switch_step(S), use_langevin=int(use_lg),
+                     waves_per_replica=0, l_prob=L_PROB, learn_rate=LR, step_w=0.025, step_eta=0.2, sigma_squared=25.0,
+                     nu_1=0.0, nu_2=0.0, seed=SEED)
+    s.set_data(train, test)
+    T = ladder.temperatures(R_global, MAXTEMP)[first:first + R_local]
+    w0 = np.stack([philox.initial_weights(SEED, first + r, P) for r in range(R_local)])
+    s.set_state(w0, T)
+    return s
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_chain(args):
+    gid, n_steps, train, test, T = args
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ptnn_oracle as orc
+    tape = orc.PhiloxTape(SEED)
+    rep = orc.Replica(orc.TASK_REG, TOPO, train, test, tape.w_init(gid, P), T, 10 * n_steps, True, L_PROB, LR, tape, gid,
+                      faithful=True)
+    t0 = time.perf_counter()
+    for i in range(n_steps):
+        rep.step(i)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(train, test, n_steps=40):
+    """The oracle (float64 numpy restatement, per-row loops like the reference: faithful=True) on the host cores:
+    the same 64-replica Langevin workload, n_steps MH steps per replica, one process per core."""
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ptnn_oracle as orc
+    cores = max(1, min(os.cpu_count() or 1, R_PER_GPU))
+    T = orc.temperature_ladder(R_PER_GPU, MAXTEMP)
+    jobs = [(g, n_steps, train, test, T[g]) for g in range(R_PER_GPU)]
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        busy = pool.map(_cpu_chain, jobs, chunksize=1)
+    wall = time.perf_counter() - t0
+    return {"value": R_PER_GPU * n_steps / wall, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{R_PER_GPU} replicas x {n_steps} MH steps (Langevin p=0.5), oracle faithful mode, "
+                      f"{cores} processes, {sum(busy):.1f} s of CPU work, no swap rounds"}
+
+
+# ------------------------------------------------------------------------------------------------ main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rw", action="store_true", help="random-walk proposals only (extra data point)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    K, W, N = a.steps, a.warmup, a.gpus
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != N:
+        if world == 1 and N > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        N = world
+    train, test, data_desc = load_sunspot()
+    si = SWAP_INTERVAL
+    S = (W + K + 1) * si + 2
+    R_global = R_PER_GPU * N
+    use_lg = not a.rw
+
+    cpu = None
+    if N == 1 and rank == 0 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(train, test)      # before the first HIP call: the pool forks
+    if N == 1:
+        s = make_sampler(train, test, R_PER_GPU, R_global, 0, S, local_rank, use_lg)
+        s.run(W * si + 1)            # REG hands off after step i = k*si (REG:427): start the timed region on an interval boundary
+        s.sync()
+        s.kernel_time(reset=True)
+        nsw0, tot0, _ = s.swap_stats()
+        t0 = time.perf_counter()
+        s.run(K * si)
+        s.sync()
+        dt = time.perf_counter() - t0
+        launches, kms = s.kernel_time()
+        nsw1, tot1, _ = s.swap_stats()
+        accepted = s.state()["num_accepted"]
+        steps_done = s.steps_done()
+    else:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from ptnn_amd import distributed as dm
+        s = make_sampler(train, test, R_PER_GPU, R_global, rank * R_PER_GPU, S, local_rank, use_lg)
+        lad = dm.ShardedLadder(dm.DeviceShard(s, local_rank), rank, N, dist)
+        lad.run_intervals(W)
+        s.sync()
+        s.kernel_time(reset=True)
+        nsw0, tot0, _ = s.swap_stats()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        lad.run_intervals(K)
+        s.sync()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt_local = time.perf_counter() - t0
+        t = torch.tensor([dt_local], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        launches, kms = s.kernel_time()
+        nsw1, tot1, _ = s.swap_stats()
+        accepted = s.state()["num_accepted"]
+        steps_done = s.steps_done()
+
+    if rank == 0:
+        mh_steps = K * si                                       # per replica, inside the timed region
+        value = R_global * mh_steps / dt
+        avg_launch_s = (kms / max(launches, 1)) * 1e-3
+        bytes_per_launch = R_PER_GPU * (mh_steps / max(launches, 1)) * B_STEP + R_PER_GPU * B_SWAP
+        achieved = bytes_per_launch / avg_launch_s / 1e9 if launches else 0.0
+        flops_per_launch = R_PER_GPU * (mh_steps / max(launches, 1)) * (F_STEP if use_lg else 42811)
+        out = {
+            "metric": "MCMC samples/sec (all replicas) + swap-accept rate; Sunspot 64-replica FNN",
+            "value": value, "unit": "samples/s", "n_gpus": N, "steps": K, "warmup": W,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": data_desc,
+            "config": {"workload": f"Sunspot FNN 4-5-1, {R_PER_GPU} replicas/GPU ({R_global} temperatures), "
+                                   + ("Langevin p=0.5 lr=0.1" if use_lg else "random-walk") +
+                                   f", maxtemp {MAXTEMP}, swap every {si} MH steps; 1 bench step = 1 swap interval",
+                       "replicas": R_global, "mh_steps_per_bench_step": si, "proposals": "langevin" if use_lg else "rw"},
+            "swap_accept_pct": 100.0 * (nsw1 - nsw0) / max(tot1 - tot0, 1),
+            "mh_accept_pct": float(100.0 * np.mean(accepted) / max(steps_done, 1)),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "ptnn::segment_kernel<0,4,1>", "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "valu_tflops": flops_per_launch / avg_launch_s / 1e12 if launches else 0.0,
+                         "valu_frac": (flops_per_launch / avg_launch_s / 1e12) / VALU_PEAK_TFLOPS if launches else 0.0,
+                         "note": "latency-bound by construction: 64 work-groups on 256 CUs, sequential SGD rows"},
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["speedup_vs_cpu_baseline"] = value / cpu["value"]
+        print(json.dumps(out), flush=True)
+    if N > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    s.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -274,13 +274,15 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
             a = d * d;
         } else {
             float out[O];
-            float best = -1.0f, se = 0.0f, oy = 0.0f;
+            float best = acc[0], se = 0.0f, oy = 0.0f;
             int arg = 0;
             const int yi = (int)y;
 #pragma unroll
             for (int o = 0; o < O; ++o) {
                 out[o] = sigmoidf_fast(acc[o]);
-                if (out[o] > best) { best = out[o]; arg = o; }        // np.argmax: first maximum (CLS:55)
+                // np.argmax(out): first maximum (CLS:55).  Taken on the pre-activation: sigmoid is monotone, and fp32
+                // outputs that saturate to 1.0f would tie where the reference's float64 outputs still differ
+                if (acc[o] > best) { best = acc[o]; arg = o; }
                 se += expf_fast(out[o]);                               // softmax of the sigmoid outputs (Q3)
                 oy = (o == yi) ? out[o] : oy;
             }

@@ -1,0 +1,131 @@
+"""Sharded ladder: one process per GPU, each owning a contiguous block of the temperature ladder.
+
+Replaces the reference's star topology (every replica ships its whole parameter vector to the parent through a
+multiprocessing.Queue each swap round, REG:427-437 <-> 719-752).  Replicas are independent for a swap interval, so
+the data path needs exactly one exchange step per interval:
+
+  1. all-gather of the R posted scalars L (4 R bytes);
+  2. every rank runs the identical cascade kernel (uniforms are Philox(seed; round, pair)) -> the same src[R];
+  3. only rows whose source lives on another rank travel: point-to-point, straight into the destination row of the
+     receiver's next-state buffer (at most one row arrives from below and one from the rank directly above);
+  4. the local rows are copied by the swap kernel, buffers flip.
+
+`torch.distributed` is the plumbing (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests); the
+tensors it moves are views of libptnn's own device buffers.  The driver is written against a small shard protocol so
+that the CPU tests can run the same routing code over the oracle.
+"""
+import numpy as np
+
+
+class DeviceShard:
+    """Adapter: a `_lib.Sampler` handle seen through the shard protocol, device buffers as torch tensors."""
+
+    def __init__(self, sampler, device_index):
+        import torch
+        self.torch = torch
+        self.s = sampler
+        self.dev = torch.device("cuda", device_index)
+        self.R_local = sampler.cfg.n_replicas_local
+        self.R_global = sampler.cfg.n_replicas_global
+        self.first = sampler.cfg.first_global_replica
+        self.S = sampler.S
+        self.PS = sampler.state_row_floats()
+
+    def _view(self, ptr, n):
+        class _Arr:            # __cuda_array_interface__ v2: zero-copy view of library-owned HBM
+            pass
+        a = _Arr()
+        a.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+        return self.torch.as_tensor(a, device=self.dev)
+
+    def run_segment(self):
+        return self.s.run_segment()
+
+    def sync(self):
+        self.s.sync()
+
+    def fence_collectives(self):
+        self.torch.cuda.synchronize(self.dev)
+
+    def steps_done(self):
+        return self.s.steps_done()
+
+    def L_tensor(self, phantom):
+        return self._view(self.s.swap_L_ptr(phantom), self.R_global)
+
+    def row_tensors(self, local):
+        cur, nxt = self.s.swap_row_ptr(local)
+        return self._view(cur, self.PS), self._view(nxt, self.PS)
+
+    def swap_cascade(self, phantom):
+        return self.s.swap_cascade(phantom)
+
+    def swap_apply(self, src, phantom):
+        self.s.swap_apply(src, phantom)
+
+
+def route(src, rank, world, R_local):
+    """Which rows this rank receives and sends in one round.  Pure function of the permutation.
+    Returns (recvs, sends): recvs = [(local_dest, peer)], sends = [(local_source, peer)], both in ascending order of
+    the GLOBAL destination slot so that the two ends of every pair enumerate their messages in the same order."""
+    first = rank * R_local
+    recvs, sends = [], []
+    for kg in range(world * R_local):
+        sg = int(src[kg])
+        dst_owner, src_owner = kg // R_local, sg // R_local
+        if dst_owner == src_owner:
+            continue
+        if dst_owner == rank:
+            recvs.append((kg - first, src_owner))
+        elif src_owner == rank:
+            sends.append((sg - first, dst_owner))
+    return recvs, sends
+
+
+class ShardedLadder:
+    def __init__(self, shard, rank, world, dist=None):
+        if dist is None:
+            import torch.distributed as dist
+        self.dist = dist
+        self.shard, self.rank, self.world = shard, rank, world
+        self.rounds = 0
+        self.bytes_moved = 0
+
+    def swap_round(self, phantom):
+        sh, dist = self.shard, self.dist
+        sh.sync()                                           # L of the local block is written
+        L = sh.L_tensor(phantom)
+        Rl = sh.R_local
+        mine = L[self.rank * Rl:(self.rank + 1) * Rl].clone()
+        dist.all_gather(list(L.split(Rl)), mine)            # 4 R bytes, latency-bound
+        if hasattr(sh, "fence_collectives"):
+            sh.fence_collectives()
+        src = sh.swap_cascade(phantom)                      # identical on every rank
+        if not phantom:
+            recvs, sends = route(src, self.rank, self.world, Rl)
+            ops = []
+            for local, peer in recvs:
+                ops.append(dist.P2POp(dist.irecv, sh.row_tensors(local)[1], peer))
+            for local, peer in sends:
+                ops.append(dist.P2POp(dist.isend, sh.row_tensors(local)[0], peer))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                if hasattr(sh, "fence_collectives"):
+                    sh.fence_collectives()
+                self.bytes_moved += 4 * sh.PS * len(ops)
+        sh.swap_apply(src, phantom)
+        self.rounds += 1
+        return src
+
+    def run_intervals(self, n_intervals=None):
+        """Advance by n swap intervals (None = to the chain end).  Returns the number of intervals done."""
+        done = 0
+        while n_intervals is None or done < n_intervals:
+            ho = self.shard.run_segment()
+            if ho:
+                self.swap_round(phantom=(ho == 2))
+                done += 1
+            if self.shard.steps_done() >= self.shard.S - 1 and ho != 1:
+                break
+        return done

@@ -83,9 +83,22 @@ def test_model_functions_against_reference_vectors(key, waves):
                     ev = s.evaluate(w)[0]
                     lik, rm, acc = g[f"lik{wi}_T1.0"]
                     np.testing.assert_allclose(ev[0], lik, rtol=2e-5, atol=1e-3)
-                    np.testing.assert_allclose([ev[1], ev[3]], [rm, acc], rtol=1e-5)
                     lik_te, rm_te, acc_te = g[f"liktest{wi}_T1.0"]
-                    np.testing.assert_allclose([ev[2], ev[4]], [rm_te, acc_te], rtol=1e-5)
+                    # argmax is discontinuous: rows whose two largest pre-activations are closer than the fp32
+                    # round-off of the hidden sum (w = linspace makes the output columns nearly equal) may
+                    # legitimately classify differently; every other row must agree
+                    for data, got_rm, got_acc, ref_rm, ref_acc in ((train, ev[1], ev[3], rm, acc),
+                                                                   (test, ev[2], ev[4], rm_te, acc_te)):
+                        W1, W2, B1, B2 = orc.decode(w, topo)
+                        hid = orc.sigmoid(data[:, :topo[0]] @ W1 - B1)
+                        z2 = np.sort(hid @ W2 - B2, axis=1)
+                        amb = int(np.count_nonzero(z2[:, -1] - z2[:, -2] < 1e-4))
+                        N = data.shape[0]
+                        if amb == 0:
+                            np.testing.assert_allclose([got_rm, got_acc], [ref_rm, ref_acc], rtol=1e-5)
+                        else:
+                            assert abs(got_acc - ref_acc) <= 100.0 * amb / N + 1e-3
+                            assert abs(got_rm ** 2 - ref_rm ** 2) <= amb * (topo[2] - 1) ** 2 / N + 1e-5
                     np.testing.assert_allclose(ev[6], lik_te, rtol=2e-5, atol=1e-3)
                     np.testing.assert_allclose(ev[5], g[f"prior{wi}"], rtol=2e-6, atol=1e-4)
         s.close()

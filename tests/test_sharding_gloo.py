@@ -1,0 +1,182 @@
+"""N > 1 path on CPU: the sharded-ladder driver (parallel-tempering-neural-net_amd/distributed.py) over `gloo`,
+world_size 2 and 4, with the oracle as the compute engine behind the shard protocol.  The sharded run must reproduce
+the single-process oracle run bit for bit (results identical for every GPU count at a fixed seed)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ptnn_oracle as orc  # noqa: E402
+
+
+def _load_distributed():
+    import ptnn_amd
+    from ptnn_amd import distributed
+    return distributed
+
+
+def test_route_is_consistent_between_ranks():
+    dm = _load_distributed()
+    rng = np.random.default_rng(0)
+    for world, Rl in ((2, 2), (4, 4), (8, 32), (8, 128)):
+        R = world * Rl
+        for _ in range(20):
+            # permutations the cascade can produce: bubble pass with random swap decisions
+            u = rng.uniform(size=R - 1)
+            src, _ = orc.swap_cascade(list(rng.normal(0, 2, R)), u)
+            plans = [dm.route(src, r, world, Rl) for r in range(world)]
+            sent = sorted((r, peer, src_l + r * Rl) for r, (rc, sd) in enumerate(plans) for src_l, peer in sd)
+            recvd = sorted((peer, r, src[dst_l + r * Rl]) for r, (rc, sd) in enumerate(plans) for dst_l, peer in rc)
+            assert sent == recvd                       # every receive has its matching send (same source row)
+            for r, (rc, sd) in enumerate(plans):
+                below = [p for _, p in rc if p < r]
+                above = [p for _, p in rc if p > r]
+                assert len(below) <= 1 and len(above) <= 1      # at most one row from below, one from above
+                assert all(p == r + 1 for p in above)
+            # per ordered pair, both ends list their messages in the same (global destination) order
+            for a in range(world):
+                for b in range(world):
+                    if a == b:
+                        continue
+                    s_order = [src_l + a * Rl for src_l, peer in plans[a][1] if peer == b]
+                    r_order = [src[dst_l + b * Rl] for dst_l, peer in plans[b][0] if peer == a]
+                    assert s_order == r_order
+
+
+class OracleShard:
+    """The shard protocol of distributed.py implemented by oracle replicas (float64, CPU tensors)."""
+
+    def __init__(self, pt_args, rank, world):
+        import torch
+        self.torch = torch
+        full = orc.PTOracle(*pt_args["args"], **pt_args["kw"])
+        self.task, self.si, self.S, self.tape = full.task, full.si, full.S, full.tape
+        self.R_global = full.R
+        self.R_local = full.R // world
+        self.first = rank * self.R_local
+        self.reps = full.replicas[self.first:self.first + self.R_local]
+        self.P = full.P
+        self.PS = self.P + 1
+        self.cur = 0
+        self.rounds_done = 0
+        self.num_swap = 0
+        self.finalized = False
+        self.L = [torch.zeros(self.R_global, dtype=torch.float64), torch.zeros(self.R_global, dtype=torch.float64)]
+        self.rows_cur = torch.zeros(self.R_local, self.PS, dtype=torch.float64)
+        self.rows_next = torch.zeros(self.R_local, self.PS, dtype=torch.float64)
+
+    def run_segment(self):
+        last = self.S - 1
+        ho = 0
+        if self.cur < last:
+            while self.cur < last:
+                i = self.cur
+                for rep in self.reps:
+                    rep.step(i)
+                self.cur += 1
+                if orc.swap_trigger(self.task, i, self.si):
+                    ho = 1
+                    break
+        if ho == 0 and self.cur == last and not self.finalized:
+            self.finalized = True
+            if int(self.S / self.si) > self.rounds_done:
+                ho = 2
+        for k, rep in enumerate(self.reps):
+            self.L[0][self.first + k] = rep.posted_L()
+            self.L[1][self.first + k] = rep.likelihood
+            self.rows_cur[k, :self.P] = self.torch.from_numpy(np.asarray(rep.w))
+            self.rows_cur[k, self.P] = rep.eta
+        return ho
+
+    def sync(self):
+        pass
+
+    def steps_done(self):
+        return self.cur
+
+    def L_tensor(self, phantom):
+        return self.L[1 if phantom else 0]
+
+    def row_tensors(self, local):
+        return self.rows_cur[local], self.rows_next[local]
+
+    def swap_cascade(self, phantom):
+        L = self.L[1 if phantom else 0].tolist()
+        u = self.tape.swap_uniforms(self.rounds_done, self.R_global - 1)
+        src, nsw = orc.swap_cascade(L, u)
+        self._nsw = nsw
+        return np.array(src, dtype=np.int32)
+
+    def swap_apply(self, src, phantom):
+        if not phantom:
+            for k in range(self.R_local):
+                sl = int(src[self.first + k]) - self.first
+                if 0 <= sl < self.R_local:
+                    self.rows_next[k] = self.rows_cur[sl]
+            for k, rep in enumerate(self.reps):
+                rep.w = self.rows_next[k, :self.P].numpy().copy()
+                rep.eta = float(self.rows_next[k, self.P])
+        self.num_swap += self._nsw
+        self.rounds_done += 1
+
+
+def _worker(rank, world, port, pt_args, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dm = _load_distributed()
+    shard = OracleShard(pt_args, rank, world)
+    lad = dm.ShardedLadder(shard, rank, world, dist)
+    lad.run_intervals(None)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"),
+             pos_w=np.stack([r.pos_w for r in shard.reps]), accept=np.stack([r.accept_list for r in shard.reps]),
+             likeh=np.stack([r.likeh for r in shard.reps]), rmse=np.stack([r.rmse_train for r in shard.reps]),
+             num_swap=shard.num_swap, rounds=shard.rounds_done, bytes_moved=lad.bytes_moved)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,task", [(2, orc.TASK_REG), (4, orc.TASK_CLS)])
+def test_sharded_ladder_matches_single_process(tmp_path, datasets, world, task):
+    import torch.multiprocessing as mp
+    if task == orc.TASK_REG:
+        args = (task, (4, 5, 1), datasets["sunspot_train"], datasets["sunspot_test"], 8, 2, 8 * 43, 5)
+        kw = dict(use_lg=True, l_prob=0.5, lr=0.1, seed=31)        # S = 43: no phantom; hand-offs at i = 5..40
+    else:
+        args = (task, (4, 12, 3), datasets["iris_train"], datasets["iris_test"], 8, 10, 8 * 40, 5)
+        kw = dict(use_lg=False, l_prob=0.5, lr=0.01, seed=32)      # S = 40: S % si == 0 -> phantom round
+    pt_args = dict(args=args, kw=kw)
+    ref = orc.PTOracle(*args, **kw).run()
+    mp.spawn(_worker, args=(world, _free_port(), pt_args, str(tmp_path)), nprocs=world, join=True)
+    Rl = 8 // world
+    moved = 0
+    for rank in range(world):
+        z = np.load(tmp_path / f"rank{rank}.npz")
+        for k in range(Rl):
+            rep = ref.replicas[rank * Rl + k]
+            assert (z["pos_w"][k] == rep.pos_w).all()
+            assert (z["accept"][k] == rep.accept_list).all()
+            assert (z["likeh"][k] == rep.likeh).all()
+            assert (z["rmse"][k] == rep.rmse_train).all()
+        assert int(z["num_swap"]) == ref.num_swap and int(z["rounds"]) == ref.rounds_done
+        moved += int(z["bytes_moved"])
+    assert ref.num_swap > 0
+    # something actually crossed a shard boundary, and never more than two rows in + two rows out per rank per round
+    assert moved > 0
+    assert moved <= ref.rounds_done * world * 4 * 4 * (ref.P + 1)
