@@ -26,6 +26,10 @@ extern "C" {
 #define PTNN_TASK_REG 0 /* Gaussian likelihood + eta = log tau^2 (REG) */
 #define PTNN_TASK_CLS 1 /* multinomial likelihood on softmax-of-sigmoid outputs (CLS) */
 
+#define PTNN_SCHED_AUTO 0
+#define PTNN_SCHED_COOPERATIVE 1
+#define PTNN_SCHED_SPECULATIVE 2
+
 typedef struct ptnn_handle ptnn_handle;
 
 /* Everything ParallelTempering.__init__ / initialize_chains / ptReplica.__init__ fix for a run
@@ -43,6 +47,8 @@ typedef struct ptnn_config {
     int32_t pt_switch_step;       /* step i at which adapttemp drops to 1 (REG:320), or -1 if 0.6*S is not integral */
     int32_t use_langevin;         /* use_langevin_gradients (REG:329) */
     int32_t waves_per_replica;    /* 0 = auto; 1,2,4,8,16: wavefronts of the work-group that owns one replica */
+    int32_t schedule;             /* 0 = auto, 1 = cooperative (all waves share one MH step), 2 = speculative
+                                   * (wave v pre-computes step i+v; identical chain) */
     float l_prob;                 /* langevin_prob (REG:174); CLS fixes 0.5 (CLS:192) */
     float learn_rate;             /* SGD step of langevin_gradient (REG:33) */
     float step_w;                 /* 0.025 (REG:258) */

@@ -52,10 +52,11 @@ typedef void (*model_fn)(const SegParams, int, const float*, const float*, float
 struct Shape {
     int task, I, O;
     seg_fn seg;
+    seg_fn spec;
     model_fn model;
 };
 
-#define X_ENTRY(T, I, O) {T, I, O, &segment_kernel<T, I, O>, &model_kernel<T, I, O>},
+#define X_ENTRY(T, I, O) {T, I, O, &segment_kernel<T, I, O>, &segment_spec_kernel<T, I, O>, &model_kernel<T, I, O>},
 const Shape g_shapes[] = {PTNN_SHAPES(X_ENTRY)};
 #undef X_ENTRY
 
@@ -75,7 +76,9 @@ struct ptnn_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int P = 0, PS = 0, IPY = 0, FWS = 0, Ntr = 0, Nte = 0, nthreads = 64;
-    size_t seg_lds = 0;
+    size_t seg_lds = 0, model_lds = 0;
+    int model_threads = 64;
+    bool speculative = false;
     bool have_data = false, have_state = false, finalized = false;
     int cur = 0;            // next MH step index
     int rounds_done = 0;    // swap rounds counted (including the phantom one)
@@ -84,7 +87,9 @@ struct ptnn_handle {
     // device memory
     float* d_data = nullptr;
     float* d_state[2] = {nullptr, nullptr};
-    float *d_rec_w = nullptr, *d_gd_w = nullptr, *d_st_f = nullptr, *d_temps = nullptr;
+    float *d_rec_w = nullptr, *d_st_f = nullptr, *d_temps = nullptr;
+    float* d_gd_w[2] = {nullptr, nullptr};
+    int* d_gd_valid[2] = {nullptr, nullptr};
     int* d_st_i = nullptr;
     float *d_L_handoff = nullptr, *d_L_final = nullptr;
     float *d_pos_w = nullptr, *d_likeh = nullptr, *d_rmse_tr = nullptr, *d_rmse_te = nullptr, *d_acc_tr = nullptr,
@@ -112,7 +117,7 @@ struct ptnn_handle {
         p.prior_c = (float)(-1.0 * (cnt / 2.0) * std::log((double)cfg.sigma_squared));
         p.nu1 = cfg.nu_1; p.nu2 = cfg.nu_2;
         p.seed_lo = (uint32_t)(cfg.seed & 0xffffffffull); p.seed_hi = (uint32_t)(cfg.seed >> 32);
-        p.data = d_data; p.w_state = d_state[flip]; p.rec_w = d_rec_w; p.gd_w = d_gd_w;
+        p.data = d_data; p.w_state = d_state[flip]; p.rec_w = d_rec_w; p.gd_w = d_gd_w[flip]; p.gd_valid = d_gd_valid[flip];
         p.st_f = d_st_f; p.st_i = d_st_i; p.temps = d_temps;
         p.L_handoff = d_L_handoff; p.L_final = d_L_final;
         p.tr_pos_w = d_pos_w; p.tr_likeh = d_likeh; p.tr_rmse_tr = d_rmse_tr; p.tr_rmse_te = d_rmse_te;
@@ -157,7 +162,8 @@ int launch_segment(ptnn_handle* h, int begin, int n) {
     auto& ev = h->timing[h->timing_used++];
     const SegParams p = h->seg_params();
     HIP_TRY(hipEventRecord(ev.first, h->stream));
-    hipLaunchKernelGGL(h->shape->seg, dim3(h->cfg.n_replicas_local), dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
+    hipLaunchKernelGGL(h->speculative ? h->shape->spec : h->shape->seg, dim3(h->cfg.n_replicas_local), dim3(h->nthreads),
+                       h->seg_lds, h->stream, p, begin, n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, h->stream));
     return 0;
@@ -172,7 +178,9 @@ int launch_swap(ptnn_handle* h, bool phantom, int mode, bool want_src) {
     sp.seed_lo = (uint32_t)(h->cfg.seed & 0xffffffffull); sp.seed_hi = (uint32_t)(h->cfg.seed >> 32);
     sp.L = phantom ? h->d_L_final : h->d_L_handoff;
     sp.cur = h->d_state[h->flip]; sp.next = h->d_state[h->flip ^ 1];
-    sp.st_i = h->d_st_i; sp.src_out = want_src ? h->d_src : nullptr;
+    sp.gd_cur = h->d_gd_w[h->flip]; sp.gd_next = h->d_gd_w[h->flip ^ 1];
+    sp.gd_valid_cur = h->d_gd_valid[h->flip]; sp.gd_valid_next = h->d_gd_valid[h->flip ^ 1];
+    sp.src_out = want_src ? h->d_src : nullptr;
     sp.counters = h->d_counters; sp.src_log = h->d_src_log; sp.log_capacity = h->max_rounds;
     const size_t lds = (size_t)(3 * sp.R + 1) * sizeof(float);
     hipLaunchKernelGGL(swap_kernel, dim3(sp.Rl), dim3(64), lds, h->stream, sp, h->rounds_done, mode);
@@ -240,7 +248,10 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
     HIP_TRY(hipMalloc(&h->d_state[0], Rl * h->PS * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_state[1], Rl * h->PS * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_rec_w, Rl * h->PS * sizeof(float)));
-    HIP_TRY(hipMalloc(&h->d_gd_w, Rl * h->PS * sizeof(float)));
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY(hipMalloc(&h->d_gd_w[b], Rl * h->PS * sizeof(float)));
+        HIP_TRY(hipMalloc(&h->d_gd_valid[b], Rl * sizeof(int)));
+    }
     HIP_TRY(hipMalloc(&h->d_st_f, Rl * SF_COUNT * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_st_i, Rl * SI_COUNT * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_temps, Rl * sizeof(float)));
@@ -268,7 +279,7 @@ int ptnn_destroy(ptnn_handle* h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device_id);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_data, h->d_state[0], h->d_state[1], h->d_rec_w, h->d_gd_w, h->d_st_f, h->d_st_i, h->d_temps,
+    void* ptrs[] = {h->d_data, h->d_state[0], h->d_state[1], h->d_rec_w, h->d_gd_w[0], h->d_gd_w[1], h->d_gd_valid[0], h->d_gd_valid[1], h->d_st_f, h->d_st_i, h->d_temps,
                     h->d_L_handoff, h->d_L_final, h->d_pos_w, h->d_likeh, h->d_rmse_tr, h->d_rmse_te, h->d_acc_tr,
                     h->d_acc_te, h->d_accept, h->d_src, h->d_src_log, h->d_counters};
     for (void* p : ptrs)
@@ -287,7 +298,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     const int Nall = ntr + nte;
     const int IPY = h->IPY;
-    std::vector<float> packed((size_t)Nall * IPY, 0.0f);
+    std::vector<float> packed((size_t)(Nall + 2) * IPY, 0.0f);      // two zero rows: look-ahead of the SGD sweep
     for (int n = 0; n < Nall; ++n) {
         const float* row = (n < ntr) ? train + (size_t)n * ncols : test + (size_t)(n - ntr) * ncols;
         for (int c = 0; c <= I; ++c) packed[(size_t)n * IPY + c] = row[c];
@@ -297,30 +308,51 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
                 return fail(-1, "class label %g in row %d is not an integer in [0, %d)", (double)y, n, h->cfg.n_out);
         }
     }
-    // LDS budget: the data set, six state vectors and the packed forward weights live in LDS for the whole launch
-    const size_t lds = lds_floats(Nall, IPY, h->PS, h->cfg.n_hidden, h->FWS) * sizeof(float);
-    if (lds > 160 * 1024)
-        return fail(-3, "replica working set needs %zu B of LDS (> 160 KiB): data %d rows x %d floats, P = %d", lds, Nall,
+    // LDS budget: the data set, the state vectors and the packed forward weights live in LDS for the whole launch
+    const int H = h->cfg.n_hidden;
+    const size_t coop_lds = lds_floats(Nall, IPY, h->PS, H, h->FWS) * sizeof(float);
+    const size_t LDS_MAX = 160 * 1024;
+    if (coop_lds > LDS_MAX)
+        return fail(-3, "replica working set needs %zu B of LDS (> 160 KiB): data %d rows x %d floats, P = %d", coop_lds, Nall,
                     IPY, h->P);
-    h->seg_lds = lds;
+    h->model_lds = coop_lds;
+    // schedule: speculative pays when MH acceptance is low (regression chains: 1-15 %) or the step is dominated by the
+    // sequential SGD sweep; cooperative when one step's row-parallel forward pass is the bulk of the work
+    int sched = h->cfg.schedule;
+    if (sched == PTNN_SCHED_AUTO)
+        sched = (h->cfg.task == PTNN_TASK_REG || h->cfg.use_langevin) ? PTNN_SCHED_SPECULATIVE : PTNN_SCHED_COOPERATIVE;
+    if (sched != PTNN_SCHED_COOPERATIVE && sched != PTNN_SCHED_SPECULATIVE) return fail(-1, "unknown schedule %d", sched);
+    int nw = h->cfg.waves_per_replica;
+    if (nw != 0 && nw != 1 && nw != 2 && nw != 4 && nw != 8 && nw != 16)
+        return fail(-1, "waves_per_replica must be 0 (auto), 1, 2, 4, 8 or 16");
+    int coop_nw = (Nall + 63) / 64, pow2 = 1;
+    while (pow2 < coop_nw) pow2 <<= 1;
+    coop_nw = std::min(pow2, 8);
+    h->model_threads = coop_nw * 64;
+    if (sched == PTNN_SCHED_SPECULATIVE) {
+        int k = nw ? nw : 8;                                  // 2 waves per SIMD: each still issues at single-wave rate
+        while (k > 1 && spec_lds_floats(Nall, IPY, h->PS, H, h->FWS, k) * sizeof(float) > LDS_MAX) k >>= 1;
+        if (nw && k != nw) {
+            if (h->cfg.schedule == PTNN_SCHED_AUTO) k = 0;      // auto: fall back to the cooperative schedule below
+            else return fail(-3, "speculative schedule with %d waves needs more than 160 KiB of LDS", nw);
+        }
+        if (k == 0 || spec_lds_floats(Nall, IPY, h->PS, H, h->FWS, k) * sizeof(float) > LDS_MAX) sched = PTNN_SCHED_COOPERATIVE;
+        else { h->speculative = true; h->nthreads = k * 64; h->seg_lds = spec_lds_floats(Nall, IPY, h->PS, H, h->FWS, k) * sizeof(float); }
+    }
+    if (sched == PTNN_SCHED_COOPERATIVE) {
+        h->speculative = false;
+        h->nthreads = (nw ? nw : coop_nw) * 64;
+        h->seg_lds = coop_lds;
+    }
     h->Ntr = ntr; h->Nte = nte;
     if (h->d_data) { HIP_TRY(hipFree(h->d_data)); h->d_data = nullptr; }
     HIP_TRY(hipMalloc(&h->d_data, packed.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(h->d_data, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (lds > 64 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->shape->seg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->shape->model), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    // waves per replica: the row-parallel forward pass uses every wave, the SGD sweep only wave 0
-    int nw = h->cfg.waves_per_replica;
-    if (nw <= 0) {
-        nw = (Nall + 63) / 64;
-        int pow2 = 1;
-        while (pow2 < nw) pow2 <<= 1;
-        nw = std::min(pow2, 8);
-    }
-    if (nw != 1 && nw != 2 && nw != 4 && nw != 8 && nw != 16) return fail(-1, "waves_per_replica must be 1, 2, 4, 8 or 16");
-    h->nthreads = nw * 64;
+    if (h->seg_lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->speculative ? h->shape->spec : h->shape->seg),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->seg_lds));
+    if (h->model_lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->shape->model), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->model_lds));
     h->have_data = true;
     return 0;
 }
@@ -335,7 +367,10 @@ int ptnn_set_state(ptnn_handle* h, const float* w0, const float* temperatures) {
     HIP_TRY(hipMemcpy(h->d_state[0], st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_state[1], st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->d_rec_w, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));   // pos_w row 0 = ones (REG:240)
-    HIP_TRY(hipMemset(h->d_gd_w, 0, (size_t)Rl * PS * sizeof(float)));
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY(hipMemset(h->d_gd_w[b], 0, (size_t)Rl * PS * sizeof(float)));
+        HIP_TRY(hipMemset(h->d_gd_valid[b], 0, (size_t)Rl * sizeof(int)));
+    }
     HIP_TRY(hipMemset(h->d_st_f, 0, (size_t)Rl * SF_COUNT * sizeof(float)));
     HIP_TRY(hipMemset(h->d_st_i, 0, (size_t)Rl * SI_COUNT * sizeof(int)));
     HIP_TRY(hipMemcpy(h->d_temps, temperatures, Rl * sizeof(float), hipMemcpyHostToDevice));
@@ -549,7 +584,7 @@ static int run_model(ptnn_handle* h, int mode, const float* w_in, const float* t
     }
     HIP_TRY(hipMalloc(&d_out, out_floats * sizeof(float)));
     const SegParams p = h->seg_params();
-    hipLaunchKernelGGL(h->shape->model, dim3(n), dim3(h->nthreads), h->seg_lds, h->stream, p, mode, d_w, d_tau, d_out, a0, a1);
+    hipLaunchKernelGGL(h->shape->model, dim3(n), dim3(h->model_threads), h->model_lds, h->stream, p, mode, d_w, d_tau, d_out, a0, a1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(out, d_out, out_floats * sizeof(float), hipMemcpyDeviceToHost));

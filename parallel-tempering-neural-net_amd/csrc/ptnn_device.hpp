@@ -43,6 +43,7 @@ struct SegParams {
     float* gd_w;             // cached langevin_gradient(w) [Rl][PS]
     float* st_f;             // [Rl][SF_COUNT]
     int* st_i;               // [Rl][SI_COUNT]
+    int* gd_valid;           // [Rl] 1 when gd_w holds langevin_gradient of the current w
     const float* temps;      // [Rl]
     float* L_handoff;        // [Rglobal] posted scalar at a hand-off (REG:430 / CLS:439)
     float* L_final;          // [Rglobal] end-of-chain scalar (REG:442 / CLS:451)
@@ -118,6 +119,16 @@ __device__ __forceinline__ float group_allsum(float v) {
 }
 __device__ __forceinline__ float wave_allsum(float v) { return group_allsum<6>(v); }
 
+// A "group" is either the whole work-group (WL = false: cooperative schedule, all waves work on one MH step) or one
+// wavefront (WL = true: speculative schedule, every wave works on its own MH step).  LDS traffic inside one wave is
+// ordered by the hardware; the fence only stops the compiler from moving accesses across it.
+template <bool WL> __device__ __forceinline__ int gtid() { return WL ? (int)(threadIdx.x & 63) : (int)threadIdx.x; }
+template <bool WL> __device__ __forceinline__ int gsize() { return WL ? WAVE : (int)blockDim.x; }
+template <bool WL> __device__ __forceinline__ void gsync() {
+    if (WL) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------
 // LDS helpers: N floats from a 16-byte aligned address as ds_read_b128s
 // ------------------------------------------------------------------------------------------------
@@ -143,66 +154,84 @@ __device__ __forceinline__ void lds_load(const float* __restrict__ p, float (&v)
 template <int TASK, int I, int O, int NRED>
 __device__ __forceinline__ void sgd_sweep(const float* __restrict__ w_in, float* __restrict__ w_out,
                                           const float* __restrict__ xy, int IPY, int Ntr, int H, float lr) {
+    // All weights are kept pre-multiplied by c = -log2(e): the pre-activation then IS the exponent of
+    // sigmoid(z) = 1 / (1 + 2^(c z)), and every update rule keeps its shape with lr folded into two constants:
+    //   W1' += lr (g' dh) x,  B1' -= lr g' dh      with g' = sum_o od W2'[.,o]  (= c g)
+    //   W2' += (c lr) od hid, B2' -= (c lr) od
+    // B2' lives negated in lane 0 of a per-lane constant that rides along in the wave reduction of hid * W2'.
+    constexpr float C = -LOG2E, IC = -LN2;
     const int lane = threadIdx.x & (WAVE - 1);
     const bool act = lane < H;
     const int hl = act ? lane : 0;
     const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
-    float w1[I], w2[O], b2[O];
+    const float clr = C * lr;
+    const float m0 = (lane == 0) ? 1.0f : 0.0f;
+    float w1[I], w2[O], cl[O];
 #pragma unroll
-    for (int i = 0; i < I; ++i) w1[i] = act ? w_in[i * H + hl] : 0.0f;
+    for (int i = 0; i < I; ++i) w1[i] = act ? C * w_in[i * H + hl] : 0.0f;
 #pragma unroll
-    for (int o = 0; o < O; ++o) w2[o] = act ? w_in[oW2 + hl * O + o] : 0.0f;
-    float b1 = act ? w_in[oB1 + hl] : 1.0e30f;
+    for (int o = 0; o < O; ++o) w2[o] = act ? C * w_in[oW2 + hl * O + o] : 0.0f;
+    float b1 = act ? C * w_in[oB1 + hl] : -1.0e30f;          // inactive lanes: exponent +1e30 -> hid == 0 exactly
 #pragma unroll
-    for (int o = 0; o < O; ++o) b2[o] = w_in[oB2 + o];
+    for (int o = 0; o < O; ++o) cl[o] = (lane == 0) ? -C * w_in[oB2 + o] : 0.0f;
 
-    float xn[I + 1];
-    lds_load<I + 1>(xy, xn);
-    for (int n = 0; n < Ntr; ++n) {
-        float x[I + 1];
+    auto row_step = [&](const float (&x)[I + 1]) {
+        float z = fmaf(x[0], w1[0], -b1);
 #pragma unroll
-        for (int i = 0; i <= I; ++i) x[i] = xn[i];
-        const int nn = (n + 1 < Ntr) ? n + 1 : n;
-        lds_load<I + 1>(xy + nn * IPY, xn);               // prefetch the next row (wave-uniform address)
-
-        float z = -b1;
-#pragma unroll
-        for (int i = 0; i < I; ++i) z = fmaf(x[i], w1[i], z);
-        const float hid = sigmoidf_fast(z);
-        const float dh = hid * (1.0f - hid);
+        for (int i = 1; i < I; ++i) z = fmaf(x[i], w1[i], z);
+        const float hid = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
+        const float dh = fmaf(-hid, hid, hid);                 // hid (1 - hid)
+        const float ldh = lr * dh;
         float g = 0.0f;
         float lod[O];
 #pragma unroll
         for (int o = 0; o < O; ++o) {
-            const float s = group_allsum<NRED>(hid * w2[o]);
-            const float out = sigmoidf_fast(s - b2[o]);
+            const float zo = group_allsum<NRED>(fmaf(hid, w2[o], cl[o]));
+            const float out = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zo));
             float t;
             if (TASK == TASK_CLS) t = ((int)x[I] == o) ? 1.0f : 0.0f;   // one-hot(int(y)) (CLS:73-75)
-            else t = x[I + o];                                           // REG: O == 1
-            const float od = (t - out) * (out * (1.0f - out));
-            g = fmaf(od, w2[o], g);                                      // uses the pre-update W2 (Q4)
-            lod[o] = lr * od;
+            else t = x[I];                                               // REG: O == 1
+            const float od = (t - out) * fmaf(-out, out, out);
+            g = fmaf(od, w2[o], g);                                      // pre-update W2 (Q4)
+            lod[o] = clr * od;
         }
-        const float lhd = lr * (g * dh);
+        const float lhd = g * ldh;
 #pragma unroll
         for (int o = 0; o < O; ++o) {
             w2[o] = fmaf(lod[o], hid, w2[o]);
-            b2[o] -= lod[o];
+            cl[o] = fmaf(lod[o], m0, cl[o]);
         }
 #pragma unroll
         for (int i = 0; i < I; ++i) w1[i] = fmaf(lhd, x[i], w1[i]);
         b1 -= lhd;
+    };
+
+    // two rows in flight: while one is computed the other's inputs (and the row after) are already on their way.
+    // The data image carries two padding rows, so the look-ahead never leaves it.
+    float xa[I + 1], xb[I + 1];
+    lds_load<I + 1>(xy, xa);
+    lds_load<I + 1>(xy + IPY, xb);
+    const float* pr = xy + 2 * IPY;
+    int n = 0;
+    for (; n + 1 < Ntr; n += 2) {
+        row_step(xa);
+        lds_load<I + 1>(pr, xa);
+        row_step(xb);
+        lds_load<I + 1>(pr + IPY, xb);
+        pr += 2 * IPY;
     }
+    if (n < Ntr) row_step(xa);
+
     if (act) {
 #pragma unroll
-        for (int i = 0; i < I; ++i) w_out[i * H + lane] = w1[i];
+        for (int i = 0; i < I; ++i) w_out[i * H + lane] = IC * w1[i];
 #pragma unroll
-        for (int o = 0; o < O; ++o) w_out[oW2 + lane * O + o] = w2[o];
-        w_out[oB1 + lane] = b1;
+        for (int o = 0; o < O; ++o) w_out[oW2 + lane * O + o] = IC * w2[o];
+        w_out[oB1 + lane] = IC * b1;
     }
     if (lane == 0) {
 #pragma unroll
-        for (int o = 0; o < O; ++o) w_out[oB2 + o] = b2[o];
+        for (int o = 0; o < O; ++o) w_out[oB2 + o] = -IC * cl[o];
     }
 }
 
@@ -220,11 +249,11 @@ __device__ __forceinline__ void sgd_sweep_dispatch(const float* w_in, float* w_o
 // packed forward layout: fw[h] = { W1[0..I-1][h], B1[h], W2[h][0..O-1], pad } (FWS floats, 16-B aligned rows),
 // then B2[0..O-1] at fw[H*FWS].  Built by all threads from a flat w.
 // ------------------------------------------------------------------------------------------------
-template <int I, int O>
+template <int I, int O, bool WL = false>
 __device__ __forceinline__ void build_fw(const float* __restrict__ w, float* __restrict__ fw, int H, int FWS) {
     const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
     constexpr int K = I + 1 + O;
-    for (int e = threadIdx.x; e < H * K; e += blockDim.x) {
+    for (int e = gtid<WL>(); e < H * K; e += gsize<WL>()) {
         const int h = e / K, c = e - h * K;
         float v;
         if (c < I) v = w[c * H + h];
@@ -232,7 +261,7 @@ __device__ __forceinline__ void build_fw(const float* __restrict__ w, float* __r
         else v = w[oW2 + h * O + (c - I - 1)];
         fw[h * FWS + c] = v;
     }
-    if (threadIdx.x < O) fw[H * FWS + threadIdx.x] = w[oB2 + threadIdx.x];
+    if (gtid<WL>() < O) fw[H * FWS + gtid<WL>()] = w[oB2 + gtid<WL>()];
 }
 
 // sums produced by one evaluation of (train ++ test) under a weight vector
@@ -243,7 +272,7 @@ struct EvalSums {
 
 // R2/R3/R6: one lane per data row; the block's threads stride over train ++ test.  Returns block-wide sums in every
 // thread (wave DPP reduction, then a fixed-order sum of the per-wave partials through LDS).
-template <int TASK, int I, int O>
+template <int TASK, int I, int O, bool WL = false>
 __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, const float* __restrict__ xy, int IPY,
                                               int FWS, int H, int Ntr, int Nall, float* __restrict__ red) {
     float a_tr = 0.f, b_tr = 0.f, c_tr = 0.f, a_te = 0.f, b_te = 0.f, c_te = 0.f;
@@ -251,7 +280,7 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
     float b2[O];
 #pragma unroll
     for (int o = 0; o < O; ++o) b2[o] = fw[H * FWS + o];
-    for (int n = threadIdx.x; n < Nall; n += blockDim.x) {
+    for (int n = gtid<WL>(); n < Nall; n += gsize<WL>()) {
         float x[I + 1];
         lds_load<I + 1>(xy + n * IPY, x);
         float acc[O];
@@ -302,7 +331,7 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
         b_te = wave_allsum(b_te); c_te = wave_allsum(c_te);
     }
     EvalSums s;
-    if (nw == 1) {
+    if (WL || nw == 1) {
         s.a_tr = a_tr; s.b_tr = b_tr; s.c_tr = c_tr; s.a_te = a_te; s.b_te = b_te; s.c_te = c_te;
         return s;
     }
@@ -321,10 +350,11 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
 }
 
 // block-wide sum of one value per thread, returned in every thread
+template <bool WL = false>
 __device__ __forceinline__ float block_sum(float s, float* __restrict__ red) {
     s = wave_allsum(s);
     const int nw = blockDim.x >> 6;
-    if (nw == 1) return s;
+    if (WL || nw == 1) return s;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * 8] = s;
     __syncthreads();
@@ -353,18 +383,20 @@ __device__ __forceinline__ float reg_residual(const float* __restrict__ row, con
 }
 
 // block-wide sum of squares of a vector in LDS (prior, REG:219)
+template <bool WL = false>
 __device__ __forceinline__ float block_sumsq(const float* __restrict__ v, int n, float* __restrict__ red) {
     float s = 0.f;
-    for (int j = threadIdx.x; j < n; j += blockDim.x) s = fmaf(v[j], v[j], s);
-    return block_sum(s, red);
+    for (int j = gtid<WL>(); j < n; j += gsize<WL>()) s = fmaf(v[j], v[j], s);
+    return block_sum<WL>(s, red);
 }
 
 // block-wide sum of squared differences (Langevin proposal ratio, REG:336-346)
+template <bool WL = false>
 __device__ __forceinline__ float block_sumsq_diff(const float* __restrict__ a, const float* __restrict__ b, int n,
                                                   float* __restrict__ red) {
     float s = 0.f;
-    for (int j = threadIdx.x; j < n; j += blockDim.x) { const float d = a[j] - b[j]; s = fmaf(d, d, s); }
-    return block_sum(s, red);
+    for (int j = gtid<WL>(); j < n; j += gsize<WL>()) { const float d = a[j] - b[j]; s = fmaf(d, d, s); }
+    return block_sum<WL>(s, red);
 }
 
 // likelihood / rmse / accuracy from the sums (R6: REG:200-205, CLS:209-222, 200-207); untempered log-likelihood
@@ -403,7 +435,7 @@ struct Lds {
 __device__ __forceinline__ Lds carve(float* base, int Nall, int IPY, int PS, int H, int FWS) {
     Lds l;
     float* q = base;
-    l.xy = q; q += Nall * IPY;
+    l.xy = q; q += (Nall + 2) * IPY;
     l.w_cur = q; q += PS;
     l.w_prop = q; q += PS;
     l.w_gd = q; q += PS;
@@ -416,14 +448,15 @@ __device__ __forceinline__ Lds carve(float* base, int Nall, int IPY, int PS, int
     return l;
 }
 __host__ __device__ inline size_t lds_floats(int Nall, int IPY, int PS, int H, int FWS) {
-    return (size_t)Nall * IPY + 6 * (size_t)PS + (size_t)(H + 1) * FWS + MAX_WAVES * 8 + 8;
+    return (size_t)(Nall + 2) * IPY + 6 * (size_t)PS + (size_t)(H + 1) * FWS + MAX_WAVES * 8 + 8;
 }
 
 // random tape of one step: noise[0..P) and scal[0..2] = {lx, u, n_eta}
+template <bool WL = false>
 __device__ __forceinline__ void tape_step(const SegParams& p, int gid, int step, float* __restrict__ noise,
                                           float* __restrict__ scal) {
     const int nq = (p.P + 3) >> 2;
-    for (int q = threadIdx.x; q <= nq; q += blockDim.x) {
+    for (int q = gtid<WL>(); q <= nq; q += gsize<WL>()) {
         const bool sc = (q == nq);
         uint32_t x[4];
         philox4x32_10(sc ? 0u : (uint32_t)q, (uint32_t)step, (uint32_t)gid, sc ? STREAM_STEP : STREAM_WNOISE, p.seed_lo,
@@ -439,6 +472,35 @@ __device__ __forceinline__ void tape_step(const SegParams& p, int gid, int step,
             *reinterpret_cast<float4*>(noise + 4 * q) = make_float4(n0, n1, n2, n3);
         }
     }
+}
+
+// R14 chain start-up: eta0 = log var(fx_train(w0) - y) (REG:270), prior (REG:280), tempered likelihood (REG:284).
+// WL = false: the whole work-group shares the rows; WL = true: the calling wave does it alone (the speculative
+// schedule uses wave 0 so that the result does not depend on the number of waves).
+template <int TASK, int I, int O, bool WL = false>
+__device__ __forceinline__ void chain_startup(const SegParams& p, const float* xy, const float* w_cur, float* fw, float* red,
+                                              float T, float& eta, float& lik, float& prior_cur) {
+    const int tid = gtid<WL>(), nthr = gsize<WL>(), H = p.H, Nall = p.Ntr + p.Nte;
+    build_fw<I, O, WL>(w_cur, fw, H, p.FWS);
+    gsync<WL>();
+    if (TASK == TASK_REG) {
+        // population variance of the residuals (np.var), two passes over the train rows
+        float s1 = 0.f;
+        for (int n = tid; n < p.Ntr; n += nthr) s1 += reg_residual<I, O>(xy + n * p.IPY, fw, p.FWS, H);
+        const float mean = block_sum<WL>(s1, red) / (float)p.Ntr;
+        float s2 = 0.f;
+        for (int n = tid; n < p.Ntr; n += nthr) {
+            const float d = reg_residual<I, O>(xy + n * p.IPY, fw, p.FWS, H) - mean;
+            s2 = fmaf(d, d, s2);
+        }
+        eta = logf_fast(block_sum<WL>(s2, red) / (float)p.Ntr);
+    }
+    const EvalSums s0 = eval_rows<TASK, I, O, WL>(fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, red);
+    float ll, r1, r2, a1, a2;
+    finish_eval<TASK>(s0, p.Ntr, p.Nte, eta, ll, r1, r2, a1, a2);
+    lik = ll / T;
+    const float ss = block_sumsq<WL>(w_cur, p.P, red);
+    prior_cur = prior_value<TASK>(p, ss, eta);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -459,7 +521,7 @@ __global__ void segment_kernel(const SegParams p, const int step_begin, const in
     {
         const float4* src = reinterpret_cast<const float4*>(p.data);
         float4* dst = reinterpret_cast<float4*>(l.xy);
-        for (int e = tid; e < (Nall * p.IPY) >> 2; e += nthr) dst[e] = src[e];
+        for (int e = tid; e < ((Nall + 2) * p.IPY) >> 2; e += nthr) dst[e] = src[e];
     }
     float* gw = p.w_state + (size_t)r * PS;
     for (int j = tid; j < PS; j += nthr) {
@@ -477,27 +539,7 @@ __global__ void segment_kernel(const SegParams p, const int step_begin, const in
     int nacc, gd_valid, lg_count;
 
     if (step_begin == 0) {
-        // R14 chain start-up: eta0 = log var(fx_train(w0) - y) (REG:270), prior (REG:280), tempered likelihood (REG:284)
-        build_fw<I, O>(l.w_cur, l.fw, H, p.FWS);
-        __syncthreads();
-        if (TASK == TASK_REG) {
-            // population variance of the residuals (np.var), two passes over the train rows
-            float s1 = 0.f;
-            for (int n = tid; n < p.Ntr; n += nthr) s1 += reg_residual<I, O>(l.xy + n * p.IPY, l.fw, p.FWS, H);
-            const float mean = block_sum(s1, l.red) / (float)p.Ntr;
-            float s2 = 0.f;
-            for (int n = tid; n < p.Ntr; n += nthr) {
-                const float d = reg_residual<I, O>(l.xy + n * p.IPY, l.fw, p.FWS, H) - mean;
-                s2 = fmaf(d, d, s2);
-            }
-            eta = logf_fast(block_sum(s2, l.red) / (float)p.Ntr);
-        }
-        const EvalSums s0 = eval_rows<TASK, I, O>(l.fw, l.xy, p.IPY, p.FWS, H, p.Ntr, Nall, l.red);
-        float ll, r1, r2, a1, a2;
-        finish_eval<TASK>(s0, p.Ntr, p.Nte, eta, ll, r1, r2, a1, a2);
-        lik = ll / T;
-        const float ss = block_sumsq(l.w_cur, P, l.red);
-        prior_cur = prior_value<TASK>(p, ss, eta);
+        chain_startup<TASK, I, O>(p, l.xy, l.w_cur, l.fw, l.red, T, eta, lik, prior_cur);
         tau_eta_last = eta;
         rec_rmse_tr = rec_rmse_te = rec_acc_tr = rec_acc_te = 0.f;
         nacc = 0; gd_valid = 0; lg_count = 0;
@@ -506,7 +548,7 @@ __global__ void segment_kernel(const SegParams p, const int step_begin, const in
         lik = sf[SF_LIK]; prior_cur = sf[SF_PRIOR]; tau_eta_last = sf[SF_TAU_LAST];
         rec_rmse_tr = sf[SF_REC_RMSE_TR]; rec_rmse_te = sf[SF_REC_RMSE_TE];
         rec_acc_tr = sf[SF_REC_ACC_TR]; rec_acc_te = sf[SF_REC_ACC_TE];
-        nacc = si[SI_NACC]; gd_valid = si[SI_GD_VALID]; lg_count = si[SI_LG_COUNT];
+        nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT];
     }
 
     const size_t trow = (size_t)r * p.S;
@@ -574,8 +616,12 @@ __global__ void segment_kernel(const SegParams p, const int step_begin, const in
             eta = eta_pro;
             rec_rmse_tr = rm_tr; rec_rmse_te = rm_te;
             rec_acc_tr = ac_tr; rec_acc_te = ac_te;       // REG: 0 (REG:403-404); CLS: accuracy (CLS:414-415)
-            gd_valid = 0;
-            for (int j = tid; j < P; j += nthr) { const float v = l.w_prop[j]; l.w_cur[j] = v; l.rec_w[j] = v; }
+            gd_valid = lg ? 1 : 0;                        // w_prop_gd is langevin_gradient(new w): keep it as the cache
+            for (int j = tid; j < P; j += nthr) {
+                const float v = l.w_prop[j];
+                l.w_cur[j] = v; l.rec_w[j] = v;
+                if (lg) l.w_gd[j] = l.w_pgd[j];
+            }
         }
         __syncthreads();
         // trace row i+1 (the only HBM traffic of a step)
@@ -602,8 +648,226 @@ __global__ void segment_kernel(const SegParams p, const int step_begin, const in
         sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur; sf[SF_TAU_LAST] = tau_eta_last;
         sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;
         sf[SF_REC_ACC_TR] = rec_acc_tr; sf[SF_REC_ACC_TE] = rec_acc_te;
-        si[SI_NACC] = nacc; si[SI_GD_VALID] = gd_valid; si[SI_LG_COUNT] = lg_count;
+        si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count;
         p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;      // Q11
+        p.L_final[gid] = lik;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Speculative schedule ("prefetching" Metropolis-Hastings).  The MH acceptance rate of these chains is low (1-15 %),
+// and every random draw is a pure function of (seed, replica, step), so wave v of the work-group computes step i+v
+// under the assumption that steps i .. i+v-1 are rejected -- the chain state (w, eta, likelihood, prior) they all start
+// from is then the same.  After one round the prefix up to and including the first accepted step is committed and the
+// rest is thrown away: the committed chain is exactly the sequential one, only the wall time per committed step drops
+// by (1 - (1-a)^k) / a for acceptance rate a and k waves.  Each wave runs its whole step alone (wave-local LDS
+// scratch, no work-group barrier inside a step), so the result does not depend on the number of waves.
+// ------------------------------------------------------------------------------------------------
+enum { SL_ACCEPT = 0, SL_LIKPROP, SL_PRIORPROP, SL_ETAPRO, SL_RM_TR, SL_RM_TE, SL_AC_TR, SL_AC_TE, SL_LG, SL_ADAPT, SL_COUNT = 16 };
+
+__host__ __device__ inline size_t spec_wave_floats(int PS, int H, int FWS) { return 3 * (size_t)PS + (size_t)(H + 1) * FWS + 8; }
+__host__ __device__ inline size_t spec_lds_floats(int Nall, int IPY, int PS, int H, int FWS, int NW) {
+    return (size_t)(Nall + 2) * IPY + 3 * (size_t)PS + MAX_WAVES * 8 + (size_t)NW * SL_COUNT + (size_t)NW * spec_wave_floats(PS, H, FWS);
+}
+
+template <int TASK, int I, int O>
+__global__ void segment_spec_kernel(const SegParams p, const int step_begin, const int n_steps) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int r = blockIdx.x;
+    const int gid = p.first_global + r;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int wave = tid >> 6, lane = tid & 63, NW = nthr >> 6;
+    const int Nall = p.Ntr + p.Nte;
+    const int P = p.P, PS = p.PS, H = p.H;
+    // shared part
+    float* q = smem;
+    float* xy = q; q += (Nall + 2) * p.IPY;
+    float* w_cur = q; q += PS;
+    float* w_gd = q; q += PS;
+    float* rec_w = q; q += PS;
+    float* red = q; q += MAX_WAVES * 8;
+    float* slots = q; q += NW * SL_COUNT;
+    // private part of every wave
+    const size_t wfl = spec_wave_floats(PS, H, p.FWS);
+    float* priv0 = q;
+    float* mine = priv0 + (size_t)wave * wfl;
+    float* my_prop = mine;
+    float* my_pgd = mine + PS;
+    float* my_noise = mine + 2 * PS;
+    float* my_fw = mine + 3 * PS;
+    float* my_scal = my_fw + (H + 1) * p.FWS;
+
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.data);
+        float4* dst = reinterpret_cast<float4*>(xy);
+        for (int e = tid; e < ((Nall + 2) * p.IPY) >> 2; e += nthr) dst[e] = src[e];
+    }
+    float* gw = p.w_state + (size_t)r * PS;
+    for (int j = tid; j < PS; j += nthr) {
+        w_cur[j] = gw[j];
+        rec_w[j] = p.rec_w[(size_t)r * PS + j];
+        w_gd[j] = p.gd_w[(size_t)r * PS + j];
+    }
+    __syncthreads();
+
+    const float T = p.temps[r];
+    float eta = (TASK == TASK_REG) ? w_cur[P] : 0.0f;
+    float* sf = p.st_f + (size_t)r * SF_COUNT;
+    int* si = p.st_i + (size_t)r * SI_COUNT;
+    float lik, prior_cur, tau_eta_last, rec_rmse_tr, rec_rmse_te, rec_acc_tr, rec_acc_te;
+    int nacc, gd_valid, lg_count;
+    if (step_begin == 0) {
+        if (wave == 0) {                                       // wave 0 alone: independent of the wave count
+            chain_startup<TASK, I, O, true>(p, xy, w_cur, my_fw, red, T, eta, lik, prior_cur);
+            if (lane == 0) { red[0] = eta; red[1] = lik; red[2] = prior_cur; }
+        }
+        __syncthreads();
+        eta = red[0]; lik = red[1]; prior_cur = red[2];
+        tau_eta_last = eta;
+        rec_rmse_tr = rec_rmse_te = rec_acc_tr = rec_acc_te = 0.f;
+        nacc = 0; gd_valid = 0; lg_count = 0;
+        __syncthreads();
+    } else {
+        lik = sf[SF_LIK]; prior_cur = sf[SF_PRIOR]; tau_eta_last = sf[SF_TAU_LAST];
+        rec_rmse_tr = sf[SF_REC_RMSE_TR]; rec_rmse_te = sf[SF_REC_RMSE_TE];
+        rec_acc_tr = sf[SF_REC_ACC_TR]; rec_acc_te = sf[SF_REC_ACC_TE];
+        nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT];
+    }
+
+    const size_t trow = (size_t)r * p.S;
+    const int end = step_begin + n_steps;
+    int i = step_begin;
+    while (i < end) {
+        if (i == p.switch_step) {
+            // R10 (REG:320-324): canonical from here on; re-evaluate the current w with the LAST PROPOSED tau (Q9)
+            if (wave == 0) {
+                build_fw<I, O, true>(w_cur, my_fw, H, p.FWS);
+                gsync<true>();
+                const EvalSums sc = eval_rows<TASK, I, O, true>(my_fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, nullptr);
+                float l2, r1, r2, a1, a2;
+                finish_eval<TASK>(sc, p.Ntr, p.Nte, tau_eta_last, l2, r1, r2, a1, a2);
+                if (lane == 0) red[0] = l2;
+            }
+            __syncthreads();
+            lik = red[0];
+            __syncthreads();
+        }
+        int k = min(NW, end - i);
+        if (p.switch_step > i) k = min(k, p.switch_step - i);     // a round never straddles the temperature switch
+        const int j = i + wave;
+        const bool active = wave < k;
+        bool lg = false;
+        float u = 0.f, n_eta = 0.f;
+        if (active) {
+            tape_step<true>(p, gid, j, my_noise, my_scal);
+            gsync<true>();
+            const float lx = my_scal[0];
+            u = my_scal[1];
+            n_eta = my_scal[2];
+            lg = p.use_lg && (lx < p.l_prob);
+        }
+        if (p.use_lg) {
+            // w_gd = langevin_gradient(w): one sweep serves every speculative step of this and later rounds until w changes
+            const int need = __syncthreads_or((active && lg && !gd_valid) ? 1 : 0);
+            if (need) {
+                if (wave == 0) sgd_sweep_dispatch<TASK, I, O>(w_cur, w_gd, xy, p.IPY, p.Ntr, H, p.lr);
+                gd_valid = 1;
+                __syncthreads();
+            }
+        }
+        if (active) {
+            const float adapttemp = (p.switch_step >= 0 && j >= p.switch_step) ? 1.0f : T;
+            float diff_prop = 0.0f;
+            if (lg) {
+                for (int e = lane; e < P; e += WAVE) my_prop[e] = fmaf(p.step_w, my_noise[e], w_gd[e]);
+                gsync<true>();
+                sgd_sweep_dispatch<TASK, I, O>(my_prop, my_pgd, xy, p.IPY, p.Ntr, H, p.lr);
+                gsync<true>();
+                const float d1 = block_sumsq_diff<true>(w_cur, my_pgd, P, nullptr);
+                const float d2 = block_sumsq<true>(my_noise, P, nullptr);
+                diff_prop = (-0.5f * d1 / (p.step_w * p.step_w) + 0.5f * d2) / adapttemp;
+            } else {
+                for (int e = lane; e < P; e += WAVE) my_prop[e] = fmaf(p.step_w, my_noise[e], w_cur[e]);
+                gsync<true>();
+            }
+            float eta_pro = eta;
+            if (TASK == TASK_REG) eta_pro = fmaf(p.step_eta, n_eta, eta);
+            build_fw<I, O, true>(my_prop, my_fw, H, p.FWS);
+            gsync<true>();
+            const EvalSums es = eval_rows<TASK, I, O, true>(my_fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, nullptr);
+            float ll, rm_tr, rm_te, ac_tr, ac_te;
+            finish_eval<TASK>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
+            const float lik_prop = ll / adapttemp;
+            const float ssq = block_sumsq<true>(my_prop, P, nullptr);
+            const float prior_prop = prior_value<TASK>(p, ssq, eta_pro);
+            const float logalpha = (lik_prop - lik) + (prior_prop - prior_cur) + diff_prop;
+            const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
+            if (p.use_lg && !lg && (u < mh)) {
+                // an accepted random-walk step: run the SGD epoch from its proposal now, so langevin_gradient(new w)
+                // is already there when the step is committed (the Langevin waves of this round are sweeping anyway)
+                sgd_sweep_dispatch<TASK, I, O>(my_prop, my_pgd, xy, p.IPY, p.Ntr, H, p.lr);
+                gsync<true>();
+            }
+            if (lane == 0) {
+                float* sl = slots + wave * SL_COUNT;
+                sl[SL_ACCEPT] = (u < mh) ? 1.0f : 0.0f;
+                sl[SL_LIKPROP] = lik_prop; sl[SL_PRIORPROP] = prior_prop; sl[SL_ETAPRO] = eta_pro;
+                sl[SL_RM_TR] = rm_tr; sl[SL_RM_TE] = rm_te; sl[SL_AC_TR] = ac_tr; sl[SL_AC_TE] = ac_te;
+                sl[SL_LG] = lg ? 1.0f : 0.0f; sl[SL_ADAPT] = adapttemp;
+            }
+        }
+        __syncthreads();
+        // commit the prefix up to and including the first accepted step
+        int m = k;
+        for (int v = k - 1; v >= 0; --v) m = (slots[v * SL_COUNT + SL_ACCEPT] != 0.0f) ? v : m;
+        const int ncommit = (m < k) ? m + 1 : k;
+        if (wave < ncommit) {
+            const bool acc_me = (wave == m);
+            const float* srcw = acc_me ? my_prop : rec_w;
+            float* prow = p.tr_pos_w + (trow + j + 1) * (size_t)P;
+            for (int e = lane; e < P; e += WAVE) prow[e] = srcw[e];
+            if (lane == 0) {
+                const float* sl = slots + wave * SL_COUNT;
+                p.tr_likeh[trow + j + 1] = (TASK == TASK_REG) ? sl[SL_LIKPROP] : sl[SL_LIKPROP] * sl[SL_ADAPT];
+                p.tr_accept[trow + j + 1] = nacc;                                   // count BEFORE this step (REG:380)
+                p.tr_rmse_tr[trow + j + 1] = acc_me ? sl[SL_RM_TR] : rec_rmse_tr;
+                p.tr_rmse_te[trow + j + 1] = acc_me ? sl[SL_RM_TE] : rec_rmse_te;
+                p.tr_acc_tr[trow + j + 1] = acc_me ? sl[SL_AC_TR] : rec_acc_tr;
+                p.tr_acc_te[trow + j + 1] = acc_me ? sl[SL_AC_TE] : rec_acc_te;
+            }
+        }
+        for (int v = 0; v < ncommit; ++v) lg_count += (slots[v * SL_COUNT + SL_LG] != 0.0f) ? 1 : 0;
+        if (TASK == TASK_REG) tau_eta_last = slots[(ncommit - 1) * SL_COUNT + SL_ETAPRO];
+        __syncthreads();                                    // every reader of rec_w is done
+        if (m < k) {
+            const float* sl = slots + m * SL_COUNT;
+            const float* wacc = priv0 + (size_t)m * wfl;
+            nacc += 1;
+            lik = sl[SL_LIKPROP]; prior_cur = sl[SL_PRIORPROP]; eta = sl[SL_ETAPRO];
+            rec_rmse_tr = sl[SL_RM_TR]; rec_rmse_te = sl[SL_RM_TE]; rec_acc_tr = sl[SL_AC_TR]; rec_acc_te = sl[SL_AC_TE];
+            // the accepted Langevin step already ran the SGD epoch from its proposal: that IS langevin_gradient(new w)
+            gd_valid = p.use_lg ? 1 : 0;
+            for (int e = tid; e < P; e += nthr) {
+                const float v = wacc[e];
+                w_cur[e] = v; rec_w[e] = v;
+                if (p.use_lg) w_gd[e] = wacc[PS + e];
+            }
+        }
+        __syncthreads();
+        i += ncommit;
+    }
+
+    for (int j = tid; j < PS; j += nthr) {
+        gw[j] = (j == P) ? eta : w_cur[j];
+        p.rec_w[(size_t)r * PS + j] = rec_w[j];
+        p.gd_w[(size_t)r * PS + j] = w_gd[j];
+    }
+    if (tid == 0) {
+        sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur; sf[SF_TAU_LAST] = tau_eta_last;
+        sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;
+        sf[SF_REC_ACC_TR] = rec_acc_tr; sf[SF_REC_ACC_TE] = rec_acc_te;
+        si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count;
+        p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;
         p.L_final[gid] = lik;
     }
 }
@@ -618,7 +882,10 @@ struct SwapParams {
     const float* L;            // [R] posted scalars
     const float* cur;          // [Rl][PS]
     float* next;               // [Rl][PS]
-    int* st_i;                 // [Rl][SI_COUNT]
+    const float* gd_cur;       // [Rl][PS] cached langevin_gradient(w) rows, travel with w inside one GPU
+    float* gd_next;            // [Rl][PS]
+    const int* gd_valid_cur;   // [Rl]
+    int* gd_valid_next;        // [Rl]
     int* src_out;              // [R] (may be null)
     long long* counters;       // [0] num_swap, [1] total_swap_proposals
     int* src_log;              // [max_rounds][R] (may be null)
@@ -665,12 +932,18 @@ __global__ void swap_kernel(const SwapParams sp, const int round, const int mode
         const int k = sp.first_global + b;
         const int s = sSrc[k];
         const int sl = s - sp.first_global;
+        // gd_valid of the destination = gd_valid of the source when the source is local; a row that arrives from
+        // another GPU comes without its cached gradient
+        int valid = 0;
         if (sl >= 0 && sl < sp.Rl) {
             const float* from = sp.cur + (size_t)sl * sp.PS;
             float* to = sp.next + (size_t)b * sp.PS;
-            for (int j = threadIdx.x; j < sp.PS; j += blockDim.x) to[j] = from[j];
+            const float* gfrom = sp.gd_cur + (size_t)sl * sp.PS;
+            float* gto = sp.gd_next + (size_t)b * sp.PS;
+            for (int j = threadIdx.x; j < sp.PS; j += blockDim.x) { to[j] = from[j]; gto[j] = gfrom[j]; }
+            valid = sp.gd_valid_cur[sl];
         }
-        if (s != k && threadIdx.x == 0) sp.st_i[(size_t)b * SI_COUNT + SI_GD_VALID] = 0;
+        if (threadIdx.x == 0) sp.gd_valid_next[b] = valid;
     }
     if (b == 0) {
         if (sp.src_out) for (int k = threadIdx.x; k < sp.R; k += blockDim.x) sp.src_out[k] = sSrc[k];
@@ -702,7 +975,7 @@ __global__ void model_kernel(const SegParams p, const int mode, const float* __r
     {
         const float4* src = reinterpret_cast<const float4*>(p.data);
         float4* dst = reinterpret_cast<float4*>(l.xy);
-        for (int e = tid; e < (Nall * p.IPY) >> 2; e += nthr) dst[e] = src[e];
+        for (int e = tid; e < ((Nall + 2) * p.IPY) >> 2; e += nthr) dst[e] = src[e];
     }
     for (int j = tid; j < p.P; j += nthr) l.w_cur[j] = w_in[(size_t)b * p.P + j];
     __syncthreads();

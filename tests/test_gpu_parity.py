@@ -108,8 +108,8 @@ TRAJ = ["reg_rw", "reg_lg", "reg_lg_mackey", "cls_rw", "cls_lg", "cls_rw_ions", 
 
 
 @pytest.mark.parametrize("key", TRAJ)
-@pytest.mark.parametrize("waves", [1, 4])
-def test_single_replica_trajectory(key, waves):
+@pytest.mark.parametrize("schedule,waves", [(1, 1), (1, 4), (2, 1), (2, 0)])
+def test_single_replica_trajectory(key, schedule, waves):
     """F4: one chain (no swaps) against the trace the reference's ptReplica.run produced on the same random tape."""
     g = parity.golden(f"trajectory_{key}.npz")
     topo = tuple(int(v) for v in g["topology"])
@@ -127,7 +127,7 @@ def test_single_replica_trajectory(key, waves):
         rep.step(i)
         la[i], lu[i] = rep.last_logalpha, np.log(rep.last_u)
     s = parity.make_sampler(task, topo, train, test, R_local=1, R_global=8, first=gid, S=S, si=10 * S,
-                            use_lg=bool(g["use_lg"]), lr=float(g["lr"]), seed=seed, waves=waves)
+                            use_lg=bool(g["use_lg"]), lr=float(g["lr"]), seed=seed, waves=waves, schedule=schedule)
     s.set_state(w0[None, :], np.array([float(g["T"])], dtype=np.float32))
     while s.steps_done() < S - 1:
         assert s.run_segment() == 0
@@ -154,7 +154,8 @@ SWAPTRAJ = ["reg", "reg_nophantom", "cls", "cls_nophantom"]
 
 
 @pytest.mark.parametrize("key", SWAPTRAJ)
-def test_full_pt_run_with_swaps(key):
+@pytest.mark.parametrize("schedule", [1, 2])
+def test_full_pt_run_with_swaps(key, schedule):
     """F6: whole ladder with swap rounds (cascade, stale likelihood, trigger index, phantom round) vs the oracle, which
     test_oracle_golden pins to the reference's multi-process run_chains on this tape."""
     g = parity.golden(f"swap_trajectory_{key}.npz")
@@ -172,7 +173,7 @@ def test_full_pt_run_with_swaps(key):
                      pt.tape, rep.gid)
     o = parity.OracleRun(pt).run()
     s = parity.make_sampler(task, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=bool(g["use_lg"]),
-                            lr=float(g["lr"]), seed=seed)
+                            lr=float(g["lr"]), seed=seed, schedule=schedule)
     s.set_state(w0, np.array(pt.temperatures, dtype=np.float32))
     s.run(-1)
     s.sync()
@@ -296,6 +297,46 @@ def test_invariants_at_full_size():
     tr3 = s3.traces()
     assert (tr3["pos_w"] == tr["pos_w"]).all() and (tr3["accept"] == tr["accept"]).all()
     s.close(); s2.close(); s3.close()
+
+
+@pytest.mark.parametrize("case", ["sunspot_lg", "iris_lg", "ions_rw"])
+def test_speculative_schedule_is_wave_count_invariant(case):
+    """Wave v of a work-group pre-computes step i+v; only the prefix up to the first accept is committed.  The committed
+    chain must not depend on how many steps were speculated: 1, 2, 4, 8 and 16 waves give bit-identical traces."""
+    d = ds()
+    if case == "sunspot_lg":
+        task, topo, name, lg, lr, R, S, si, mt = 0, (4, 5, 1), "sunspot", True, 0.1, 8, 400, 20, 2
+    elif case == "iris_lg":
+        task, topo, name, lg, lr, R, S, si, mt = 1, (4, 12, 3), "iris", True, 0.01, 6, 300, 10, 10
+    else:
+        task, topo, name, lg, lr, R, S, si, mt = 1, (34, 50, 2), "ions", False, 0.01, 4, 100, 10, 10
+    P = orc.num_param(topo)
+    tape = orc.PhiloxTape(77)
+    w0 = np.stack([tape.w_init(r, P) for r in range(R)]).astype(np.float32)
+    T = np.array(orc.temperature_ladder(R, mt), dtype=np.float32)
+    ref = None
+    for waves in (1, 2, 4, 8, 16):
+        try:
+            s = parity.make_sampler(task, topo, d[name + "_train"], d[name + "_test"], R_local=R, R_global=R, first=0, S=S,
+                                    si=si, use_lg=lg, lr=lr, seed=77, waves=waves, schedule=2)
+        except Exception as e:                      # more waves than the LDS budget admits: the library says so
+            assert "LDS" in str(e), e
+            continue
+        s.set_state(w0, T)
+        s.run(-1)
+        s.sync()
+        got = (s.traces(), s.swap_stats(), s.swap_log().copy(), s.state())
+        s.close()
+        if ref is None:
+            ref = got
+            assert got[1][2] == S // si
+            continue
+        assert got[1] == ref[1] and (got[2] == ref[2]).all()
+        for k in got[0]:
+            assert (got[0][k] == ref[0][k]).all(), (waves, k)
+        for k in got[3]:
+            assert (got[3][k] == ref[3][k]).all(), (waves, k)
+    assert ref is not None
 
 
 def test_smoke_entry():
