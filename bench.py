@@ -60,13 +60,13 @@ def switch_step(S):
     return int(pt) if pt == int(pt) else -1
 
 
-def make_sampler(train, test, R_local, R_global, first, S, device, use_lg=True, schedule=0, waves=0):
+def make_sampler(train, test, R_local, R_global, first, S, device, use_lg=True, schedule=0, waves=0, groups=0):
     import ptnn_amd
     from ptnn_amd import _lib, ladder, philox
     s = _lib.Sampler(device_id=device, task=_lib.TASK_REG, n_in=TOPO[0], n_hidden=TOPO[1], n_out=TOPO[2],
                      n_replicas_local=R_local, n_replicas_global=R_global, first_global_replica=first, n_samples=S,
                      swap_interval=SWAP_INTERVAL, pt_switch_step=switch_step(S), use_langevin=int(use_lg),
-                     waves_per_replica=waves, schedule=schedule, l_prob=L_PROB, learn_rate=LR, step_w=0.025, step_eta=0.2, sigma_squared=25.0,
+                     waves_per_replica=waves, schedule=schedule, groups_per_replica=groups, l_prob=L_PROB, learn_rate=LR, step_w=0.025, step_eta=0.2, sigma_squared=25.0,
                      nu_1=0.0, nu_2=0.0, seed=SEED)
     s.set_data(train, test)
     T = ladder.temperatures(R_global, MAXTEMP)[first:first + R_local]
@@ -117,7 +117,8 @@ def main():
     ap.add_argument("--rw", action="store_true", help="random-walk proposals only (extra data point)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--schedule", type=int, default=0, help="0 auto, 1 cooperative, 2 speculative")
-    ap.add_argument("--waves", type=int, default=0, help="wavefronts per replica (0 = auto)")
+    ap.add_argument("--waves", type=int, default=0, help="wavefronts per work-group (0 = auto)")
+    ap.add_argument("--groups", type=int, default=0, help="work-groups (CUs) per replica, speculative schedule (0 = auto)")
     a = ap.parse_args()
     K, W, N = a.steps, a.warmup, a.gpus
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,7 +138,7 @@ def main():
     if N == 1 and rank == 0 and not a.no_cpu_baseline:
         cpu = cpu_baseline(train, test)      # before the first HIP call: the pool forks
     if N == 1:
-        s = make_sampler(train, test, R_PER_GPU, R_global, 0, S, local_rank, use_lg, a.schedule, a.waves)
+        s = make_sampler(train, test, R_PER_GPU, R_global, 0, S, local_rank, use_lg, a.schedule, a.waves, a.groups)
         s.run(W * si + 1)            # REG hands off after step i = k*si (REG:427): start the timed region on an interval boundary
         s.sync()
         s.kernel_time(reset=True)
@@ -157,7 +158,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         from ptnn_amd import distributed as dm
-        s = make_sampler(train, test, R_PER_GPU, R_global, rank * R_PER_GPU, S, local_rank, use_lg, a.schedule, a.waves)
+        s = make_sampler(train, test, R_PER_GPU, R_global, rank * R_PER_GPU, S, local_rank, use_lg, a.schedule, a.waves, a.groups)
         lad = dm.ShardedLadder(dm.DeviceShard(s, local_rank), rank, N, dist)
         lad.run_intervals(W)
         s.sync()
@@ -195,7 +196,7 @@ def main():
                                    + ("Langevin p=0.5 lr=0.1" if use_lg else "random-walk") +
                                    f", maxtemp {MAXTEMP}, swap every {si} MH steps; 1 bench step = 1 swap interval",
                        "replicas": R_global, "mh_steps_per_bench_step": si, "proposals": "langevin" if use_lg else "rw",
-                       "schedule": a.schedule, "waves_per_replica": a.waves},
+                       "schedule": a.schedule, "waves_per_replica": a.waves, "groups_per_replica": a.groups},
             "swap_accept_pct": 100.0 * (nsw1 - nsw0) / max(tot1 - tot0, 1),
             "mh_accept_pct": float(100.0 * np.mean(accepted) / max(steps_done, 1)),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

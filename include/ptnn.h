@@ -49,6 +49,8 @@ typedef struct ptnn_config {
     int32_t waves_per_replica;    /* 0 = auto; 1,2,4,8,16: wavefronts of the work-group that owns one replica */
     int32_t schedule;             /* 0 = auto, 1 = cooperative (all waves share one MH step), 2 = speculative
                                    * (wave v pre-computes step i+v; identical chain) */
+    int32_t groups_per_replica;   /* speculative schedule: work-groups (CUs) cooperating on one replica; 0 = auto
+                                   * (as many of 1, 2, 4 as keeps replicas x groups <= number of CUs) */
     float l_prob;                 /* langevin_prob (REG:174); CLS fixes 0.5 (CLS:192) */
     float learn_rate;             /* SGD step of langevin_gradient (REG:33) */
     float step_w;                 /* 0.025 (REG:258) */

@@ -79,6 +79,11 @@ struct ptnn_handle {
     size_t seg_lds = 0, model_lds = 0;
     int model_threads = 64;
     bool speculative = false;
+    int groups = 1;                 // work-groups (CUs) per replica in the speculative schedule
+    unsigned epoch_base = 0;
+    int num_cus = 0;
+    unsigned long long *d_xslots = nullptr, *d_xw = nullptr;
+    int* d_error = nullptr;
     bool have_data = false, have_state = false, finalized = false;
     int cur = 0;            // next MH step index
     int rounds_done = 0;    // swap rounds counted (including the phantom one)
@@ -122,6 +127,7 @@ struct ptnn_handle {
         p.L_handoff = d_L_handoff; p.L_final = d_L_final;
         p.tr_pos_w = d_pos_w; p.tr_likeh = d_likeh; p.tr_rmse_tr = d_rmse_tr; p.tr_rmse_te = d_rmse_te;
         p.tr_acc_tr = d_acc_tr; p.tr_acc_te = d_acc_te; p.tr_accept = d_accept;
+        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.error_flag = d_error;
         return p;
     }
 };
@@ -162,8 +168,10 @@ int launch_segment(ptnn_handle* h, int begin, int n) {
     auto& ev = h->timing[h->timing_used++];
     const SegParams p = h->seg_params();
     HIP_TRY(hipEventRecord(ev.first, h->stream));
-    hipLaunchKernelGGL(h->speculative ? h->shape->spec : h->shape->seg, dim3(h->cfg.n_replicas_local), dim3(h->nthreads),
-                       h->seg_lds, h->stream, p, begin, n);
+    const int grid = h->cfg.n_replicas_local * (h->speculative ? h->groups : 1);
+    hipLaunchKernelGGL(h->speculative ? h->shape->spec : h->shape->seg, dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream, p,
+                       begin, n);
+    h->epoch_base += (unsigned)n + 1u;                    // granule tags never repeat across launches
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, h->stream));
     return 0;
@@ -237,6 +245,7 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
     ptnn_handle* h = new ptnn_handle();
     h->cfg = *cfg;
     h->shape = sh;
+    h->num_cus = prop.multiProcessorCount;
     const int I = cfg->n_in, H = cfg->n_hidden, O = cfg->n_out;
     h->P = I * H + H * O + H + O;
     h->PS = round_up4(h->P + 1);
@@ -267,6 +276,8 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
     HIP_TRY(hipMalloc(&h->d_src, R * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_src_log, (size_t)h->max_rounds * R * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_counters, 2 * sizeof(long long)));
+    HIP_TRY(hipMalloc(&h->d_error, sizeof(int)));
+    HIP_TRY(hipMemsetAsync(h->d_error, 0, sizeof(int), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(long long), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_L_handoff, 0, R * sizeof(float), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_L_final, 0, R * sizeof(float), h->stream));
@@ -281,7 +292,7 @@ int ptnn_destroy(ptnn_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_data, h->d_state[0], h->d_state[1], h->d_rec_w, h->d_gd_w[0], h->d_gd_w[1], h->d_gd_valid[0], h->d_gd_valid[1], h->d_st_f, h->d_st_i, h->d_temps,
                     h->d_L_handoff, h->d_L_final, h->d_pos_w, h->d_likeh, h->d_rmse_tr, h->d_rmse_te, h->d_acc_tr,
-                    h->d_acc_te, h->d_accept, h->d_src, h->d_src_log, h->d_counters};
+                    h->d_acc_te, h->d_accept, h->d_src, h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& ev : h->timing) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -330,14 +341,38 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
     coop_nw = std::min(pow2, 8);
     h->model_threads = coop_nw * 64;
     if (sched == PTNN_SCHED_SPECULATIVE) {
-        int k = nw ? nw : 8;                                  // 2 waves per SIMD: each still issues at single-wave rate
-        while (k > 1 && spec_lds_floats(Nall, IPY, h->PS, H, h->FWS, k) * sizeof(float) > LDS_MAX) k >>= 1;
+        // Two waves on one SIMD slow each other ~1.65x (the SGD sweep is VALU-issue bound), so speculation depth comes
+        // from more CUs first: G work-groups of 4 waves (one per SIMD) per replica while R*G <= number of CUs, and
+        // 8 waves on a single CU otherwise.
+        const int Rl = h->cfg.n_replicas_local;
+        int G = 1;
+        if (h->cfg.groups_per_replica > 0) G = h->cfg.groups_per_replica;
+        else { while (G < 4 && Rl * (G * 2) <= h->num_cus) G *= 2; }
+        if (G != 1 && G != 2 && G != 4 && G != 8) return fail(-1, "groups_per_replica must be 0 (auto), 1, 2, 4 or 8");
+        if (Rl * G > h->num_cus * 2)
+            return fail(-3, "%d replicas x %d work-groups cannot all be resident on %d CUs", Rl, G, h->num_cus);
+        int k = nw ? nw : (G > 1 ? 4 : 8);
+        while (k > 1 && spec_lds_floats(Nall, IPY, h->PS, H, h->FWS, k, G) * sizeof(float) > LDS_MAX) k >>= 1;
         if (nw && k != nw) {
             if (h->cfg.schedule == PTNN_SCHED_AUTO) k = 0;      // auto: fall back to the cooperative schedule below
             else return fail(-3, "speculative schedule with %d waves needs more than 160 KiB of LDS", nw);
         }
-        if (k == 0 || spec_lds_floats(Nall, IPY, h->PS, H, h->FWS, k) * sizeof(float) > LDS_MAX) sched = PTNN_SCHED_COOPERATIVE;
-        else { h->speculative = true; h->nthreads = k * 64; h->seg_lds = spec_lds_floats(Nall, IPY, h->PS, H, h->FWS, k) * sizeof(float); }
+        if (k * G > MAX_SLOTS) return fail(-1, "waves x groups must not exceed %d", MAX_SLOTS);
+        if (k == 0 || spec_lds_floats(Nall, IPY, h->PS, H, h->FWS, k, G) * sizeof(float) > LDS_MAX) sched = PTNN_SCHED_COOPERATIVE;
+        else {
+            h->speculative = true; h->nthreads = k * 64; h->groups = G;
+            h->seg_lds = spec_lds_floats(Nall, IPY, h->PS, H, h->FWS, k, G) * sizeof(float);
+            if (h->d_xslots) { HIP_TRY(hipFree(h->d_xslots)); h->d_xslots = nullptr; }
+            if (h->d_xw) { HIP_TRY(hipFree(h->d_xw)); h->d_xw = nullptr; }
+            if (G > 1) {
+                const size_t ns = (size_t)Rl * 2 * MAX_SLOTS * SL_COUNT, nx = (size_t)Rl * 2 * MAX_SLOTS * 2 * h->PS;
+                HIP_TRY(hipMalloc(&h->d_xslots, ns * sizeof(unsigned long long)));
+                HIP_TRY(hipMalloc(&h->d_xw, nx * sizeof(unsigned long long)));
+                HIP_TRY(hipMemset(h->d_xslots, 0, ns * sizeof(unsigned long long)));
+                HIP_TRY(hipMemset(h->d_xw, 0, nx * sizeof(unsigned long long)));
+                h->epoch_base = 1;                              // tag 0 = never written
+            }
+        }
     }
     if (sched == PTNN_SCHED_COOPERATIVE) {
         h->speculative = false;
@@ -432,6 +467,10 @@ int ptnn_sync(ptnn_handle* h) {
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     HIP_TRY(hipStreamSynchronize(h->stream));
     collect_timing(h);
+    int err = 0;
+    HIP_TRY(hipMemcpy(&err, h->d_error, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) return fail(-5, "a cross-work-group hand-off timed out inside the segment kernel (%d work-groups gave up); "
+                             "the run is invalid", err);
     return 0;
 }
 

@@ -51,6 +51,12 @@ struct SegParams {
     float* tr_likeh;         // [Rl][S]
     float* tr_rmse_tr; float* tr_rmse_te; float* tr_acc_tr; float* tr_acc_te;   // [Rl][S]
     int* tr_accept;          // [Rl][S]
+    // speculative schedule across G work-groups (CUs) per replica
+    int G;                   // work-groups per replica (1 = no cross-CU exchange)
+    unsigned epoch_base;     // granule tags of this launch are epoch_base + round
+    unsigned long long* xslots;   // [Rl][2][MAX_SLOTS][16] result granules
+    unsigned long long* xw;       // [Rl][2][MAX_SLOTS][2 PS] accepted-proposal granules
+    int* error_flag;         // != 0 after a launch: a bounded spin expired
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -664,19 +670,44 @@ __global__ void segment_kernel(const SegParams p, const int step_begin, const in
 // scratch, no work-group barrier inside a step), so the result does not depend on the number of waves.
 // ------------------------------------------------------------------------------------------------
 enum { SL_ACCEPT = 0, SL_LIKPROP, SL_PRIORPROP, SL_ETAPRO, SL_RM_TR, SL_RM_TE, SL_AC_TR, SL_AC_TE, SL_LG, SL_ADAPT, SL_COUNT = 16 };
+constexpr int MAX_SLOTS = 64;          // speculative steps per round: work-groups per replica x waves per work-group
+constexpr unsigned SPIN_LIMIT = 1u << 22;   // x (s_sleep 2 + one L2 round trip) = a few seconds, then the launch gives up
 
 __host__ __device__ inline size_t spec_wave_floats(int PS, int H, int FWS) { return 3 * (size_t)PS + (size_t)(H + 1) * FWS + 8; }
-__host__ __device__ inline size_t spec_lds_floats(int Nall, int IPY, int PS, int H, int FWS, int NW) {
-    return (size_t)(Nall + 2) * IPY + 3 * (size_t)PS + MAX_WAVES * 8 + (size_t)NW * SL_COUNT + (size_t)NW * spec_wave_floats(PS, H, FWS);
+__host__ __device__ inline size_t spec_lds_floats(int Nall, int IPY, int PS, int H, int FWS, int NW, int G) {
+    return (size_t)(Nall + 2) * IPY + 3 * (size_t)PS + MAX_WAVES * 8 + (size_t)NW * G * SL_COUNT + (size_t)NW * spec_wave_floats(PS, H, FWS);
 }
 
+// 8-byte {tag, value} granule written by ONE agent-scope relaxed atomic store (sc1, write-through) and polled with
+// agent-scope relaxed atomic loads (sc1, L1 bypass): the data is its own flag, no fence on either side
+// (cdna_hip_programming.md Guideline 16, form R2).  Every spin is bounded.
+typedef unsigned long long granule_t;
+__device__ __forceinline__ void granule_store(granule_t* g, unsigned epoch, float v) {
+    __hip_atomic_store(g, ((granule_t)epoch << 32) | (granule_t)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool granule_wait(const granule_t* g, unsigned epoch, float& v) {
+    for (unsigned spins = 0; spins < SPIN_LIMIT; ++spins) {
+        const granule_t x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x >> 32) == epoch) { v = __builtin_bit_cast(float, (unsigned)x); return true; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
+
+// p.G work-groups (one per CU) cooperate on one replica: work-group g, wave v owns speculative slot g*NW + v.
+// Every work-group keeps its own LDS copy of the chain state and applies the same commits, so the copies never
+// diverge; only the per-slot results (and the accepted proposal) cross CUs.
 template <int TASK, int I, int O>
 __global__ void segment_spec_kernel(const SegParams p, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int r = blockIdx.x;
+    const int G = p.G;
+    const int r = blockIdx.x / G, grp = blockIdx.x - r * G;
     const int gid = p.first_global + r;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int wave = tid >> 6, lane = tid & 63, NW = nthr >> 6;
+    const int K = NW * G;                                  // speculative slots per round
+    const int sidx = grp * NW + wave;                      // my slot
     const int Nall = p.Ntr + p.Nte;
     const int P = p.P, PS = p.PS, H = p.H;
     // shared part
@@ -686,8 +717,8 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
     float* w_gd = q; q += PS;
     float* rec_w = q; q += PS;
     float* red = q; q += MAX_WAVES * 8;
-    float* slots = q; q += NW * SL_COUNT;
-    // private part of every wave
+    float* slots = q; q += K * SL_COUNT;
+    // private part of every wave: proposal, its SGD epoch, noise, packed forward image, scalars
     const size_t wfl = spec_wave_floats(PS, H, p.FWS);
     float* priv0 = q;
     float* mine = priv0 + (size_t)wave * wfl;
@@ -696,6 +727,9 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
     float* my_noise = mine + 2 * PS;
     float* my_fw = mine + 3 * PS;
     float* my_scal = my_fw + (H + 1) * p.FWS;
+    // exchange areas of this replica (G > 1): [parity][slot][16] result granules, [parity][slot][2 PS] proposal granules
+    granule_t* xs = p.xslots + (size_t)r * 2 * MAX_SLOTS * SL_COUNT;
+    granule_t* xw = p.xw + (size_t)r * 2 * MAX_SLOTS * 2 * PS;
 
     {
         const float4* src = reinterpret_cast<const float4*>(p.data);
@@ -717,7 +751,7 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
     float lik, prior_cur, tau_eta_last, rec_rmse_tr, rec_rmse_te, rec_acc_tr, rec_acc_te;
     int nacc, gd_valid, lg_count;
     if (step_begin == 0) {
-        if (wave == 0) {                                       // wave 0 alone: independent of the wave count
+        if (wave == 0) {                                       // one wave alone: independent of wave and group count
             chain_startup<TASK, I, O, true>(p, xy, w_cur, my_fw, red, T, eta, lik, prior_cur);
             if (lane == 0) { red[0] = eta; red[1] = lik; red[2] = prior_cur; }
         }
@@ -737,7 +771,11 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
     const size_t trow = (size_t)r * p.S;
     const int end = step_begin + n_steps;
     int i = step_begin;
+    unsigned epoch = p.epoch_base;
+    int par = 0;
+    bool failed = false;
     while (i < end) {
+        epoch += 1;
         if (i == p.switch_step) {
             // R10 (REG:320-324): canonical from here on; re-evaluate the current w with the LAST PROPOSED tau (Q9)
             if (wave == 0) {
@@ -752,10 +790,10 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
             lik = red[0];
             __syncthreads();
         }
-        int k = min(NW, end - i);
+        int k = min(K, end - i);
         if (p.switch_step > i) k = min(k, p.switch_step - i);     // a round never straddles the temperature switch
-        const int j = i + wave;
-        const bool active = wave < k;
+        const int j = i + sidx;
+        const bool active = sidx < k;
         bool lg = false;
         float u = 0.f, n_eta = 0.f;
         if (active) {
@@ -766,15 +804,15 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
             n_eta = my_scal[2];
             lg = p.use_lg && (lx < p.l_prob);
         }
-        if (p.use_lg) {
-            // w_gd = langevin_gradient(w): one sweep serves every speculative step of this and later rounds until w changes
-            const int need = __syncthreads_or((active && lg && !gd_valid) ? 1 : 0);
-            if (need) {
-                if (wave == 0) sgd_sweep_dispatch<TASK, I, O>(w_cur, w_gd, xy, p.IPY, p.Ntr, H, p.lr);
-                gd_valid = 1;
-                __syncthreads();
-            }
+        if (p.use_lg && !gd_valid) {
+            // w_gd = langevin_gradient(w) is missing (chain start, or w arrived from another GPU): every work-group
+            // recomputes it for itself.  Decided from state all groups share, so they all take this branch together.
+            if (wave == 0) sgd_sweep_dispatch<TASK, I, O>(w_cur, w_gd, xy, p.IPY, p.Ntr, H, p.lr);
+            gd_valid = 1;
+            __syncthreads();
         }
+        float* sl = slots + sidx * SL_COUNT;
+        bool acc_mine = false;
         if (active) {
             const float adapttemp = (p.switch_step >= 0 && j >= p.switch_step) ? 1.0f : T;
             float diff_prop = 0.0f;
@@ -802,32 +840,52 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
             const float prior_prop = prior_value<TASK>(p, ssq, eta_pro);
             const float logalpha = (lik_prop - lik) + (prior_prop - prior_cur) + diff_prop;
             const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
-            if (p.use_lg && !lg && (u < mh)) {
+            acc_mine = u < mh;
+            if (p.use_lg && !lg && acc_mine) {
                 // an accepted random-walk step: run the SGD epoch from its proposal now, so langevin_gradient(new w)
                 // is already there when the step is committed (the Langevin waves of this round are sweeping anyway)
                 sgd_sweep_dispatch<TASK, I, O>(my_prop, my_pgd, xy, p.IPY, p.Ntr, H, p.lr);
                 gsync<true>();
             }
             if (lane == 0) {
-                float* sl = slots + wave * SL_COUNT;
-                sl[SL_ACCEPT] = (u < mh) ? 1.0f : 0.0f;
+                sl[SL_ACCEPT] = acc_mine ? 1.0f : 0.0f;
                 sl[SL_LIKPROP] = lik_prop; sl[SL_PRIORPROP] = prior_prop; sl[SL_ETAPRO] = eta_pro;
                 sl[SL_RM_TR] = rm_tr; sl[SL_RM_TE] = rm_te; sl[SL_AC_TR] = ac_tr; sl[SL_AC_TE] = ac_te;
                 sl[SL_LG] = lg ? 1.0f : 0.0f; sl[SL_ADAPT] = adapttemp;
             }
+            if (G > 1) {
+                // publish my slot (one 128-byte wave store) and, if accepted, the proposal and its SGD epoch
+                gsync<true>();
+                if (lane < SL_COUNT) granule_store(xs + ((size_t)par * MAX_SLOTS + sidx) * SL_COUNT + lane, epoch, sl[lane]);
+                if (acc_mine) {
+                    granule_t* xo = xw + ((size_t)par * MAX_SLOTS + sidx) * 2 * PS;
+                    for (int e = lane; e < 2 * PS; e += WAVE) granule_store(xo + e, epoch, mine[e]);   // my_prop ++ my_pgd
+                }
+            }
         }
         __syncthreads();
+        if (G > 1) {
+            // gather the slots of the other work-groups of this replica
+            bool ok = true;
+            for (int t = tid; t < k * SL_COUNT; t += nthr) {
+                const int s_ = t / SL_COUNT;
+                if (s_ / NW == grp) continue;
+                float v;
+                ok = granule_wait(xs + ((size_t)par * MAX_SLOTS) * SL_COUNT + t, epoch, v) && ok;
+                slots[t] = v;
+            }
+            if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
+        }
         // commit the prefix up to and including the first accepted step
         int m = k;
         for (int v = k - 1; v >= 0; --v) m = (slots[v * SL_COUNT + SL_ACCEPT] != 0.0f) ? v : m;
         const int ncommit = (m < k) ? m + 1 : k;
-        if (wave < ncommit) {
-            const bool acc_me = (wave == m);
+        if (sidx < ncommit) {
+            const bool acc_me = (sidx == m);
             const float* srcw = acc_me ? my_prop : rec_w;
             float* prow = p.tr_pos_w + (trow + j + 1) * (size_t)P;
             for (int e = lane; e < P; e += WAVE) prow[e] = srcw[e];
             if (lane == 0) {
-                const float* sl = slots + wave * SL_COUNT;
                 p.tr_likeh[trow + j + 1] = (TASK == TASK_REG) ? sl[SL_LIKPROP] : sl[SL_LIKPROP] * sl[SL_ADAPT];
                 p.tr_accept[trow + j + 1] = nacc;                                   // count BEFORE this step (REG:380)
                 p.tr_rmse_tr[trow + j + 1] = acc_me ? sl[SL_RM_TR] : rec_rmse_tr;
@@ -840,35 +898,55 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
         if (TASK == TASK_REG) tau_eta_last = slots[(ncommit - 1) * SL_COUNT + SL_ETAPRO];
         __syncthreads();                                    // every reader of rec_w is done
         if (m < k) {
-            const float* sl = slots + m * SL_COUNT;
-            const float* wacc = priv0 + (size_t)m * wfl;
+            const float* sm = slots + m * SL_COUNT;
             nacc += 1;
-            lik = sl[SL_LIKPROP]; prior_cur = sl[SL_PRIORPROP]; eta = sl[SL_ETAPRO];
-            rec_rmse_tr = sl[SL_RM_TR]; rec_rmse_te = sl[SL_RM_TE]; rec_acc_tr = sl[SL_AC_TR]; rec_acc_te = sl[SL_AC_TE];
-            // the accepted Langevin step already ran the SGD epoch from its proposal: that IS langevin_gradient(new w)
+            lik = sm[SL_LIKPROP]; prior_cur = sm[SL_PRIORPROP]; eta = sm[SL_ETAPRO];
+            rec_rmse_tr = sm[SL_RM_TR]; rec_rmse_te = sm[SL_RM_TE]; rec_acc_tr = sm[SL_AC_TR]; rec_acc_te = sm[SL_AC_TE];
             gd_valid = p.use_lg ? 1 : 0;
-            for (int e = tid; e < P; e += nthr) {
-                const float v = wacc[e];
-                w_cur[e] = v; rec_w[e] = v;
-                if (p.use_lg) w_gd[e] = wacc[PS + e];
+            const int owner = m / NW;
+            bool ok = true;
+            if (owner == grp) {
+                const float* wacc = priv0 + (size_t)(m - grp * NW) * wfl;
+                for (int e = tid; e < P; e += nthr) {
+                    const float v = wacc[e];
+                    w_cur[e] = v; rec_w[e] = v;
+                    if (p.use_lg) w_gd[e] = wacc[PS + e];
+                }
+            } else {
+                const granule_t* xo = xw + ((size_t)par * MAX_SLOTS + m) * 2 * PS;
+                for (int e = tid; e < P; e += nthr) {
+                    float v = 0.f, gv = 0.f;
+                    ok = granule_wait(xo + e, epoch, v) && ok;
+                    if (p.use_lg) ok = granule_wait(xo + PS + e, epoch, gv) && ok;
+                    w_cur[e] = v; rec_w[e] = v;
+                    if (p.use_lg) w_gd[e] = gv;
+                }
             }
+            if (G > 1 && __syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
         }
         __syncthreads();
         i += ncommit;
+        par ^= 1;
     }
 
-    for (int j = tid; j < PS; j += nthr) {
-        gw[j] = (j == P) ? eta : w_cur[j];
-        p.rec_w[(size_t)r * PS + j] = rec_w[j];
-        p.gd_w[(size_t)r * PS + j] = w_gd[j];
+    if (failed) {
+        if (tid == 0) atomicAdd(p.error_flag, 1);           // a bounded spin ran out: the host reports it
+        return;
     }
-    if (tid == 0) {
-        sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur; sf[SF_TAU_LAST] = tau_eta_last;
-        sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;
-        sf[SF_REC_ACC_TR] = rec_acc_tr; sf[SF_REC_ACC_TE] = rec_acc_te;
-        si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count;
-        p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;
-        p.L_final[gid] = lik;
+    if (grp == 0) {
+        for (int j = tid; j < PS; j += nthr) {
+            gw[j] = (j == P) ? eta : w_cur[j];
+            p.rec_w[(size_t)r * PS + j] = rec_w[j];
+            p.gd_w[(size_t)r * PS + j] = w_gd[j];
+        }
+        if (tid == 0) {
+            sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur; sf[SF_TAU_LAST] = tau_eta_last;
+            sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;
+            sf[SF_REC_ACC_TR] = rec_acc_tr; sf[SF_REC_ACC_TE] = rec_acc_te;
+            si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count;
+            p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;
+            p.L_final[gid] = lik;
+        }
     }
 }
 

@@ -34,7 +34,7 @@ class ParallelTemperingBase:
 
     def __init__(self, use_langevin_gradients, learn_rate, traindata, testdata, topology, num_chains, maxtemp,
                  NumSample, swap_interval, langevin_prob, path, *, seed=None, device=None, waves_per_replica=0,
-                 schedule=0, write_files=True, io_threads=None):
+                 schedule=0, groups_per_replica=0, write_files=True, io_threads=None):
         # FNN chain variables (REG:491-494)
         self.traindata = traindata
         self.testdata = testdata
@@ -62,6 +62,7 @@ class ParallelTemperingBase:
         self.device = int(os.environ.get("PTNN_DEVICE", "0")) if device is None else int(device)
         self.waves_per_replica = int(waves_per_replica)
         self.schedule = int(schedule)            # 0 auto, 1 cooperative, 2 speculative (include/ptnn.h)
+        self.groups_per_replica = int(groups_per_replica)
         self.write_files = bool(write_files)
         self.io_threads = io_threads or min(16, os.cpu_count() or 1)
         self.timings = {}
@@ -128,7 +129,7 @@ class ParallelTemperingBase:
             n_replicas_local=self.num_chains, n_replicas_global=self.num_chains, first_global_replica=0,
             n_samples=S, swap_interval=int(self.swap_interval), pt_switch_step=self._pt_switch_step(),
             use_langevin=1 if self.use_langevin_gradients is True else 0, waves_per_replica=self.waves_per_replica,
-            schedule=self.schedule,
+            schedule=self.schedule, groups_per_replica=self.groups_per_replica,
             l_prob=float(self.langevin_prob), learn_rate=float(self.learn_rate), step_w=0.025, step_eta=0.2,
             sigma_squared=25.0, nu_1=0.0, nu_2=0.0, seed=self.seed)
         self._sampler.set_data(train, test)

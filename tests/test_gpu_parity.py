@@ -301,8 +301,9 @@ def test_invariants_at_full_size():
 
 @pytest.mark.parametrize("case", ["sunspot_lg", "iris_lg", "ions_rw"])
 def test_speculative_schedule_is_wave_count_invariant(case):
-    """Wave v of a work-group pre-computes step i+v; only the prefix up to the first accept is committed.  The committed
-    chain must not depend on how many steps were speculated: 1, 2, 4, 8 and 16 waves give bit-identical traces."""
+    """Slot s = (work-group g, wave v) pre-computes step i+s; only the prefix up to the first accept is committed.  The
+    committed chain must not depend on how many steps were speculated nor on how the slots are spread over CUs: every
+    (waves, work-groups per replica) combination gives bit-identical traces, swap logs and final states."""
     d = ds()
     if case == "sunspot_lg":
         task, topo, name, lg, lr, R, S, si, mt = 0, (4, 5, 1), "sunspot", True, 0.1, 8, 400, 20, 2
@@ -315,10 +316,10 @@ def test_speculative_schedule_is_wave_count_invariant(case):
     w0 = np.stack([tape.w_init(r, P) for r in range(R)]).astype(np.float32)
     T = np.array(orc.temperature_ladder(R, mt), dtype=np.float32)
     ref = None
-    for waves in (1, 2, 4, 8, 16):
+    for waves, groups in ((1, 1), (2, 1), (4, 1), (8, 1), (16, 1), (4, 2), (4, 4), (2, 4), (1, 8), (8, 4)):
         try:
             s = parity.make_sampler(task, topo, d[name + "_train"], d[name + "_test"], R_local=R, R_global=R, first=0, S=S,
-                                    si=si, use_lg=lg, lr=lr, seed=77, waves=waves, schedule=2)
+                                    si=si, use_lg=lg, lr=lr, seed=77, waves=waves, schedule=2, groups=groups)
         except Exception as e:                      # more waves than the LDS budget admits: the library says so
             assert "LDS" in str(e), e
             continue
@@ -333,9 +334,9 @@ def test_speculative_schedule_is_wave_count_invariant(case):
             continue
         assert got[1] == ref[1] and (got[2] == ref[2]).all()
         for k in got[0]:
-            assert (got[0][k] == ref[0][k]).all(), (waves, k)
+            assert (got[0][k] == ref[0][k]).all(), (waves, groups, k)
         for k in got[3]:
-            assert (got[3][k] == ref[3][k]).all(), (waves, k)
+            assert (got[3][k] == ref[3][k]).all(), (waves, groups, k)
     assert ref is not None
 
 
