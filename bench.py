@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--schedule", type=int, default=0, help="0 auto, 1 cooperative, 2 speculative")
     ap.add_argument("--waves", type=int, default=0, help="wavefronts per work-group (0 = auto)")
+    ap.add_argument("--force-dist", action="store_true", help="use the sharded-ladder driver even at world size 1 (rehearsal)")
     ap.add_argument("--groups", type=int, default=0, help="work-groups (CUs) per replica, speculative schedule (0 = auto)")
     a = ap.parse_args()
     K, W, N = a.steps, a.warmup, a.gpus
@@ -137,7 +138,7 @@ def main():
     cpu = None
     if N == 1 and rank == 0 and not a.no_cpu_baseline:
         cpu = cpu_baseline(train, test)      # before the first HIP call: the pool forks
-    if N == 1:
+    if N == 1 and not a.force_dist:
         s = make_sampler(train, test, R_PER_GPU, R_global, 0, S, local_rank, use_lg, a.schedule, a.waves, a.groups)
         s.run(W * si + 1)            # REG hands off after step i = k*si (REG:427): start the timed region on an interval boundary
         s.sync()
@@ -187,6 +188,16 @@ def main():
         bytes_per_launch = R_PER_GPU * (mh_steps / max(launches, 1)) * B_STEP + R_PER_GPU * B_SWAP
         achieved = bytes_per_launch / avg_launch_s / 1e9 if launches else 0.0
         flops_per_launch = R_PER_GPU * (mh_steps / max(launches, 1)) * (F_STEP if use_lg else 42811)
+        # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE, separate runs of this same command, gfx950 FETCH_SIZE x2 correction applied)
+        traffic, kname = None, ("ptnn::segment_spec_kernel<0,4,1>" if (a.schedule != 1) else "ptnn::segment_kernel<0,4,1>")
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "current_pmc.json")))
+            for kn, e in pmc["kernels"].items():
+                if kname.split("<")[0].split("::")[1] + "<" in kn and use_lg and N == 1 and a.waves == 0 and a.groups == 0:
+                    traffic = e.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
         out = {
             "metric": "MCMC samples/sec (all replicas) + swap-accept rate; Sunspot 64-replica FNN",
             "value": value, "unit": "samples/s", "n_gpus": N, "steps": K, "warmup": W,
@@ -200,18 +211,21 @@ def main():
             "swap_accept_pct": 100.0 * (nsw1 - nsw0) / max(tot1 - tot0, 1),
             "mh_accept_pct": float(100.0 * np.mean(accepted) / max(steps_done, 1)),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "ptnn::segment_kernel<0,4,1>", "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": kname, "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "valu_tflops": flops_per_launch / avg_launch_s / 1e12 if launches else 0.0,
                          "valu_frac": (flops_per_launch / avg_launch_s / 1e12) / VALU_PEAK_TFLOPS if launches else 0.0,
-                         "note": "latency-bound by construction: 64 work-groups on 256 CUs, sequential SGD rows"},
+                         "traffic_source": "profiles/current_pmc.json (bytes per launch; includes the sc1 granule exchange between "
+                                           "the work-groups of a replica and their polling loads)",
+                         "note": "instruction-issue bound by construction (sequential SGD rows, AI 627 flop/B); the HBM "
+                                 "fraction is reported because BASELINE.json asks for it"},
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
         print(json.dumps(out), flush=True)
-    if N > 1:
+    if N > 1 or a.force_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
