@@ -46,7 +46,7 @@ typedef struct ptnn_config {
     int32_t swap_interval;        /* REG:496; hand-off trigger differs per task (REG:427 vs CLS:438) */
     int32_t pt_switch_step;       /* step i at which adapttemp drops to 1 (REG:320), or -1 if 0.6*S is not integral */
     int32_t use_langevin;         /* use_langevin_gradients (REG:329) */
-    int32_t waves_per_replica;    /* 0 = auto; 1,2,4,8,16: wavefronts of the work-group that owns one replica */
+    int32_t waves_per_replica;    /* 0 = auto; 1,2,4,8: wavefronts per work-group */
     int32_t schedule;             /* 0 = auto, 1 = cooperative (all waves share one MH step), 2 = speculative
                                    * (wave v pre-computes step i+v; identical chain) */
     int32_t groups_per_replica;   /* speculative schedule: work-groups (CUs) cooperating on one replica; 0 = auto
@@ -134,6 +134,11 @@ int ptnn_tape(ptnn_handle *h, int replica, int step, float *noise, float *scal);
 /* timing of the dominant kernel, measured with HIP events on the library's stream around every segment launch
  * since the last reset: launches, total milliseconds */
 int ptnn_kernel_time(ptnn_handle *h, int reset, int64_t *launches, double *total_ms);
+
+/* cycle sums per phase of the speculative kernel, replica 0 / wave 0; all zero unless the library was built with
+ * -DPTNN_STAMPS (diagnostic build, never the product).  160 entries: [0..8] phase sums, [9] rounds, [16+2r], [17+2r] =
+ * cycles and rounds of replica r < 64; reading resets. */
+int ptnn_debug_stamps(ptnn_handle *h, uint64_t *out16);
 
 /* ---- host-side helper (no GPU): the text dump the result-file layout requires ---- */
 /* np.savetxt(path, data[rows, cols], fmt=fmt) with ' ' between columns and '\n' after rows (REG:454-481, 864-868).

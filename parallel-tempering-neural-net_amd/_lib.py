@@ -63,6 +63,7 @@ SYMBOLS = {
     "ptnn_langevin_gradient": (C.c_int, [C.c_void_p, _fp, C.c_int, _fp]),
     "ptnn_tape": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp]),
     "ptnn_kernel_time": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "ptnn_debug_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "ptnn_savetxt": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_char_p]),
 }
 
@@ -233,6 +234,11 @@ class Sampler:
         noise, scal = np.empty(self.P, np.float32), np.empty(3, np.float32)
         self._check(self.lib.ptnn_tape(self.h, int(replica), int(step), _ptr(noise), _ptr(scal)))
         return noise, scal
+
+    def debug_stamps(self):
+        buf = (C.c_uint64 * 160)()
+        self._check(self.lib.ptnn_debug_stamps(self.h, buf))
+        return list(buf)
 
     def kernel_time(self, reset=False):
         n, ms = C.c_int64(), C.c_double()

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -84,6 +85,7 @@ struct ptnn_handle {
     int num_cus = 0;
     unsigned long long *d_xslots = nullptr, *d_xw = nullptr;
     int* d_error = nullptr;
+    unsigned long long* d_stamps = nullptr;
     bool have_data = false, have_state = false, finalized = false;
     int cur = 0;            // next MH step index
     int rounds_done = 0;    // swap rounds counted (including the phantom one)
@@ -105,6 +107,8 @@ struct ptnn_handle {
     // kernel timing (HIP events on our stream)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing;
     size_t timing_used = 0;
+    int timing_stride = 1;          // PTNN_TIMING_STRIDE: 0 = never, n = every n-th segment launch
+    long long launch_count = 0;
     int64_t timed_launches = 0;
     double timed_ms = 0.0;
 
@@ -127,7 +131,7 @@ struct ptnn_handle {
         p.L_handoff = d_L_handoff; p.L_final = d_L_final;
         p.tr_pos_w = d_pos_w; p.tr_likeh = d_likeh; p.tr_rmse_tr = d_rmse_tr; p.tr_rmse_te = d_rmse_te;
         p.tr_acc_tr = d_acc_tr; p.tr_acc_te = d_acc_te; p.tr_accept = d_accept;
-        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.error_flag = d_error;
+        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.error_flag = d_error; p.stamps = d_stamps;
         return p;
     }
 };
@@ -154,6 +158,17 @@ void collect_timing(ptnn_handle* h) {
 int launch_segment(ptnn_handle* h, int begin, int n) {
     if (n <= 0) return 0;
     HIP_TRY(hipSetDevice(h->cfg.device_id));
+    // event pairs around a launch cost a pipeline bubble each; time every timing_stride-th launch only
+    const bool timed = h->timing_stride > 0 && (h->launch_count++ % h->timing_stride) == 0;
+    if (!timed) {
+        const SegParams p = h->seg_params();
+        const int grid = h->cfg.n_replicas_local * (h->speculative ? h->groups : 1);
+        hipLaunchKernelGGL(h->speculative ? h->shape->spec : h->shape->seg, dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream,
+                           p, begin, n);
+        h->epoch_base += (unsigned)n + 1u;
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (h->timing_used == h->timing.size()) {
         if (h->timing.size() >= 4096) {               // keep the pool bounded: drain it (synchronises)
             HIP_TRY(hipStreamSynchronize(h->stream));
@@ -246,6 +261,7 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
     h->cfg = *cfg;
     h->shape = sh;
     h->num_cus = prop.multiProcessorCount;
+    if (const char* ts = std::getenv("PTNN_TIMING_STRIDE")) h->timing_stride = std::atoi(ts);
     const int I = cfg->n_in, H = cfg->n_hidden, O = cfg->n_out;
     h->P = I * H + H * O + H + O;
     h->PS = round_up4(h->P + 1);
@@ -277,6 +293,8 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
     HIP_TRY(hipMalloc(&h->d_src_log, (size_t)h->max_rounds * R * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_counters, 2 * sizeof(long long)));
     HIP_TRY(hipMalloc(&h->d_error, sizeof(int)));
+    HIP_TRY(hipMalloc(&h->d_stamps, 160 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(h->d_stamps, 0, 160 * sizeof(unsigned long long), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_error, 0, sizeof(int), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_counters, 0, 2 * sizeof(long long), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_L_handoff, 0, R * sizeof(float), h->stream));
@@ -292,7 +310,7 @@ int ptnn_destroy(ptnn_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_data, h->d_state[0], h->d_state[1], h->d_rec_w, h->d_gd_w[0], h->d_gd_w[1], h->d_gd_valid[0], h->d_gd_valid[1], h->d_st_f, h->d_st_i, h->d_temps,
                     h->d_L_handoff, h->d_L_final, h->d_pos_w, h->d_likeh, h->d_rmse_tr, h->d_rmse_te, h->d_acc_tr,
-                    h->d_acc_te, h->d_accept, h->d_src, h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw};
+                    h->d_acc_te, h->d_accept, h->d_src, h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_stamps};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& ev : h->timing) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -334,8 +352,8 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         sched = (h->cfg.task == PTNN_TASK_REG || h->cfg.use_langevin) ? PTNN_SCHED_SPECULATIVE : PTNN_SCHED_COOPERATIVE;
     if (sched != PTNN_SCHED_COOPERATIVE && sched != PTNN_SCHED_SPECULATIVE) return fail(-1, "unknown schedule %d", sched);
     int nw = h->cfg.waves_per_replica;
-    if (nw != 0 && nw != 1 && nw != 2 && nw != 4 && nw != 8 && nw != 16)
-        return fail(-1, "waves_per_replica must be 0 (auto), 1, 2, 4, 8 or 16");
+    if (nw != 0 && nw != 1 && nw != 2 && nw != 4 && nw != 8)
+        return fail(-1, "waves_per_replica must be 0 (auto), 1, 2, 4 or 8");
     int coop_nw = (Nall + 63) / 64, pow2 = 1;
     while (pow2 < coop_nw) pow2 <<= 1;
     coop_nw = std::min(pow2, 8);
@@ -661,6 +679,17 @@ int ptnn_kernel_time(ptnn_handle* h, int reset, int64_t* launches, double* total
     if (launches) *launches = h->timed_launches;
     if (total_ms) *total_ms = h->timed_ms;
     if (reset) { h->timed_launches = 0; h->timed_ms = 0.0; }
+    return 0;
+}
+
+int ptnn_debug_stamps(ptnn_handle* h, uint64_t* out16) {   // 160 entries: 16 phase sums + 64 x (cycles, rounds)
+    if (!h || !out16) return fail(-1, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(out16, h->d_stamps, 160 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(h->d_stamps, 0, 160 * sizeof(unsigned long long)));
+    const unsigned long long big = ~0ull;
+    HIP_TRY(hipMemcpy(h->d_stamps + 12, &big, sizeof big, hipMemcpyHostToDevice));
     return 0;
 }
 

@@ -16,7 +16,8 @@ namespace ptnn {
 constexpr int TASK_REG = 0;
 constexpr int TASK_CLS = 1;
 constexpr int WAVE = 64;
-constexpr int MAX_WAVES = 16;
+constexpr int MAX_WAVES = 8;            // waves per work-group: 2 per SIMD, 256 VGPRs each
+constexpr int MAX_THREADS = MAX_WAVES * WAVE;
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
@@ -57,6 +58,7 @@ struct SegParams {
     unsigned long long* xslots;   // [Rl][2][MAX_SLOTS][16] result granules
     unsigned long long* xw;       // [Rl][2][MAX_SLOTS][2 PS] accepted-proposal granules
     int* error_flag;         // != 0 after a launch: a bounded spin expired
+    unsigned long long* stamps;   // diagnostic build only (PTNN_STAMPS): cycle sums per phase, else unused
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -131,7 +133,11 @@ __device__ __forceinline__ float wave_allsum(float v) { return group_allsum<6>(v
 template <bool WL> __device__ __forceinline__ int gtid() { return WL ? (int)(threadIdx.x & 63) : (int)threadIdx.x; }
 template <bool WL> __device__ __forceinline__ int gsize() { return WL ? WAVE : (int)blockDim.x; }
 template <bool WL> __device__ __forceinline__ void gsync() {
-    if (WL) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    // WL: the LDS executes one wave's instructions in issue order, so a later ds_read of any lane sees an earlier
+    // ds_write of any lane; only the compiler has to be stopped from reordering (no s_waitcnt vmcnt: a work-group
+    // scope fence would also wait for the trace stores still in flight)
+    if (WL) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
     else __syncthreads();
 }
 
@@ -283,51 +289,66 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
                                               int FWS, int H, int Ntr, int Nall, float* __restrict__ red) {
     float a_tr = 0.f, b_tr = 0.f, c_tr = 0.f, a_te = 0.f, b_te = 0.f, c_te = 0.f;
     constexpr int K = I + 1 + O;
+    // RB data rows of one lane are kept in registers while the hidden units stream by: the packed weights of unit h are
+    // read from LDS once per RB rows, and the RB independent chains hide the exp/rcp latency of each other
+    constexpr int RB = ((I + 1) * 8 <= 64) ? 8 : ((I + 1) * 4 <= 64) ? 4 : ((I + 1) * 2 <= 80) ? 2 : 1;
     float b2[O];
 #pragma unroll
     for (int o = 0; o < O; ++o) b2[o] = fw[H * FWS + o];
-    for (int n = gtid<WL>(); n < Nall; n += gsize<WL>()) {
-        float x[I + 1];
-        lds_load<I + 1>(xy + n * IPY, x);
-        float acc[O];
+    const int stride = gsize<WL>();
+    for (int n0 = gtid<WL>(); n0 < Nall; n0 += stride * RB) {
+        float x[RB][I + 1];
+        float acc[RB][O];
 #pragma unroll
-        for (int o = 0; o < O; ++o) acc[o] = -b2[o];
+        for (int b = 0; b < RB; ++b) {
+            const int n = n0 + b * stride;
+            lds_load<I + 1>(xy + (n < Nall ? n : n0) * IPY, x[b]);
+#pragma unroll
+            for (int o = 0; o < O; ++o) acc[b][o] = -b2[o];
+        }
         for (int h = 0; h < H; ++h) {
             float f[K];
             lds_load<K>(fw + h * FWS, f);                  // wave-uniform address: broadcast reads
-            float z = -f[I];
 #pragma unroll
-            for (int i = 0; i < I; ++i) z = fmaf(x[i], f[i], z);
-            const float hid = sigmoidf_fast(z);
+            for (int b = 0; b < RB; ++b) {
+                float z = -f[I];
 #pragma unroll
-            for (int o = 0; o < O; ++o) acc[o] = fmaf(hid, f[I + 1 + o], acc[o]);
-        }
-        const float y = x[I];
-        float a, b = 0.f, c = 0.f;
-        if (TASK == TASK_REG) {
-            const float d = y - sigmoidf_fast(acc[0]);
-            a = d * d;
-        } else {
-            float out[O];
-            float best = acc[0], se = 0.0f, oy = 0.0f;
-            int arg = 0;
-            const int yi = (int)y;
+                for (int i = 0; i < I; ++i) z = fmaf(x[b][i], f[i], z);
+                const float hid = sigmoidf_fast(z);
 #pragma unroll
-            for (int o = 0; o < O; ++o) {
-                out[o] = sigmoidf_fast(acc[o]);
-                // np.argmax(out): first maximum (CLS:55).  Taken on the pre-activation: sigmoid is monotone, and fp32
-                // outputs that saturate to 1.0f would tie where the reference's float64 outputs still differ
-                if (acc[o] > best) { best = acc[o]; arg = o; }
-                se += expf_fast(out[o]);                               // softmax of the sigmoid outputs (Q3)
-                oy = (o == yi) ? out[o] : oy;
+                for (int o = 0; o < O; ++o) acc[b][o] = fmaf(hid, f[I + 1 + o], acc[b][o]);
             }
-            a = oy - logf_fast(se);
-            const float dd = (float)arg - y;
-            b = dd * dd;
-            c = ((float)arg == y) ? 1.0f : 0.0f;
         }
-        if (n < Ntr) { a_tr += a; b_tr += b; c_tr += c; }
-        else { a_te += a; b_te += b; c_te += c; }
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int n = n0 + b * stride;
+            if (n >= Nall) continue;
+            const float y = x[b][I];
+            float a, bb = 0.f, c = 0.f;
+            if (TASK == TASK_REG) {
+                const float d = y - sigmoidf_fast(acc[b][0]);
+                a = d * d;
+            } else {
+                float best = acc[b][0], se = 0.0f, oy = 0.0f;
+                int arg = 0;
+                const int yi = (int)y;
+#pragma unroll
+                for (int o = 0; o < O; ++o) {
+                    const float out = sigmoidf_fast(acc[b][o]);
+                    // np.argmax(out): first maximum (CLS:55).  Taken on the pre-activation: sigmoid is monotone, and fp32
+                    // outputs that saturate to 1.0f would tie where the reference's float64 outputs still differ
+                    if (acc[b][o] > best) { best = acc[b][o]; arg = o; }
+                    se += expf_fast(out);                              // softmax of the sigmoid outputs (Q3)
+                    oy = (o == yi) ? out : oy;
+                }
+                a = oy - logf_fast(se);
+                const float dd = (float)arg - y;
+                bb = dd * dd;
+                c = ((float)arg == y) ? 1.0f : 0.0f;
+            }
+            if (n < Ntr) { a_tr += a; b_tr += bb; c_tr += c; }
+            else { a_te += a; b_te += bb; c_te += c; }
+        }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     a_tr = wave_allsum(a_tr);
@@ -514,7 +535,7 @@ __device__ __forceinline__ void chain_startup(const SegParams& p, const float* x
 // step_begin == 0 also performs the chain start-up (REG:266-285).
 // ------------------------------------------------------------------------------------------------
 template <int TASK, int I, int O>
-__global__ void segment_kernel(const SegParams p, const int step_begin, const int n_steps) {
+__global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int r = blockIdx.x;
     const int gid = p.first_global + r;
@@ -695,12 +716,31 @@ __device__ __forceinline__ bool granule_wait(const granule_t* g, unsigned epoch,
     return false;
 }
 
+// Diagnostic build only (-DPTNN_STAMPS): wave 0 of the first work-group of replica 0 adds up shader-clock cycles per phase
+// of a round and writes the sums to p.stamps at the end.  In the product build no stamp executes.
+#ifdef PTNN_STAMPS
+#define STAMP(slot)                                                                          \
+    do {                                                                                     \
+        if (stamp_on) {                                                                      \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                      \
+            __builtin_amdgcn_s_waitcnt(0xC07F);                                              \
+            stamp_acc[slot] += t_ - stamp_last; stamp_last = t_;                             \
+        }                                                                                    \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 // p.G work-groups (one per CU) cooperate on one replica: work-group g, wave v owns speculative slot g*NW + v.
 // Every work-group keeps its own LDS copy of the chain state and applies the same commits, so the copies never
 // diverge; only the per-slot results (and the accepted proposal) cross CUs.
 template <int TASK, int I, int O>
-__global__ void segment_spec_kernel(const SegParams p, const int step_begin, const int n_steps) {
+__global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegParams p, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef PTNN_STAMPS
+    const unsigned long long stamp_entry = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     const int G = p.G;
     const int r = blockIdx.x / G, grp = blockIdx.x - r * G;
     const int gid = p.first_global + r;
@@ -768,14 +808,28 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
         nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT];
     }
 
+#ifdef PTNN_STAMPS
+    const bool stamp_on = (blockIdx.x == 0 && wave == 0);
+    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    unsigned long long stamp_rounds = 0;
+    const unsigned long long stamp_t0 = stamp_last;
+    const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     const size_t trow = (size_t)r * p.S;
     const int end = step_begin + n_steps;
     int i = step_begin;
     unsigned epoch = p.epoch_base;
     int par = 0;
     bool failed = false;
+    STAMP(0);                                             // launch prologue: staging, start-up
     while (i < end) {
         epoch += 1;
+#ifdef PTNN_STAMPS
+        stamp_rounds += 1;
+#endif
         if (i == p.switch_step) {
             // R10 (REG:320-324): canonical from here on; re-evaluate the current w with the LAST PROPOSED tau (Q9)
             if (wave == 0) {
@@ -804,6 +858,7 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
             n_eta = my_scal[2];
             lg = p.use_lg && (lx < p.l_prob);
         }
+        STAMP(1);                                         // random tape
         if (p.use_lg && !gd_valid) {
             // w_gd = langevin_gradient(w) is missing (chain start, or w arrived from another GPU): every work-group
             // recomputes it for itself.  Decided from state all groups share, so they all take this branch together.
@@ -813,6 +868,7 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
         }
         float* sl = slots + sidx * SL_COUNT;
         bool acc_mine = false;
+        STAMP(2);                                         // langevin_gradient(w) recompute (rare)
         if (active) {
             const float adapttemp = (p.switch_step >= 0 && j >= p.switch_step) ? 1.0f : T;
             float diff_prop = 0.0f;
@@ -828,6 +884,7 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
                 for (int e = lane; e < P; e += WAVE) my_prop[e] = fmaf(p.step_w, my_noise[e], w_cur[e]);
                 gsync<true>();
             }
+            STAMP(3);                                     // proposal (+ SGD epoch for a Langevin slot)
             float eta_pro = eta;
             if (TASK == TASK_REG) eta_pro = fmaf(p.step_eta, n_eta, eta);
             build_fw<I, O, true>(my_prop, my_fw, H, p.FWS);
@@ -841,6 +898,7 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
             const float logalpha = (lik_prop - lik) + (prior_prop - prior_cur) + diff_prop;
             const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
             acc_mine = u < mh;
+            STAMP(4);                                     // forward pass, likelihood, prior, MH ratio
             if (p.use_lg && !lg && acc_mine) {
                 // an accepted random-walk step: run the SGD epoch from its proposal now, so langevin_gradient(new w)
                 // is already there when the step is committed (the Langevin waves of this round are sweeping anyway)
@@ -863,7 +921,9 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
                 }
             }
         }
+        STAMP(5);                                         // publish
         __syncthreads();
+        STAMP(6);                                         // waiting for the slowest wave of this work-group
         if (G > 1) {
             // gather the slots of the other work-groups of this replica
             bool ok = true;
@@ -876,9 +936,12 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
             }
             if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
         }
+        STAMP(7);                                         // gather from the other work-groups (incl. waiting for them)
         // commit the prefix up to and including the first accepted step
-        int m = k;
-        for (int v = k - 1; v >= 0; --v) m = (slots[v * SL_COUNT + SL_ACCEPT] != 0.0f) ? v : m;
+        const bool my_flag_acc = (lane < k) && (slots[lane * SL_COUNT + SL_ACCEPT] != 0.0f);
+        const bool my_flag_lg = (lane < k) && (slots[lane * SL_COUNT + SL_LG] != 0.0f);
+        const unsigned long long bal_acc = __ballot(my_flag_acc), bal_lg = __ballot(my_flag_lg);
+        const int m = bal_acc ? (__ffsll((long long)bal_acc) - 1) : k;
         const int ncommit = (m < k) ? m + 1 : k;
         if (sidx < ncommit) {
             const bool acc_me = (sidx == m);
@@ -894,7 +957,7 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
                 p.tr_acc_te[trow + j + 1] = acc_me ? sl[SL_AC_TE] : rec_acc_te;
             }
         }
-        for (int v = 0; v < ncommit; ++v) lg_count += (slots[v * SL_COUNT + SL_LG] != 0.0f) ? 1 : 0;
+        lg_count += __popcll(bal_lg & ((ncommit >= 64) ? ~0ull : ((1ull << ncommit) - 1ull)));
         if (TASK == TASK_REG) tau_eta_last = slots[(ncommit - 1) * SL_COUNT + SL_ETAPRO];
         __syncthreads();                                    // every reader of rec_w is done
         if (m < k) {
@@ -927,7 +990,27 @@ __global__ void segment_spec_kernel(const SegParams p, const int step_begin, con
         __syncthreads();
         i += ncommit;
         par ^= 1;
+        STAMP(8);                                         // commit: trace rows, state update
     }
+#ifdef PTNN_STAMPS
+    if (stamp_on && lane == 0 && p.stamps) {
+        for (int q_ = 0; q_ < 9; ++q_) atomicAdd(p.stamps + q_, stamp_acc[q_]);
+        atomicAdd(p.stamps + 9, stamp_rounds);
+        atomicAdd(p.stamps + 10, __builtin_amdgcn_s_memtime() - stamp_t0);          // shader clock ticks
+        atomicAdd(p.stamps + 11, __builtin_amdgcn_s_memrealtime() - stamp_rt0);     // 100 MHz ticks
+    }
+    if (tid == 0 && p.stamps) {                               // 100 MHz timeline of this work-group: entry, loop start, loop end
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        atomicMin(p.stamps + 12, stamp_entry);
+        atomicMax(p.stamps + 13, stamp_rt0 - stamp_entry);      // longest prologue
+        atomicMax(p.stamps + 14, now - stamp_rt0);              // longest round loop
+        atomicMax(p.stamps + 15, now);                          // last loop end
+    }
+    if (grp == 0 && tid == 0 && p.stamps && r < 64) {        // per-replica totals: cycles in the round loop, rounds
+        atomicAdd(p.stamps + 16 + 2 * r, __builtin_amdgcn_s_memtime() - stamp_t0);
+        atomicAdd(p.stamps + 17 + 2 * r, stamp_rounds);
+    }
+#endif
 
     if (failed) {
         if (tid == 0) atomicAdd(p.error_flag, 1);           // a bounded spin ran out: the host reports it
@@ -1037,7 +1120,7 @@ __global__ void swap_kernel(const SwapParams sp, const int round, const int mode
 // stand-alone model functions (same device code): mode 0 = evaluate, 1 = langevin_gradient, 2 = tape
 // ------------------------------------------------------------------------------------------------
 template <int TASK, int I, int O>
-__global__ void model_kernel(const SegParams p, const int mode, const float* __restrict__ w_in,
+__global__ void __launch_bounds__(MAX_THREADS) model_kernel(const SegParams p, const int mode, const float* __restrict__ w_in,
                              const float* __restrict__ tau_sq, float* __restrict__ out, int a0, int a1) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
