@@ -63,7 +63,8 @@ typedef struct ptnn_config {
 int ptnn_abi_version(void);
 /* thread-local, valid until the next failing call on this thread */
 const char *ptnn_last_error(void);
-/* 1 if a kernel is compiled for (task, n_in, n_out); n_hidden may be anything in [1, 64] */
+/* 1 if a kernel is compiled for (task, n_in, n_out); n_hidden may be anything in [1, 512] (<= 64: one wave per SGD
+ * sweep, speculative or cooperative schedule; 65..512: one thread per hidden unit, cooperative schedule) */
 int ptnn_supports(int task, int n_in, int n_hidden, int n_out);
 
 /* replaces ParallelTempering.__init__ + the construction of the ptReplica objects (REG:489, 650) */

@@ -55,9 +55,13 @@ struct Shape {
     seg_fn seg;
     seg_fn spec;
     model_fn model;
+    seg_fn seg_wide;        // 64 < H <= MAX_HIDDEN
+    model_fn model_wide;
 };
 
-#define X_ENTRY(T, I, O) {T, I, O, &segment_kernel<T, I, O>, &segment_spec_kernel<T, I, O>, &model_kernel<T, I, O>},
+#define X_ENTRY(T, I, O) {T, I, O, &segment_kernel<T, I, O>, &segment_spec_kernel<T, I, O>, &model_kernel<T, I, O>, \
+                          &segment_wide_kernel<T, I, O>, &model_wide_kernel<T, I, O>},
+constexpr int MAX_HIDDEN = MAX_WAVES * WAVE;    // one thread per hidden unit
 const Shape g_shapes[] = {PTNN_SHAPES(X_ENTRY)};
 #undef X_ENTRY
 
@@ -80,6 +84,8 @@ struct ptnn_handle {
     size_t seg_lds = 0, model_lds = 0;
     int model_threads = 64;
     bool speculative = false;
+    bool wide = false;              // 64 < H: vectors in HBM, one thread per hidden unit
+    float* d_wide_scratch = nullptr;
     int groups = 1;                 // work-groups (CUs) per replica in the speculative schedule
     unsigned epoch_base = 0;
     int num_cus = 0;
@@ -131,7 +137,7 @@ struct ptnn_handle {
         p.L_handoff = d_L_handoff; p.L_final = d_L_final;
         p.tr_pos_w = d_pos_w; p.tr_likeh = d_likeh; p.tr_rmse_tr = d_rmse_tr; p.tr_rmse_te = d_rmse_te;
         p.tr_acc_tr = d_acc_tr; p.tr_acc_te = d_acc_te; p.tr_accept = d_accept;
-        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.error_flag = d_error; p.stamps = d_stamps;
+        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch;
         return p;
     }
 };
@@ -163,8 +169,8 @@ int launch_segment(ptnn_handle* h, int begin, int n) {
     if (!timed) {
         const SegParams p = h->seg_params();
         const int grid = h->cfg.n_replicas_local * (h->speculative ? h->groups : 1);
-        hipLaunchKernelGGL(h->speculative ? h->shape->spec : h->shape->seg, dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream,
-                           p, begin, n);
+        hipLaunchKernelGGL(h->wide ? h->shape->seg_wide : (h->speculative ? h->shape->spec : h->shape->seg), dim3(grid),
+                           dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
         h->epoch_base += (unsigned)n + 1u;
         HIP_TRY(hipGetLastError());
         return 0;
@@ -184,8 +190,8 @@ int launch_segment(ptnn_handle* h, int begin, int n) {
     const SegParams p = h->seg_params();
     HIP_TRY(hipEventRecord(ev.first, h->stream));
     const int grid = h->cfg.n_replicas_local * (h->speculative ? h->groups : 1);
-    hipLaunchKernelGGL(h->speculative ? h->shape->spec : h->shape->seg, dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream, p,
-                       begin, n);
+    hipLaunchKernelGGL(h->wide ? h->shape->seg_wide : (h->speculative ? h->shape->spec : h->shape->seg), dim3(grid),
+                       dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
     h->epoch_base += (unsigned)n + 1u;                    // granule tags never repeat across launches
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, h->stream));
@@ -226,7 +232,7 @@ int ptnn_abi_version(void) { return PTNN_ABI_VERSION; }
 const char* ptnn_last_error(void) { return g_err.c_str(); }
 
 int ptnn_supports(int task, int n_in, int n_hidden, int n_out) {
-    return (find_shape(task, n_in, n_out) != nullptr && n_hidden >= 1 && n_hidden <= 64) ? 1 : 0;
+    return (find_shape(task, n_in, n_out) != nullptr && n_hidden >= 1 && n_hidden <= MAX_HIDDEN) ? 1 : 0;
 }
 
 int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
@@ -240,8 +246,8 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
     if (!sh)
         return fail(-3, "no gfx950 kernel compiled for task=%d n_in=%d n_out=%d: add it to PTNN_SHAPES and rebuild",
                     cfg->task, cfg->n_in, cfg->n_out);
-    if (cfg->n_hidden > 64)
-        return fail(-3, "n_hidden=%d > 64: the one-wave-per-replica SGD sweep holds one hidden unit per lane", cfg->n_hidden);
+    if (cfg->n_hidden > MAX_HIDDEN)
+        return fail(-3, "n_hidden=%d > %d: the SGD sweep holds one hidden unit per thread of one work-group", cfg->n_hidden, MAX_HIDDEN);
     if (cfg->n_replicas_local < 1 || cfg->n_replicas_global < 2 || cfg->first_global_replica < 0 ||
         cfg->first_global_replica + cfg->n_replicas_local > cfg->n_replicas_global)
         return fail(-1, "bad replica partition: local=%d global=%d first=%d", cfg->n_replicas_local,
@@ -310,7 +316,7 @@ int ptnn_destroy(ptnn_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_data, h->d_state[0], h->d_state[1], h->d_rec_w, h->d_gd_w[0], h->d_gd_w[1], h->d_gd_valid[0], h->d_gd_valid[1], h->d_st_f, h->d_st_i, h->d_temps,
                     h->d_L_handoff, h->d_L_final, h->d_pos_w, h->d_likeh, h->d_rmse_tr, h->d_rmse_te, h->d_acc_tr,
-                    h->d_acc_te, h->d_accept, h->d_src, h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_stamps};
+                    h->d_acc_te, h->d_accept, h->d_src, h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_stamps, h->d_wide_scratch};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& ev : h->timing) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -337,8 +343,29 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
                 return fail(-1, "class label %g in row %d is not an integer in [0, %d)", (double)y, n, h->cfg.n_out);
         }
     }
-    // LDS budget: the data set, the state vectors and the packed forward weights live in LDS for the whole launch
     const int H = h->cfg.n_hidden;
+    if (H > WAVE) {
+        // wide net: one thread per hidden unit, vectors in HBM, only the packed forward image + scratch in LDS
+        const size_t lds = wide_lds_floats(H, h->FWS, h->cfg.n_out) * sizeof(float);
+        if (lds > 160 * 1024) return fail(-3, "wide net needs %zu B of LDS (> 160 KiB)", lds);
+        if (h->cfg.schedule == PTNN_SCHED_SPECULATIVE) return fail(-3, "the speculative schedule is built for n_hidden <= 64");
+        h->wide = true; h->speculative = false; h->groups = 1;
+        h->nthreads = ((H + WAVE - 1) / WAVE) * WAVE;
+        h->model_threads = h->nthreads;
+        h->seg_lds = h->model_lds = lds;
+        h->Ntr = ntr; h->Nte = nte;
+        if (h->d_data) { HIP_TRY(hipFree(h->d_data)); h->d_data = nullptr; }
+        HIP_TRY(hipMalloc(&h->d_data, packed.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(h->d_data, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (!h->d_wide_scratch) HIP_TRY(hipMalloc(&h->d_wide_scratch, (size_t)h->cfg.n_replicas_local * 3 * h->PS * sizeof(float)));
+        if (lds > 64 * 1024) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->shape->seg_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->shape->model_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        h->have_data = true;
+        return 0;
+    }
+    // LDS budget: the data set, the state vectors and the packed forward weights live in LDS for the whole launch
     const size_t coop_lds = lds_floats(Nall, IPY, h->PS, H, h->FWS) * sizeof(float);
     const size_t LDS_MAX = 160 * 1024;
     if (coop_lds > LDS_MAX)
@@ -641,7 +668,8 @@ static int run_model(ptnn_handle* h, int mode, const float* w_in, const float* t
     }
     HIP_TRY(hipMalloc(&d_out, out_floats * sizeof(float)));
     const SegParams p = h->seg_params();
-    hipLaunchKernelGGL(h->shape->model, dim3(n), dim3(h->model_threads), h->model_lds, h->stream, p, mode, d_w, d_tau, d_out, a0, a1);
+    hipLaunchKernelGGL(h->wide ? h->shape->model_wide : h->shape->model, dim3(n), dim3(h->model_threads), h->model_lds, h->stream, p,
+                       mode, d_w, d_tau, d_out, a0, a1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipMemcpy(out, d_out, out_floats * sizeof(float), hipMemcpyDeviceToHost));
@@ -664,10 +692,12 @@ int ptnn_langevin_gradient(ptnn_handle* h, const float* w_in, int n, float* w_ou
 
 int ptnn_tape(ptnn_handle* h, int replica, int step, float* noise, float* scal) {
     if (!h || !noise || !scal) return fail(-1, "null argument");
-    std::vector<float> buf((size_t)h->P + 3);
+    // narrow nets return {noise[P], scal[3]}; the wide kernel writes whole float4s: {noise[PS], scal[3]}
+    const size_t off = h->wide ? (size_t)h->PS : (size_t)h->P;
+    std::vector<float> buf(off + 3);
     if (int rc = run_model(h, 2, nullptr, nullptr, 1, buf.data(), buf.size(), replica, step)) return rc;
     std::memcpy(noise, buf.data(), h->P * sizeof(float));
-    std::memcpy(scal, buf.data() + h->P, 3 * sizeof(float));
+    std::memcpy(scal, buf.data() + off, 3 * sizeof(float));
     return 0;
 }
 

@@ -59,6 +59,7 @@ struct SegParams {
     unsigned long long* xw;       // [Rl][2][MAX_SLOTS][2 PS] accepted-proposal granules
     int* error_flag;         // != 0 after a launch: a bounded spin expired
     unsigned long long* stamps;   // diagnostic build only (PTNN_STAMPS): cycle sums per phase, else unused
+    float* wide_scratch;     // [Rl][3][PS] proposal, its SGD epoch, noise (wide nets only: these do not fit in LDS)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -276,6 +277,24 @@ __device__ __forceinline__ void build_fw(const float* __restrict__ w, float* __r
     if (gtid<WL>() < O) fw[H * FWS + gtid<WL>()] = w[oB2 + gtid<WL>()];
 }
 
+// Ordering key of np.argmax over the reference's FLOAT64 sigmoid outputs, computed from the fp32 pre-activation z.
+// sigmoid is monotone, so below z = 30 the key is z itself (fp32 outputs saturating to 1.0f must not tie where float64
+// outputs still differ).  From z = 30 on, float64 itself quantises: 1 + e^-z is rounded to a multiple of 2^-52, outputs
+// tie exactly when that multiple k = rint(e^-z 2^52) ties, and for z >= 53 ln 2 = 36.74 every output is exactly 1.0
+// (k = 0): np.argmax then returns the FIRST such class.  Below z = -709.78 np.exp(-z) overflows and the output is 0.0.
+// Returns (regime, value): compared lexicographically, full fp32 resolution of z inside the ordinary regime.
+struct ArgKey { int hi; float lo; };
+__device__ __forceinline__ ArgKey argmax_key(float z) {
+    ArgKey k;
+    if (z >= 30.0f) { k.hi = 2; k.lo = -rintf(__builtin_amdgcn_exp2f(fmaf(-LOG2E, z, 52.0f))); }
+    else if (z < -709.78f) { k.hi = 0; k.lo = 0.0f; }
+    else { k.hi = 1; k.lo = z; }
+    return k;
+}
+__device__ __forceinline__ bool argkey_greater(const ArgKey& a, const ArgKey& b) {
+    return (a.hi > b.hi) || (a.hi == b.hi && a.lo > b.lo);
+}
+
 // sums produced by one evaluation of (train ++ test) under a weight vector
 struct EvalSums {
     float a_tr, b_tr, c_tr;   // REG: SSE, -, -      CLS: sum log p(y), sum (pred-y)^2, #correct   (train rows)
@@ -329,15 +348,15 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
                 const float d = y - sigmoidf_fast(acc[b][0]);
                 a = d * d;
             } else {
-                float best = acc[b][0], se = 0.0f, oy = 0.0f;
+                ArgKey best = argmax_key(acc[b][0]);
+                float se = 0.0f, oy = 0.0f;
                 int arg = 0;
                 const int yi = (int)y;
 #pragma unroll
                 for (int o = 0; o < O; ++o) {
                     const float out = sigmoidf_fast(acc[b][o]);
-                    // np.argmax(out): first maximum (CLS:55).  Taken on the pre-activation: sigmoid is monotone, and fp32
-                    // outputs that saturate to 1.0f would tie where the reference's float64 outputs still differ
-                    if (acc[b][o] > best) { best = acc[b][o]; arg = o; }
+                    const ArgKey key = argmax_key(acc[b][o]);
+                    if (argkey_greater(key, best)) { best = key; arg = o; }   // np.argmax(out): first maximum (CLS:55)
                     se += expf_fast(out);                              // softmax of the sigmoid outputs (Q3)
                     oy = (o == yi) ? out : oy;
                 }
@@ -1030,6 +1049,260 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
             p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;
             p.L_final[gid] = lik;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wide hidden layers (64 < H <= 512, e.g. BASELINE config 5: 32-512-1, P = 17 409): one THREAD per hidden unit over up to
+// 8 waves of the work-group.  The per-replica vectors (w, proposal, SGD results, noise: 70 KB each) no longer fit in LDS
+// next to each other, so they live in HBM/L2 and are streamed with coalesced accesses; LDS holds the packed forward image of
+// the proposal and the reduction scratch; the data set is read through the scalar cache (wave-uniform rows) in the sweep
+// and through L2 in the forward pass.  Cooperative schedule only.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t wide_lds_floats(int H, int FWS, int O) {
+    return (size_t)(H + 1) * FWS + MAX_WAVES * 8 + 2 * MAX_WAVES * (size_t)((O + 3) & ~3) + 16;
+}
+
+// R5 for H > 64: thread h owns hidden unit h; the output pre-activation is a two-level sum (DPP inside the wave, then the
+// per-wave partials through LDS, summed in a fixed order by every thread); ONE work-group barrier per data row (the
+// partial buffers alternate between rows).
+template <int TASK, int I, int O>
+__device__ __forceinline__ void sgd_sweep_wide(const float* __restrict__ w_in, float* __restrict__ w_out,
+                                               const float* __restrict__ data, int IPY, int Ntr, int H, float lr,
+                                               float* __restrict__ part) {
+    constexpr float C = -LOG2E, IC = -LN2;
+    constexpr int OP = (O + 3) & ~3;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+    const bool act = t < H;
+    const int hl = act ? t : 0;
+    const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
+    const float clr = C * lr;
+    float w1[I], w2[O], cl[O];
+#pragma unroll
+    for (int i = 0; i < I; ++i) w1[i] = act ? C * w_in[i * H + hl] : 0.0f;
+#pragma unroll
+    for (int o = 0; o < O; ++o) w2[o] = act ? C * w_in[oW2 + hl * O + o] : 0.0f;
+    float b1 = act ? C * w_in[oB1 + hl] : -1.0e30f;
+#pragma unroll
+    for (int o = 0; o < O; ++o) cl[o] = -C * w_in[oB2 + o];          // replicated in every thread, updated identically
+    int par = 0;
+    for (int n = 0; n < Ntr; ++n) {
+        const float* __restrict__ row = data + (size_t)n * IPY;       // wave-uniform: scalar loads
+        float x[I + 1];
+#pragma unroll
+        for (int i = 0; i <= I; ++i) x[i] = row[i];
+        float z = fmaf(x[0], w1[0], -b1);
+#pragma unroll
+        for (int i = 1; i < I; ++i) z = fmaf(x[i], w1[i], z);
+        const float hid = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
+        const float ldh = lr * fmaf(-hid, hid, hid);
+        float* mypart = part + (size_t)par * MAX_WAVES * OP;
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            const float s_ = wave_allsum(hid * w2[o]);
+            if (lane == 0) mypart[wave * OP + o] = s_;
+        }
+        __syncthreads();
+        float g = 0.0f;
+        float lod[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            float zo = cl[o];
+            for (int w = 0; w < nw; ++w) zo += mypart[w * OP + o];
+            const float out = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zo));
+            float tt;
+            if (TASK == TASK_CLS) tt = ((int)x[I] == o) ? 1.0f : 0.0f;
+            else tt = x[I];
+            const float od = (tt - out) * fmaf(-out, out, out);
+            g = fmaf(od, w2[o], g);
+            lod[o] = clr * od;
+        }
+        const float lhd = g * ldh;
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            w2[o] = fmaf(lod[o], hid, w2[o]);
+            cl[o] += lod[o];
+        }
+#pragma unroll
+        for (int i = 0; i < I; ++i) w1[i] = fmaf(lhd, x[i], w1[i]);
+        b1 -= lhd;
+        par ^= 1;
+    }
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < I; ++i) w_out[i * H + t] = IC * w1[i];
+#pragma unroll
+        for (int o = 0; o < O; ++o) w_out[oW2 + t * O + o] = IC * w2[o];
+        w_out[oB1 + t] = IC * b1;
+    }
+    if (t == 0) {
+#pragma unroll
+        for (int o = 0; o < O; ++o) w_out[oB2 + o] = -IC * cl[o];
+    }
+    __syncthreads();
+}
+
+template <int TASK, int I, int O>
+__global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegParams p, const int step_begin, const int n_steps) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int OP = (O + 3) & ~3;
+    const int r = blockIdx.x;
+    const int gid = p.first_global + r;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int Nall = p.Ntr + p.Nte;
+    const int P = p.P, PS = p.PS, H = p.H;
+    float* fw = smem;
+    float* red = fw + (size_t)(H + 1) * p.FWS;
+    float* part = red + MAX_WAVES * 8;
+    float* scal = part + 2 * MAX_WAVES * OP;
+    const float* xy = p.data;                                   // global (L2 / scalar cache)
+    float* w_cur = p.w_state + (size_t)r * PS;                  // chain state row, updated in place
+    float* w_gd = p.gd_w + (size_t)r * PS;
+    float* rec_w = p.rec_w + (size_t)r * PS;
+    float* w_prop = p.wide_scratch + ((size_t)r * 3 + 0) * PS;
+    float* w_pgd = p.wide_scratch + ((size_t)r * 3 + 1) * PS;
+    float* noise = p.wide_scratch + ((size_t)r * 3 + 2) * PS;
+
+    const float T = p.temps[r];
+    float eta = (TASK == TASK_REG) ? w_cur[P] : 0.0f;
+    float* sf = p.st_f + (size_t)r * SF_COUNT;
+    int* si = p.st_i + (size_t)r * SI_COUNT;
+    float lik, prior_cur, tau_eta_last, rec_rmse_tr, rec_rmse_te, rec_acc_tr, rec_acc_te;
+    int nacc, gd_valid, lg_count;
+    if (step_begin == 0) {
+        chain_startup<TASK, I, O>(p, xy, w_cur, fw, red, T, eta, lik, prior_cur);
+        tau_eta_last = eta;
+        rec_rmse_tr = rec_rmse_te = rec_acc_tr = rec_acc_te = 0.f;
+        nacc = 0; gd_valid = 0; lg_count = 0;
+        __syncthreads();
+    } else {
+        lik = sf[SF_LIK]; prior_cur = sf[SF_PRIOR]; tau_eta_last = sf[SF_TAU_LAST];
+        rec_rmse_tr = sf[SF_REC_RMSE_TR]; rec_rmse_te = sf[SF_REC_RMSE_TE];
+        rec_acc_tr = sf[SF_REC_ACC_TR]; rec_acc_te = sf[SF_REC_ACC_TE];
+        nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT];
+    }
+
+    const size_t trow = (size_t)r * p.S;
+    for (int i = step_begin; i < step_begin + n_steps; ++i) {
+        const float adapttemp = (p.switch_step >= 0 && i >= p.switch_step) ? 1.0f : T;
+        if (i == p.switch_step) {
+            build_fw<I, O>(w_cur, fw, H, p.FWS);
+            __syncthreads();
+            const EvalSums sc = eval_rows<TASK, I, O>(fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, red);
+            float ll, r1, r2, a1, a2;
+            finish_eval<TASK>(sc, p.Ntr, p.Nte, tau_eta_last, ll, r1, r2, a1, a2);
+            lik = ll;
+            __syncthreads();
+        }
+        tape_step(p, gid, i, noise, scal);
+        __syncthreads();
+        const float lx = scal[0], u = scal[1], n_eta = scal[2];
+        float diff_prop = 0.0f;
+        const bool lg = p.use_lg && (lx < p.l_prob);
+        if (lg) {
+            if (!gd_valid) {
+                sgd_sweep_wide<TASK, I, O>(w_cur, w_gd, xy, p.IPY, p.Ntr, H, p.lr, part);
+                gd_valid = 1;
+            }
+            for (int j = tid; j < P; j += nthr) w_prop[j] = fmaf(p.step_w, noise[j], w_gd[j]);
+            __syncthreads();
+            sgd_sweep_wide<TASK, I, O>(w_prop, w_pgd, xy, p.IPY, p.Ntr, H, p.lr, part);
+            const float d1 = block_sumsq_diff(w_cur, w_pgd, P, red);
+            const float d2 = block_sumsq(noise, P, red);
+            diff_prop = (-0.5f * d1 / (p.step_w * p.step_w) + 0.5f * d2) / adapttemp;
+            lg_count += 1;
+        } else {
+            for (int j = tid; j < P; j += nthr) w_prop[j] = fmaf(p.step_w, noise[j], w_cur[j]);
+            __syncthreads();
+        }
+        float eta_pro = eta;
+        if (TASK == TASK_REG) { eta_pro = fmaf(p.step_eta, n_eta, eta); tau_eta_last = eta_pro; }
+        build_fw<I, O>(w_prop, fw, H, p.FWS);
+        __syncthreads();
+        const EvalSums es = eval_rows<TASK, I, O>(fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, red);
+        float ll, rm_tr, rm_te, ac_tr, ac_te;
+        finish_eval<TASK>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
+        const float lik_prop = ll / adapttemp;
+        const float ssq = block_sumsq(w_prop, P, red);
+        const float prior_prop = prior_value<TASK>(p, ssq, eta_pro);
+        const float logalpha = (lik_prop - lik) + (prior_prop - prior_cur) + diff_prop;
+        const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
+        const bool accept = u < mh;
+        const int acc_before = nacc;
+        __syncthreads();                                    // every reader of w_cur / w_gd of this step is done
+        float* prow = p.tr_pos_w + (trow + i + 1) * (size_t)P;
+        if (accept) {
+            nacc += 1;
+            lik = lik_prop; prior_cur = prior_prop; eta = eta_pro;
+            rec_rmse_tr = rm_tr; rec_rmse_te = rm_te; rec_acc_tr = ac_tr; rec_acc_te = ac_te;
+            gd_valid = lg ? 1 : 0;
+            for (int j = tid; j < P; j += nthr) {
+                const float v = w_prop[j];
+                w_cur[j] = v; rec_w[j] = v; prow[j] = v;
+                if (lg) w_gd[j] = w_pgd[j];
+            }
+        } else {
+            for (int j = tid; j < P; j += nthr) prow[j] = rec_w[j];
+        }
+        if (tid == 0) {
+            p.tr_likeh[trow + i + 1] = (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp;
+            p.tr_accept[trow + i + 1] = acc_before;
+            p.tr_rmse_tr[trow + i + 1] = rec_rmse_tr;
+            p.tr_rmse_te[trow + i + 1] = rec_rmse_te;
+            p.tr_acc_tr[trow + i + 1] = rec_acc_tr;
+            p.tr_acc_te[trow + i + 1] = rec_acc_te;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        w_cur[P] = eta;
+        sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur; sf[SF_TAU_LAST] = tau_eta_last;
+        sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;
+        sf[SF_REC_ACC_TR] = rec_acc_tr; sf[SF_REC_ACC_TE] = rec_acc_te;
+        si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count;
+        p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;
+        p.L_final[gid] = lik;
+    }
+}
+
+// stand-alone model functions for wide nets: mode 0 = evaluate, 1 = langevin_gradient (mode 2, the tape, is shape
+// independent and served by model_kernel)
+template <int TASK, int I, int O>
+__global__ void __launch_bounds__(MAX_THREADS) model_wide_kernel(const SegParams p, const int mode, const float* __restrict__ w_in,
+                                                                  const float* __restrict__ tau_sq, float* __restrict__ out, int a0,
+                                                                  int a1) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int OP = (O + 3) & ~3;
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const int Nall = p.Ntr + p.Nte;
+    float* fw = smem;
+    float* red = fw + (size_t)(p.H + 1) * p.FWS;
+    float* part = red + MAX_WAVES * 8;
+    float* scal = part + 2 * MAX_WAVES * OP;
+    if (mode == 2) {
+        tape_step(p, a0, a1, out, scal);                  // noise straight to the output buffer (16-byte aligned)
+        __syncthreads();
+        if (tid < 3) out[p.PS + tid] = scal[tid];
+        return;
+    }
+    const float* w = w_in + (size_t)b * p.P;
+    if (mode == 1) {
+        sgd_sweep_wide<TASK, I, O>(w, out + (size_t)b * p.P, p.data, p.IPY, p.Ntr, p.H, p.lr, part);
+        return;
+    }
+    build_fw<I, O>(w, fw, p.H, p.FWS);
+    __syncthreads();
+    const EvalSums s = eval_rows<TASK, I, O>(fw, p.data, p.IPY, p.FWS, p.H, p.Ntr, Nall, red);
+    const float eta = (TASK == TASK_REG) ? logf_fast(tau_sq[b]) : 0.0f;
+    float ll, r1, r2, a_tr, a_te;
+    finish_eval<TASK>(s, p.Ntr, p.Nte, eta, ll, r1, r2, a_tr, a_te);
+    const float ss = block_sumsq(w, p.P, red);
+    const float pr = prior_value<TASK>(p, ss, eta);
+    float ll_te = s.a_te;
+    if (TASK == TASK_REG) ll_te = -0.5f * (float)p.Nte * (LOG_2PI + eta) - 0.5f * s.a_te * expf_fast(-eta);
+    if (tid == 0) {
+        float* o = out + (size_t)b * 8;
+        o[0] = ll; o[1] = r1; o[2] = r2; o[3] = a_tr; o[4] = a_te; o[5] = pr; o[6] = ll_te; o[7] = 0.f;
     }
 }
 

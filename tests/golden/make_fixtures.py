@@ -72,7 +72,22 @@ def load_datasets():
     d["ions_test"] = np.genfromtxt(os.path.join(cbase, "Ions", "Ions", "ftest.csv"), delimiter=",")[:, :-1]
     d["cancer_train"] = np.genfromtxt(os.path.join(cbase, "Cancer", "ftrain.txt"), delimiter=" ")[:, :-1]
     d["cancer_test"] = np.genfromtxt(os.path.join(cbase, "Cancer", "ftest.txt"), delimiter=" ")[:, :-1]
+    # small sibling of BASELINE config 5: teacher FNN on uniform inputs, 32 features, targets in [0,1]
+    d["synth32_train"], d["synth32_test"] = synthetic_regression(96, 64, 32, 96, seed=5)
     return d
+
+
+def synthetic_regression(n_rows, n_train, n_in, n_hidden, seed):
+    """SURVEY.md 8(d) config 5 recipe: X ~ U(0,1), teacher FNN [n_in, n_hidden, 1] with N(0,1)/sqrt(fan_in) weights run
+    through the reference forward rule (bias subtracted, sigmoid output), y = clip(teacher + N(0, 0.02^2), 0, 1)."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, 1, (n_rows, n_in))
+    topo = (n_in, n_hidden, 1)
+    w_t = np.concatenate([rng.standard_normal(n_in * n_hidden) / np.sqrt(n_in), rng.standard_normal(n_hidden) / np.sqrt(n_hidden),
+                          rng.standard_normal(n_hidden) / np.sqrt(n_in), rng.standard_normal(1) / np.sqrt(n_hidden)])
+    y = np.clip(orc.forward(X, w_t, topo)[1][:, 0] + rng.normal(0, 0.02, n_rows), 0, 1)
+    data = np.hstack([X, y[:, None]])
+    return data[:n_train], data[n_train:]
 
 
 # --------------------------------------------------------------------------------------------
@@ -185,6 +200,8 @@ CASES = [  # (key, module, task, topology, dataset)
     ("reg_mackey_4_10_1", "REG", orc.TASK_REG, [4, 10, 1], "mackey"),
     ("cls_iris_4_12_3", "CLS", orc.TASK_CLS, [4, 12, 3], "iris"),
     ("cls_ions_34_50_2", "CLS", orc.TASK_CLS, [34, 50, 2], "ions"),
+    ("reg_synth_32_96_1", "REG", orc.TASK_REG, [32, 96, 1], "synth32"),      # H > 64: the multi-wave (wide) kernels
+    ("cls_ions_34_100_2", "CLS", orc.TASK_CLS, [34, 100, 2], "ions"),
 ]
 
 
@@ -261,6 +278,8 @@ TRAJ = [  # key, module, task, topo, dataset, use_lg, lr, T, S, seed
     ("cls_lg", "CLS", orc.TASK_CLS, [4, 12, 3], "iris", True, 0.01, 1.0, 100, 105),
     ("cls_rw_ions", "CLS", orc.TASK_CLS, [34, 50, 2], "ions", False, 0.01, 1.6681005372000588, 60, 106),
     ("reg_rw_noswitch", "REG", orc.TASK_REG, [4, 5, 1], "sunspot", False, 0.1, 2.0, 57, 107),  # 0.6*57 not integral
+    ("reg_lg_wide", "REG", orc.TASK_REG, [32, 96, 1], "synth32", True, 0.1, 1.2599210498948732, 30, 108),
+    ("cls_lg_wide", "CLS", orc.TASK_CLS, [34, 100, 2], "ions", True, 0.01, 1.0, 30, 109),
 ]
 
 

@@ -22,7 +22,7 @@ def ds():
 
 
 FUNC_CASES = {"reg_sunspot_4_5_1": "sunspot", "reg_mackey_4_10_1": "mackey", "cls_iris_4_12_3": "iris",
-              "cls_ions_34_50_2": "ions"}
+              "cls_ions_34_50_2": "ions", "reg_synth_32_96_1": "synth32", "cls_ions_34_100_2": "ions"}
 
 
 def test_library_is_the_hip_build():
@@ -30,15 +30,18 @@ def test_library_is_the_hip_build():
     lib = ptnn_amd.load_library()
     assert lib.ptnn_abi_version() == 1
     assert lib.ptnn_supports(0, 4, 5, 1) == 1 and lib.ptnn_supports(1, 34, 50, 2) == 1
-    assert lib.ptnn_supports(0, 4, 65, 1) == 0 and lib.ptnn_supports(0, 7, 5, 1) == 0
+    assert lib.ptnn_supports(0, 4, 65, 1) == 1 and lib.ptnn_supports(0, 32, 512, 1) == 1
+    assert lib.ptnn_supports(0, 4, 513, 1) == 0 and lib.ptnn_supports(0, 7, 5, 1) == 0
 
 
 @pytest.mark.parametrize("waves", [1, 4])
 def test_random_tape_matches_spec(waves):
     d = ds()
-    for topo, task, name in (((4, 5, 1), 0, "sunspot"), ((34, 50, 2), 1, "ions")):
+    for topo, task, name in (((4, 5, 1), 0, "sunspot"), ((34, 50, 2), 1, "ions"), ((32, 96, 1), 0, "synth32")):
+        if topo[1] > 64 and waves != 1:
+            continue
         s = parity.make_sampler(task, topo, d[name + "_train"], d[name + "_test"], R_local=2, R_global=2, first=0, S=10,
-                                si=100, use_lg=False, lr=0.1, seed=0x1234567890ABCDEF, waves=waves)
+                                si=100, use_lg=False, lr=0.1, seed=0x1234567890ABCDEF, waves=0 if topo[1] > 64 else waves)
         tape = orc.PhiloxTape(0x1234567890ABCDEF)
         P = orc.num_param(topo)
         for rep, step in ((0, 0), (1, 7), (63, 9999), (1023, 123456)):
@@ -62,6 +65,8 @@ def test_model_functions_against_reference_vectors(key, waves):
     task = int(g["task"])
     d = ds()
     train, test = d[FUNC_CASES[key] + "_train"], d[FUNC_CASES[key] + "_test"]
+    if topo[1] > 64:
+        waves = 0                                    # wide nets: the thread count follows n_hidden
     for lr in (0.1, 0.01):
         s = parity.make_sampler(task, topo, train, test, R_local=2, R_global=2, first=0, S=10, si=100, use_lg=True, lr=lr,
                                 seed=1, waves=waves)
@@ -104,7 +109,7 @@ def test_model_functions_against_reference_vectors(key, waves):
         s.close()
 
 
-TRAJ = ["reg_rw", "reg_lg", "reg_lg_mackey", "cls_rw", "cls_lg", "cls_rw_ions", "reg_rw_noswitch"]
+TRAJ = ["reg_rw", "reg_lg", "reg_lg_mackey", "cls_rw", "cls_lg", "cls_rw_ions", "reg_rw_noswitch", "reg_lg_wide", "cls_lg_wide"]
 
 
 @pytest.mark.parametrize("key", TRAJ)
@@ -113,6 +118,10 @@ def test_single_replica_trajectory(key, schedule, waves):
     """F4: one chain (no swaps) against the trace the reference's ptReplica.run produced on the same random tape."""
     g = parity.golden(f"trajectory_{key}.npz")
     topo = tuple(int(v) for v in g["topology"])
+    if topo[1] > 64 and (schedule == 2 or waves != 0 and schedule != 1):
+        pytest.skip("wide nets run the cooperative schedule with one thread per hidden unit")
+    if topo[1] > 64:
+        waves = 0
     task, S, gid, seed = int(g["task"]), int(g["S"]), int(g["gid"]), int(g["seed"])
     d = ds()
     dname = str(g["dataset"])

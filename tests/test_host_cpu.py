@@ -37,7 +37,7 @@ def test_supports_table(pt):
     for task, I, H, O in [(0, 4, 5, 1), (0, 4, 10, 1), (0, 5, 5, 1), (1, 4, 12, 3), (1, 34, 50, 2), (1, 9, 12, 2),
                           (1, 16, 30, 10), (1, 11, 50, 10), (1, 20, 50, 2), (1, 6, 25, 18), (0, 32, 64, 1)]:
         assert lib.ptnn_supports(task, I, H, O) == 1, (task, I, H, O)
-    assert lib.ptnn_supports(0, 32, 512, 1) == 0          # H > 64: not built yet, must say so
+    assert lib.ptnn_supports(0, 32, 512, 1) == 1 and lib.ptnn_supports(0, 32, 513, 1) == 0
     assert lib.ptnn_supports(0, 3, 5, 1) == 0
 
 

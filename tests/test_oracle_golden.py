@@ -16,9 +16,10 @@ def _load(golden_dir, name):
     return dict(np.load(os.path.join(golden_dir, name), allow_pickle=False))
 
 
-FUNC_CASES = ["reg_sunspot_4_5_1", "reg_mackey_4_10_1", "cls_iris_4_12_3", "cls_ions_34_50_2"]
+FUNC_CASES = ["reg_sunspot_4_5_1", "reg_mackey_4_10_1", "cls_iris_4_12_3", "cls_ions_34_50_2", "reg_synth_32_96_1",
+              "cls_ions_34_100_2"]
 DATA_OF = {"reg_sunspot_4_5_1": "sunspot", "reg_mackey_4_10_1": "mackey", "cls_iris_4_12_3": "iris",
-           "cls_ions_34_50_2": "ions"}
+           "cls_ions_34_50_2": "ions", "reg_synth_32_96_1": "synth32", "cls_ions_34_100_2": "ions"}
 
 
 def test_philox_known_answer():
