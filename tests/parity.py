@@ -111,3 +111,16 @@ def run_smoke_check():
             assert gap < LOGALPHA_SLACK or np.isnan(gap), f"replica {r} diverged at step {i} with |log a - log u| = {gap}"
     s.close()
     return firsts
+
+
+def synthetic_regression(n_rows, n_train, n_in, n_hidden, seed):
+    """SURVEY.md 8(d) config-5 recipe (same as tests/golden/make_fixtures.py): X ~ U(0,1), teacher FNN run through the
+    reference forward rule, y = clip(teacher + N(0, 0.02^2), 0, 1)."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(0, 1, (n_rows, n_in))
+    topo = (n_in, n_hidden, 1)
+    w_t = np.concatenate([rng.standard_normal(n_in * n_hidden) / np.sqrt(n_in), rng.standard_normal(n_hidden) / np.sqrt(n_hidden),
+                          rng.standard_normal(n_hidden) / np.sqrt(n_in), rng.standard_normal(1) / np.sqrt(n_hidden)])
+    y = np.clip(orc.forward(X, w_t, topo)[1][:, 0] + rng.normal(0, 0.02, n_rows), 0, 1)
+    data = np.hstack([X, y[:, None]])
+    return data[:n_train], data[n_train:]

@@ -399,3 +399,33 @@ def test_statistics_match_long_reference_runs(key):
     if task == 1:
         ref_at = [r["acc_train_mean"] for r in f["runs"]]
         assert min(ref_at) - 15 < np.mean(at) < max(ref_at) + 15, (np.mean(at), ref_at)
+
+
+def test_config5_shape_against_oracle():
+    """BASELINE config 5 at full network and data size (FNN 32-512-1, P = 17 409, 1024 / 256 rows, Langevin), a few
+    replicas and steps: the wide kernels against the oracle on the same tape."""
+    train, test = parity.synthetic_regression(1280, 1024, 32, 512, seed=5)
+    topo, R, S, si, seed = (32, 512, 1), 4, 12, 5, 55
+    pt = orc.PTOracle(orc.TASK_REG, topo, train, test, R, 2, R * S, si, use_lg=True, l_prob=0.5, lr=0.1, seed=seed)
+    w0 = (0.3 * np.stack([rep.w for rep in pt.replicas])).astype(np.float32)
+    for rep, w in zip(pt.replicas, w0):
+        rep.__init__(orc.TASK_REG, topo, pt.train, pt.test, w.astype(np.float64), rep.T, S, True, 0.5, 0.1, pt.tape, rep.gid)
+    o = parity.OracleRun(pt).run()
+    s = parity.make_sampler(orc.TASK_REG, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=True, lr=0.1,
+                            seed=seed)
+    s.set_state(w0, np.array(pt.temperatures, dtype=np.float32))
+    s.run(-1)
+    s.sync()
+    tr = s.traces()
+    nsw, tot, rounds = s.swap_stats()
+    assert rounds == pt.rounds_done and tot == pt.total_swap_proposals
+    for r in range(R):
+        first = parity.compare_replica_trace(tr, r, pt.replicas[r], f"config5 r{r} ")
+        if first is not None:
+            i = first - 2
+            assert abs(o.logalpha[r, i] - o.logu[r, i]) < 0.05, (r, i, o.logalpha[r, i], o.logu[r, i])
+    # the SGD epoch on its own at this size: 1024 dependent rows, 512 x 33 weights
+    w = w0[0]
+    np.testing.assert_allclose(s.langevin_gradient(w)[0], orc.langevin_gradient(train, w.astype(np.float64), topo, 0.1, 0),
+                               rtol=2e-4, atol=5e-5)
+    s.close()
