@@ -58,6 +58,7 @@ def load_datasets():
     for name in ("Sunspot", "Mackey", "Lazer"):
         d[name.lower() + "_train"] = np.loadtxt(os.path.join(base, name, "train.txt"))
         d[name.lower() + "_test"] = np.loadtxt(os.path.join(base, name, "test.txt"))
+        d[name.lower() + "_scaled"] = np.loadtxt(os.path.join(base, name, "scaled_dataset.txt")).reshape(-1)
     cbase = os.path.join(REF, "multicore-pt-classification", "DATA")
     iris = np.genfromtxt(os.path.join(cbase, "iris.csv"), delimiter=";")
     classes = iris[:, 4].reshape(-1, 1) - 1          # CLS:921

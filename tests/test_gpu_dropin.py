@@ -105,3 +105,28 @@ def test_zero_rounds_raises_like_the_reference(tmp_path):
     pt.initialize_chains(0.5)
     with pytest.raises(ZeroDivisionError):          # swap_interval > NumSamples: no round, 0/0 (REG:769)
         pt.run_chains()
+
+
+def test_experiment_drivers(tmp_path):
+    """drivers.run_regression / run_classification: run-dir numbering, result.txt, master_result_file.txt (REG:1044-1061)."""
+    import ptnn_amd
+    from ptnn_amd import drivers
+    d = parity.datasets()
+    base, db = str(tmp_path / "work") + "/", str(tmp_path / "db") + "/"
+    os.makedirs(base); os.makedirs(db)
+    for k in range(2):
+        out = drivers.run_regression("Sunspot", d["sunspot_train"], d["sunspot_test"], hidden=5, NumSample=4000, num_chains=4,
+                                     problemfolder=base, problemfolder_db=db, seed=5 + k, plots=(k == 0))
+        assert out["run_name"] == f"Sunspot_{k}" and os.path.isdir(base + f"Sunspot_{k}/posterior/pos_w")
+        row = open(out["path"] + "/result.txt").read().split()
+        assert len(row) == 15 and row[0] == "2.0000" and row[1] == "4000.0000" and row[3] == "10.0000"
+        assert all(len(t.split(".")[1]) == 4 for t in row)
+    master = open(base + "master_result_file.txt").read().strip().splitlines()
+    assert len(master) == 2 and master[0].split()[-1] == "Sunspot_0" and master[1].split()[-1] == "Sunspot_1"
+    assert len(master[0].split()) == 16
+    assert os.path.exists(db + "Sunspot_0/rmse_samples.pdf") and os.path.exists(base + "Sunspot_0/likelihood.pdf")
+    out = drivers.run_classification("iris", d["iris_train"], d["iris_test"], NumSample=4000, num_chains=4, problemfolder=base,
+                                     problemfolder_db=db, seed=7, plots=False)
+    row = open(out["path_db"] + "/result.txt").read().split()
+    assert len(row) == 15 and row[0] == "3.00" and row[2] == "10.00" and row[3] == "20.00"
+    assert 0.0 <= float(row[6]) <= 100.0 and 0.0 <= float(row[12]) <= 100.0

@@ -128,3 +128,24 @@ def test_text_round_is_the_file_round_trip(pt, tmp_path):
         f = tmp_path / "x.txt"
         np.savetxt(f, a, fmt=fmt)
         assert (np.loadtxt(f) == _text_round(a, fmt)).all()
+
+
+def test_takens_embedding_reproduces_shipped_files(pt, datasets):
+    from ptnn_amd import drivers
+    for name in ("sunspot", "mackey", "lazer"):
+        tr, te = drivers.takens_embedding(datasets[name + "_scaled"], window=5, stride=2)
+        assert tr.shape == datasets[name + "_train"].shape and te.shape == datasets[name + "_test"].shape, name
+        np.testing.assert_allclose(tr, datasets[name + "_train"], atol=1e-12)
+        np.testing.assert_allclose(te, datasets[name + "_test"], atol=1e-12)
+
+
+def test_split_and_normalise(pt):
+    from ptnn_amd import drivers
+    rng = np.random.default_rng(0)
+    f = rng.normal(3, 2, (150, 4))
+    c = rng.integers(0, 3, (150, 1)).astype(float)
+    tr, te = drivers.split_and_normalise(f, c, 4, rng=np.random.default_rng(1))
+    assert tr.shape == (105, 5) and te.shape == (45, 5)
+    allx = np.vstack([tr, te])[:, :4]
+    np.testing.assert_allclose(allx.mean(0), 0, atol=1e-12)
+    np.testing.assert_allclose(allx.std(0), 1, atol=1e-12)
