@@ -51,6 +51,8 @@ typedef struct ptnn_config {
                                    * (wave v pre-computes step i+v; identical chain) */
     int32_t groups_per_replica;   /* speculative schedule: work-groups (CUs) cooperating on one replica; 0 = auto
                                    * (as many of 1, 2, 4 as keeps replicas x groups <= number of CUs) */
+    int32_t trace_capacity;       /* rows per replica kept on the device (ring); 0 = all n_samples rows.  With a smaller
+                                   * value the caller drains with ptnn_get_traces at least every trace_capacity steps */
     float l_prob;                 /* langevin_prob (REG:174); CLS fixes 0.5 (CLS:192) */
     float learn_rate;             /* SGD step of langevin_gradient (REG:33) */
     float step_w;                 /* 0.025 (REG:258) */
@@ -108,7 +110,8 @@ int ptnn_state_row_floats(ptnn_handle *h);
 int ptnn_swap_apply(ptnn_handle *h, const int32_t *src_host, int phantom);
 
 /* ---- results ---- */
-/* traces of steps [step0, step0+nsteps) for all local replicas; any pointer may be NULL.
+/* traces of rows [step0, step0+nsteps) for all local replicas (row i+1 is written by MH step i; the rows must still be in
+ * the ring: step0 >= steps_done + 1 - trace_capacity); any pointer may be NULL.
  * pos_w [R,nsteps,P] (REG:240,408,417); likeh [R,nsteps] = column 0 of likeh_list (REG:391 / CLS:404);
  * rmse_* / acc_* [R,nsteps] (REG:403-423); accept_count [R,nsteps] = accept_list (REG:380). */
 int ptnn_get_traces(ptnn_handle *h, int step0, int nsteps, float *pos_w, float *likeh, float *rmse_train,
@@ -145,6 +148,10 @@ int ptnn_debug_stamps(ptnn_handle *h, uint64_t *out16);
 /* np.savetxt(path, data[rows, cols], fmt=fmt) with ' ' between columns and '\n' after rows (REG:454-481, 864-868).
  * fmt is one printf floating conversion such as "%.18e", "%1.8f", "%1.2f". */
 int ptnn_savetxt(const char *path, const double *data, int64_t rows, int64_t cols, const char *fmt);
+
+/* in place: every value as np.loadtxt would read it back after np.savetxt(fmt=fmt) (show_results re-reads the per-chain
+ * files, REG:795-831) */
+int ptnn_text_round(double *values, int64_t n, const char *fmt);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ class Config(C.Structure):
         ("n_in", C.c_int32), ("n_hidden", C.c_int32), ("n_out", C.c_int32),
         ("n_replicas_local", C.c_int32), ("n_replicas_global", C.c_int32), ("first_global_replica", C.c_int32),
         ("n_samples", C.c_int32), ("swap_interval", C.c_int32), ("pt_switch_step", C.c_int32),
-        ("use_langevin", C.c_int32), ("waves_per_replica", C.c_int32), ("schedule", C.c_int32), ("groups_per_replica", C.c_int32),
+        ("use_langevin", C.c_int32), ("waves_per_replica", C.c_int32), ("schedule", C.c_int32), ("groups_per_replica", C.c_int32), ("trace_capacity", C.c_int32),
         ("l_prob", C.c_float), ("learn_rate", C.c_float), ("step_w", C.c_float), ("step_eta", C.c_float),
         ("sigma_squared", C.c_float), ("nu_1", C.c_float), ("nu_2", C.c_float),
         ("seed", C.c_uint64),
@@ -64,6 +64,7 @@ SYMBOLS = {
     "ptnn_tape": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp]),
     "ptnn_kernel_time": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ptnn_debug_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "ptnn_text_round": (C.c_int, [C.POINTER(C.c_double), C.c_int64, C.c_char_p]),
     "ptnn_savetxt": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_char_p]),
 }
 
@@ -259,3 +260,31 @@ def savetxt(path, array, fmt):
     rc = lib.ptnn_savetxt(os.fsencode(path), a.ctypes.data_as(C.POINTER(C.c_double)), rows, cols, fmt.encode())
     if rc < 0:
         raise PtnnError(lib.ptnn_last_error().decode())
+
+
+def text_round(array, fmt, threads=8):
+    """Values as np.loadtxt reads them back after np.savetxt(..., fmt=fmt): printf + strtod in the C library, chunked
+    over a few threads (ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    lib = load_library()
+    a = np.array(array, dtype=np.float64, order="C", copy=True)
+    flat = a.reshape(-1)
+    n = flat.shape[0]
+    if n == 0:
+        return a
+    nchunk = max(1, min(threads, n // 4096 + 1))
+    bounds = np.linspace(0, n, nchunk + 1).astype(np.int64)
+
+    def work(k):
+        lo, hi = int(bounds[k]), int(bounds[k + 1])
+        if hi > lo:
+            rc = lib.ptnn_text_round(flat[lo:hi].ctypes.data_as(C.POINTER(C.c_double)), hi - lo, fmt.encode())
+            if rc < 0:
+                raise PtnnError(lib.ptnn_last_error().decode())
+
+    if nchunk == 1:
+        work(0)
+    else:
+        with ThreadPoolExecutor(max_workers=nchunk) as ex:
+            list(ex.map(work, range(nchunk)))
+    return a

@@ -93,6 +93,8 @@ struct ptnn_handle {
     int* d_error = nullptr;
     unsigned long long* d_stamps = nullptr;
     bool have_data = false, have_state = false, finalized = false;
+    int cap = 0;            // trace ring rows per replica
+    int drained = 0;        // rows [0, drained] have been fetched by the caller (streaming mode)
     int cur = 0;            // next MH step index
     int rounds_done = 0;    // swap rounds counted (including the phantom one)
     int max_rounds = 0;
@@ -123,6 +125,7 @@ struct ptnn_handle {
         p.H = cfg.n_hidden; p.P = P; p.PS = PS;
         p.Ntr = Ntr; p.Nte = Nte; p.IPY = IPY; p.FWS = FWS;
         p.S = cfg.n_samples; p.switch_step = cfg.pt_switch_step; p.use_lg = cfg.use_langevin;
+        p.trace_cap = cap;
         p.first_global = cfg.first_global_replica;
         p.l_prob = cfg.l_prob; p.lr = cfg.learn_rate; p.step_w = cfg.step_w; p.step_eta = cfg.step_eta;
         p.inv_2sig2 = 1.0f / (2.0f * cfg.sigma_squared);
@@ -275,7 +278,10 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
     h->FWS = round_up4(I + 1 + O);
     h->max_rounds = cfg->n_samples / cfg->swap_interval + 2;
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    const size_t Rl = cfg->n_replicas_local, R = cfg->n_replicas_global, S = cfg->n_samples;
+    if (cfg->trace_capacity < 0 || (cfg->trace_capacity > 0 && cfg->trace_capacity < 2))
+        return fail(-1, "trace_capacity must be 0 (= n_samples) or >= 2");
+    h->cap = (cfg->trace_capacity > 0 && cfg->trace_capacity < cfg->n_samples) ? cfg->trace_capacity : cfg->n_samples;
+    const size_t Rl = cfg->n_replicas_local, R = cfg->n_replicas_global, S = h->cap;
     HIP_TRY(hipMalloc(&h->d_state[0], Rl * h->PS * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_state[1], Rl * h->PS * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_rec_w, Rl * h->PS * sizeof(float)));
@@ -441,7 +447,7 @@ int ptnn_set_state(ptnn_handle* h, const float* w0, const float* temperatures) {
     if (!h || !w0 || !temperatures) return fail(-1, "null argument");
     if (!h->have_data) return fail(-1, "call ptnn_set_data before ptnn_set_state");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    const int Rl = h->cfg.n_replicas_local, P = h->P, PS = h->PS, S = h->cfg.n_samples;
+    const int Rl = h->cfg.n_replicas_local, P = h->P, PS = h->PS, S = h->cap;
     std::vector<float> st((size_t)Rl * PS, 0.0f), ones((size_t)Rl * PS, 1.0f);
     for (int r = 0; r < Rl; ++r) std::memcpy(&st[(size_t)r * PS], w0 + (size_t)r * P, P * sizeof(float));
     HIP_TRY(hipMemcpy(h->d_state[0], st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -467,7 +473,7 @@ int ptnn_set_state(ptnn_handle* h, const float* w0, const float* temperatures) {
         HIP_TRY(hipMemcpy(h->d_pos_w + (size_t)r * S * P, onesP.data(), P * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->d_likeh + (size_t)r * S, &m100, sizeof(float), hipMemcpyHostToDevice));
     }
-    h->flip = 0; h->cur = 0; h->rounds_done = 0; h->finalized = false;
+    h->flip = 0; h->cur = 0; h->rounds_done = 0; h->finalized = false; h->drained = 0;
     HIP_TRY(hipMemset(h->d_counters, 0, 2 * sizeof(long long)));
     h->have_state = true;
     return 0;
@@ -482,6 +488,9 @@ int ptnn_run(ptnn_handle* h, int n_steps) {
     const int S = h->cfg.n_samples;
     const int last = S - 1;                                  // steps are i = 0 .. S-2
     int end = (n_steps < 0) ? last : std::min(last, h->cur + n_steps);
+    if (h->cap < S && end - h->drained > h->cap - 1)
+        return fail(-6, "trace ring of %d rows would overflow: rows from %d on have not been fetched; call ptnn_get_traces "
+                        "first or run fewer steps", h->cap, h->drained + 1);
     while (h->cur < end) {
         int seg_end = h->cur;
         while (seg_end < end && !swap_trigger(h->cfg, seg_end)) ++seg_end;
@@ -529,6 +538,9 @@ int ptnn_run_segment(ptnn_handle* h, int* handoff) {
         while (seg_end < last && !swap_trigger(h->cfg, seg_end)) ++seg_end;
         const bool ho = seg_end < last;
         const int stop = ho ? seg_end + 1 : last;
+        if (h->cap < S && stop - h->drained > h->cap - 1)
+            return fail(-6, "trace ring of %d rows would overflow: fetch rows from %d on with ptnn_get_traces first", h->cap,
+                        h->drained + 1);
         if (int rc = launch_segment(h, h->cur, stop - h->cur)) return rc;
         h->cur = stop;
         if (ho) { *handoff = 1; return 0; }
@@ -584,18 +596,31 @@ int ptnn_swap_apply(ptnn_handle* h, const int32_t* src_host, int phantom) {
 int ptnn_get_traces(ptnn_handle* h, int step0, int nsteps, float* pos_w, float* likeh, float* rmse_train,
                     float* rmse_test, float* acc_train, float* acc_test, int32_t* accept_count) {
     if (int rc = check_ready(h)) return rc;
-    const int S = h->cfg.n_samples, Rl = h->cfg.n_replicas_local, P = h->P;
+    const int S = h->cfg.n_samples, Rl = h->cfg.n_replicas_local, P = h->P, cap = h->cap;
     if (step0 < 0 || nsteps < 0 || step0 + nsteps > S) return fail(-1, "trace range [%d, %d) outside [0, %d)", step0, step0 + nsteps, S);
     if (nsteps == 0) return 0;
+    if (step0 + nsteps > h->cur + 1) return fail(-1, "rows up to %d requested but only %d MH steps have been queued", step0 + nsteps - 1, h->cur);
+    if (step0 < h->cur + 1 - cap) return fail(-1, "row %d has already been overwritten in the trace ring (capacity %d, %d steps done)", step0, cap, h->cur);
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     HIP_TRY(hipStreamSynchronize(h->stream));
     collect_timing(h);
+    // the range may wrap around the ring: at most two contiguous pieces
     auto copy2d = [&](void* dst, const void* src_base, size_t elem_bytes, size_t per_step) -> hipError_t {
         if (!dst) return hipSuccess;
-        const size_t width = (size_t)nsteps * per_step * elem_bytes;
-        const size_t spitch = (size_t)S * per_step * elem_bytes;
-        const char* src = static_cast<const char*>(src_base) + (size_t)step0 * per_step * elem_bytes;
-        return hipMemcpy2D(dst, width, src, spitch, width, Rl, hipMemcpyDeviceToHost);
+        const size_t dpitch = (size_t)nsteps * per_step * elem_bytes;
+        const size_t spitch = (size_t)cap * per_step * elem_bytes;
+        int done = 0;
+        while (done < nsteps) {
+            const int slot = (step0 + done) % cap;
+            const int n = std::min(nsteps - done, cap - slot);
+            const size_t width = (size_t)n * per_step * elem_bytes;
+            const char* src = static_cast<const char*>(src_base) + (size_t)slot * per_step * elem_bytes;
+            char* d = static_cast<char*>(dst) + (size_t)done * per_step * elem_bytes;
+            hipError_t e = hipMemcpy2D(d, dpitch, src, spitch, width, Rl, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return e;
+            done += n;
+        }
+        return hipSuccess;
     };
     HIP_TRY(copy2d(pos_w, h->d_pos_w, sizeof(float), P));
     HIP_TRY(copy2d(likeh, h->d_likeh, sizeof(float), 1));
@@ -604,6 +629,7 @@ int ptnn_get_traces(ptnn_handle* h, int step0, int nsteps, float* pos_w, float* 
     HIP_TRY(copy2d(acc_train, h->d_acc_tr, sizeof(float), 1));
     HIP_TRY(copy2d(acc_test, h->d_acc_te, sizeof(float), 1));
     HIP_TRY(copy2d(accept_count, h->d_accept, sizeof(int), 1));
+    h->drained = std::max(h->drained, step0 + nsteps - 1);
     return 0;
 }
 
@@ -723,14 +749,29 @@ int ptnn_debug_stamps(ptnn_handle* h, uint64_t* out16) {   // 160 entries: 16 ph
     return 0;
 }
 
-int ptnn_savetxt(const char* path, const double* data, int64_t rows, int64_t cols, const char* fmt) {
-    if (!path || !data || !fmt) return fail(-1, "null argument");
-    if (rows < 0 || cols < 1) return fail(-1, "bad shape %lld x %lld", (long long)rows, (long long)cols);
-    // exactly one floating conversion: % [flags] [width] [.precision] (e|E|f|F|g|G)
+// exactly one floating conversion: % [flags] [width] [.precision] (e|E|f|F|g|G)
+static bool float_format_ok(const char* fmt) {
     const size_t fl = std::strlen(fmt);
     bool ok = fl >= 2 && fl < 16 && fmt[0] == '%' && std::strchr("eEfFgG", fmt[fl - 1]) != nullptr;
     for (size_t k = 1; ok && k + 1 < fl; ++k) ok = std::strchr("0123456789.+- #", fmt[k]) != nullptr;
-    if (!ok) return fail(-1, "unsupported format '%s'", fmt);
+    return ok;
+}
+
+int ptnn_text_round(double* values, int64_t n, const char* fmt) {
+    if (!values || !fmt || n < 0) return fail(-1, "bad argument");
+    if (!float_format_ok(fmt)) return fail(-1, "unsupported format '%s'", fmt);
+    char buf[512];
+    for (int64_t k = 0; k < n; ++k) {
+        std::snprintf(buf, sizeof buf, fmt, values[k]);
+        values[k] = std::strtod(buf, nullptr);
+    }
+    return 0;
+}
+
+int ptnn_savetxt(const char* path, const double* data, int64_t rows, int64_t cols, const char* fmt) {
+    if (!path || !data || !fmt) return fail(-1, "null argument");
+    if (rows < 0 || cols < 1) return fail(-1, "bad shape %lld x %lld", (long long)rows, (long long)cols);
+    if (!float_format_ok(fmt)) return fail(-1, "unsupported format '%s'", fmt);
     FILE* f = std::fopen(path, "w");
     if (!f) return fail(-4, "cannot open %s for writing", path);
     std::vector<char> buf(1 << 20);

@@ -34,6 +34,7 @@ struct SegParams {
     int H, P, PS;            // hidden units, parameters, state row length (P + 1 rounded up to 4)
     int Ntr, Nte, IPY, FWS;  // rows, data row stride (floats), packed forward row stride (floats)
     int S, switch_step, use_lg;
+    int trace_cap;           // rows per replica in the trace rings
     int first_global;
     float l_prob, lr, step_w, step_eta;
     float inv_2sig2, prior_c, nu1, nu2;
@@ -597,7 +598,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
         nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT];
     }
 
-    const size_t trow = (size_t)r * p.S;
+    const size_t trow = (size_t)r * p.trace_cap;        // traces are rings of trace_cap rows per replica (== S unless streaming)
     for (int i = step_begin; i < step_begin + n_steps; ++i) {
         // R10 temperature schedule (REG:317-324): tempered until the switch step, canonical afterwards
         float adapttemp = (p.switch_step >= 0 && i >= p.switch_step) ? 1.0f : T;
@@ -671,15 +672,16 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
         }
         __syncthreads();
         // trace row i+1 (the only HBM traffic of a step)
-        float* prow = p.tr_pos_w + (trow + i + 1) * (size_t)P;
+        const size_t tpos = trow + (size_t)((i + 1) % p.trace_cap);
+        float* prow = p.tr_pos_w + tpos * (size_t)P;
         for (int j = tid; j < P; j += nthr) prow[j] = l.rec_w[j];
         if (tid == 0) {
-            p.tr_likeh[trow + i + 1] = (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp;   // REG:391 / CLS:404
-            p.tr_accept[trow + i + 1] = acc_before;                                            // REG:380
-            p.tr_rmse_tr[trow + i + 1] = rec_rmse_tr;
-            p.tr_rmse_te[trow + i + 1] = rec_rmse_te;
-            p.tr_acc_tr[trow + i + 1] = rec_acc_tr;
-            p.tr_acc_te[trow + i + 1] = rec_acc_te;
+            p.tr_likeh[tpos] = (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp;   // REG:391 / CLS:404
+            p.tr_accept[tpos] = acc_before;                                            // REG:380
+            p.tr_rmse_tr[tpos] = rec_rmse_tr;
+            p.tr_rmse_te[tpos] = rec_rmse_te;
+            p.tr_acc_tr[tpos] = rec_acc_tr;
+            p.tr_acc_te[tpos] = rec_acc_te;
         }
     }
 
@@ -837,7 +839,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
     const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-    const size_t trow = (size_t)r * p.S;
+    const size_t trow = (size_t)r * p.trace_cap;        // traces are rings of trace_cap rows per replica (== S unless streaming)
     const int end = step_begin + n_steps;
     int i = step_begin;
     unsigned epoch = p.epoch_base;
@@ -965,15 +967,16 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
         if (sidx < ncommit) {
             const bool acc_me = (sidx == m);
             const float* srcw = acc_me ? my_prop : rec_w;
-            float* prow = p.tr_pos_w + (trow + j + 1) * (size_t)P;
+            const size_t tpos = trow + (size_t)((j + 1) % p.trace_cap);
+            float* prow = p.tr_pos_w + tpos * (size_t)P;
             for (int e = lane; e < P; e += WAVE) prow[e] = srcw[e];
             if (lane == 0) {
-                p.tr_likeh[trow + j + 1] = (TASK == TASK_REG) ? sl[SL_LIKPROP] : sl[SL_LIKPROP] * sl[SL_ADAPT];
-                p.tr_accept[trow + j + 1] = nacc;                                   // count BEFORE this step (REG:380)
-                p.tr_rmse_tr[trow + j + 1] = acc_me ? sl[SL_RM_TR] : rec_rmse_tr;
-                p.tr_rmse_te[trow + j + 1] = acc_me ? sl[SL_RM_TE] : rec_rmse_te;
-                p.tr_acc_tr[trow + j + 1] = acc_me ? sl[SL_AC_TR] : rec_acc_tr;
-                p.tr_acc_te[trow + j + 1] = acc_me ? sl[SL_AC_TE] : rec_acc_te;
+                p.tr_likeh[tpos] = (TASK == TASK_REG) ? sl[SL_LIKPROP] : sl[SL_LIKPROP] * sl[SL_ADAPT];
+                p.tr_accept[tpos] = nacc;                                   // count BEFORE this step (REG:380)
+                p.tr_rmse_tr[tpos] = acc_me ? sl[SL_RM_TR] : rec_rmse_tr;
+                p.tr_rmse_te[tpos] = acc_me ? sl[SL_RM_TE] : rec_rmse_te;
+                p.tr_acc_tr[tpos] = acc_me ? sl[SL_AC_TR] : rec_acc_tr;
+                p.tr_acc_te[tpos] = acc_me ? sl[SL_AC_TE] : rec_acc_te;
             }
         }
         lg_count += __popcll(bal_lg & ((ncommit >= 64) ? ~0ull : ((1ull << ncommit) - 1ull)));
@@ -1182,7 +1185,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
         nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT];
     }
 
-    const size_t trow = (size_t)r * p.S;
+    const size_t trow = (size_t)r * p.trace_cap;        // traces are rings of trace_cap rows per replica (== S unless streaming)
     for (int i = step_begin; i < step_begin + n_steps; ++i) {
         const float adapttemp = (p.switch_step >= 0 && i >= p.switch_step) ? 1.0f : T;
         if (i == p.switch_step) {
@@ -1230,7 +1233,8 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
         const bool accept = u < mh;
         const int acc_before = nacc;
         __syncthreads();                                    // every reader of w_cur / w_gd of this step is done
-        float* prow = p.tr_pos_w + (trow + i + 1) * (size_t)P;
+        const size_t tpos = trow + (size_t)((i + 1) % p.trace_cap);
+        float* prow = p.tr_pos_w + tpos * (size_t)P;
         if (accept) {
             nacc += 1;
             lik = lik_prop; prior_cur = prior_prop; eta = eta_pro;
@@ -1245,12 +1249,12 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
             for (int j = tid; j < P; j += nthr) prow[j] = rec_w[j];
         }
         if (tid == 0) {
-            p.tr_likeh[trow + i + 1] = (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp;
-            p.tr_accept[trow + i + 1] = acc_before;
-            p.tr_rmse_tr[trow + i + 1] = rec_rmse_tr;
-            p.tr_rmse_te[trow + i + 1] = rec_rmse_te;
-            p.tr_acc_tr[trow + i + 1] = rec_acc_tr;
-            p.tr_acc_te[trow + i + 1] = rec_acc_te;
+            p.tr_likeh[tpos] = (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp;
+            p.tr_accept[tpos] = acc_before;
+            p.tr_rmse_tr[tpos] = rec_rmse_tr;
+            p.tr_rmse_te[tpos] = rec_rmse_te;
+            p.tr_acc_tr[tpos] = rec_acc_tr;
+            p.tr_acc_te[tpos] = rec_acc_te;
         }
         __syncthreads();
     }

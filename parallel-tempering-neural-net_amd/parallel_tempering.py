@@ -22,10 +22,9 @@ from . import _lib, ladder, philox
 TASK_REG, TASK_CLS = _lib.TASK_REG, _lib.TASK_CLS
 
 
-def _text_round(a, fmt):
+def _text_round(a, fmt, threads=8):
     """Values as np.loadtxt would read them back from np.savetxt(..., fmt=fmt) (show_results re-reads the files)."""
-    a = np.asarray(a, dtype=np.float64)
-    return np.char.mod(fmt, a.reshape(-1)).astype(np.float64).reshape(a.shape)
+    return _lib.text_round(a, fmt, threads)
 
 
 class ParallelTemperingBase:
@@ -34,7 +33,7 @@ class ParallelTemperingBase:
 
     def __init__(self, use_langevin_gradients, learn_rate, traindata, testdata, topology, num_chains, maxtemp,
                  NumSample, swap_interval, langevin_prob, path, *, seed=None, device=None, waves_per_replica=0,
-                 schedule=0, groups_per_replica=0, write_files=True, io_threads=None):
+                 schedule=0, groups_per_replica=0, trace_capacity=0, write_files=True, io_threads=None):
         # FNN chain variables (REG:491-494)
         self.traindata = traindata
         self.testdata = testdata
@@ -63,6 +62,7 @@ class ParallelTemperingBase:
         self.waves_per_replica = int(waves_per_replica)
         self.schedule = int(schedule)            # 0 auto, 1 cooperative, 2 speculative (include/ptnn.h)
         self.groups_per_replica = int(groups_per_replica)
+        self.trace_capacity = int(trace_capacity)   # rows per replica kept in HBM (0 = all); smaller = streamed to the host
         self.write_files = bool(write_files)
         self.io_threads = io_threads or min(16, os.cpu_count() or 1)
         self.timings = {}
@@ -129,7 +129,7 @@ class ParallelTemperingBase:
             n_replicas_local=self.num_chains, n_replicas_global=self.num_chains, first_global_replica=0,
             n_samples=S, swap_interval=int(self.swap_interval), pt_switch_step=self._pt_switch_step(),
             use_langevin=1 if self.use_langevin_gradients is True else 0, waves_per_replica=self.waves_per_replica,
-            schedule=self.schedule, groups_per_replica=self.groups_per_replica,
+            schedule=self.schedule, groups_per_replica=self.groups_per_replica, trace_capacity=self.trace_capacity,
             l_prob=float(self.langevin_prob), learn_rate=float(self.learn_rate), step_w=0.025, step_eta=0.2,
             sigma_squared=25.0, nu_1=0.0, nu_2=0.0, seed=self.seed)
         self._sampler.set_data(train, test)
@@ -142,12 +142,31 @@ class ParallelTemperingBase:
         S = self.NumSamples
         open(self.path + '/num_exchange.txt', 'a').close()                      # REG:704: opened, never written
         t0 = time.perf_counter()
-        self._sampler.run(-1)
-        self._sampler.sync()
-        t1 = time.perf_counter()
-        self.num_swap, self.total_swap_proposals, self.rounds = self._sampler.swap_stats()
-        tr = self._sampler.traces()
-        t2 = time.perf_counter()
+        cap = self.trace_capacity
+        if cap and cap < S:
+            # streaming: the device keeps a ring of `cap` trace rows per replica; drain it every cap - 1 steps
+            parts, row, t_fetch = [], 0, 0.0
+            while self._sampler.steps_done() < S - 1:
+                self._sampler.run(min(cap - 1, S - 1 - self._sampler.steps_done()))
+                self._sampler.sync()
+                tf = time.perf_counter()
+                hi = self._sampler.steps_done() + 1
+                parts.append(self._sampler.traces(row, hi - row))
+                row = hi
+                t_fetch += time.perf_counter() - tf
+            self._sampler.run(-1)                                               # phantom round, if due
+            self._sampler.sync()
+            tr = {k: np.concatenate([p[k] for p in parts], axis=1) for k in parts[0]}
+            t1 = time.perf_counter() - t_fetch
+            t2 = t1 + t_fetch
+            self.num_swap, self.total_swap_proposals, self.rounds = self._sampler.swap_stats()
+        else:
+            self._sampler.run(-1)
+            self._sampler.sync()
+            t1 = time.perf_counter()
+            self.num_swap, self.total_swap_proposals, self.rounds = self._sampler.swap_stats()
+            tr = self._sampler.traces()
+            t2 = time.perf_counter()
         if self.write_files:
             self._write_chain_files(tr)
         t3 = time.perf_counter()

@@ -130,3 +130,10 @@ def test_experiment_drivers(tmp_path):
     row = open(out["path_db"] + "/result.txt").read().split()
     assert len(row) == 15 and row[0] == "3.00" and row[2] == "10.00" and row[3] == "20.00"
     assert 0.0 <= float(row[6]) <= 100.0 and 0.0 <= float(row[12]) <= 100.0
+
+
+def test_streaming_run_chains_equals_resident(tmp_path):
+    a = _run("reg", tmp_path / "a")[2] if os.makedirs(tmp_path / "a") is None else None
+    b = _run("reg", tmp_path / "b", trace_capacity=17)[2] if os.makedirs(tmp_path / "b") is None else None
+    for x, y in zip(a, b):
+        assert np.array_equal(np.asarray(x), np.asarray(y))

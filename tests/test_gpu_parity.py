@@ -429,3 +429,45 @@ def test_config5_shape_against_oracle():
     np.testing.assert_allclose(s.langevin_gradient(w)[0], orc.langevin_gradient(train, w.astype(np.float64), topo, 0.1, 0),
                                rtol=2e-4, atol=5e-5)
     s.close()
+
+
+@pytest.mark.parametrize("schedule", [1, 2])
+def test_trace_ring_streaming_equals_full_traces(schedule):
+    """trace_capacity < S keeps only a ring of rows in HBM; draining it in windows must give exactly the full traces, and
+    running past an undrained ring must be refused."""
+    d = ds()
+    R, S, si, cap = 8, 257, 10, 40
+    tape = orc.PhiloxTape(3)
+    w0 = np.stack([tape.w_init(r, 31) for r in range(R)]).astype(np.float32)
+    T = np.array(orc.temperature_ladder(R, 2), dtype=np.float32)
+    full = parity.make_sampler(0, (4, 5, 1), d["sunspot_train"], d["sunspot_test"], R_local=R, R_global=R, first=0, S=S, si=si,
+                               use_lg=True, lr=0.1, seed=3, schedule=schedule)
+    full.set_state(w0, T)
+    full.run(-1)
+    full.sync()
+    ref = full.traces()
+    ring = parity.make_sampler(0, (4, 5, 1), d["sunspot_train"], d["sunspot_test"], R_local=R, R_global=R, first=0, S=S, si=si,
+                               use_lg=True, lr=0.1, seed=3, schedule=schedule, trace_capacity=cap)
+    ring.set_state(w0, T)
+    from ptnn_amd import PtnnError
+    with pytest.raises(PtnnError):
+        ring.run(cap)                                # cap steps would overwrite row 0 before it was fetched
+    parts, row = [], 0
+    chunks = [cap - 1, 7, cap - 1, 1, cap - 1]
+    k = 0
+    while ring.steps_done() < S - 1:
+        ring.run(min(chunks[k % len(chunks)], S - 1 - ring.steps_done()))
+        k += 1
+        ring.sync()
+        hi = ring.steps_done() + 1
+        parts.append(ring.traces(row, hi - row))
+        row = hi
+    ring.run(-1)                                     # phantom round bookkeeping (no steps left)
+    ring.sync()
+    got = {k: np.concatenate([p[k] for p in parts], axis=1) for k in parts[0]}
+    for k in ref:
+        assert got[k].shape == ref[k].shape and (got[k] == ref[k]).all(), k
+    with pytest.raises(PtnnError):
+        ring.traces(0, 10)                           # long gone from the ring
+    assert ring.swap_stats()[:2] == full.swap_stats()[:2]
+    full.close(); ring.close()

@@ -123,7 +123,8 @@ def test_host_class_surface(pt):
 
 def test_text_round_is_the_file_round_trip(pt, tmp_path):
     from ptnn_amd.parallel_tempering import _text_round
-    a = np.random.default_rng(0).normal(size=(4, 50)) * 3
+    a = np.random.default_rng(0).normal(size=(4, 5000)) * 3
+    a[0, :9] = [0.005, 0.015, 0.025, 2.675, -0.125, 1e-9, -1e-9, 123456.789, 0.0]
     for fmt in ("%1.8f", "%1.2f", "%1.4f"):
         f = tmp_path / "x.txt"
         np.savetxt(f, a, fmt=fmt)
