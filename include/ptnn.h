@@ -53,6 +53,8 @@ typedef struct ptnn_config {
                                    * (as many of 1, 2, 4 as keeps replicas x groups <= number of CUs) */
     int32_t trace_capacity;       /* rows per replica kept on the device (ring); 0 = all n_samples rows.  With a smaller
                                    * value the caller drains with ptnn_get_traces at least every trace_capacity steps */
+    int32_t forward_bf16;         /* wide nets (n_hidden > 64, multiple of 32): 1 = forward-pass GEMM operands rounded to
+                                   * bf16 with fp32 accumulation (v_mfma_f32_32x32x16_bf16), 0 = exact fp32 MFMA */
     float l_prob;                 /* langevin_prob (REG:174); CLS fixes 0.5 (CLS:192) */
     float learn_rate;             /* SGD step of langevin_gradient (REG:33) */
     float step_w;                 /* 0.025 (REG:258) */

@@ -86,6 +86,8 @@ struct ptnn_handle {
     bool speculative = false;
     bool wide = false;              // 64 < H: vectors in HBM, one thread per hidden unit
     float* d_wide_scratch = nullptr;
+    float* d_xt = nullptr;          // transposed data image for the MFMA forward pass
+    int Npad = 0;
     int groups = 1;                 // work-groups (CUs) per replica in the speculative schedule
     unsigned epoch_base = 0;
     int num_cus = 0;
@@ -140,7 +142,7 @@ struct ptnn_handle {
         p.L_handoff = d_L_handoff; p.L_final = d_L_final;
         p.tr_pos_w = d_pos_w; p.tr_likeh = d_likeh; p.tr_rmse_tr = d_rmse_tr; p.tr_rmse_te = d_rmse_te;
         p.tr_acc_tr = d_acc_tr; p.tr_acc_te = d_acc_te; p.tr_accept = d_accept;
-        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch;
+        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.xt = d_xt; p.Npad = Npad; p.forward_bf16 = cfg.forward_bf16;
         return p;
     }
 };
@@ -322,7 +324,7 @@ int ptnn_destroy(ptnn_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_data, h->d_state[0], h->d_state[1], h->d_rec_w, h->d_gd_w[0], h->d_gd_w[1], h->d_gd_valid[0], h->d_gd_valid[1], h->d_st_f, h->d_st_i, h->d_temps,
                     h->d_L_handoff, h->d_L_final, h->d_pos_w, h->d_likeh, h->d_rmse_tr, h->d_rmse_te, h->d_acc_tr,
-                    h->d_acc_te, h->d_accept, h->d_src, h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_stamps, h->d_wide_scratch};
+                    h->d_acc_te, h->d_accept, h->d_src, h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_stamps, h->d_wide_scratch, h->d_xt};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& ev : h->timing) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -352,7 +354,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
     const int H = h->cfg.n_hidden;
     if (H > WAVE) {
         // wide net: one thread per hidden unit, vectors in HBM, only the packed forward image + scratch in LDS
-        const size_t lds = wide_lds_floats(H, h->FWS, h->cfg.n_out) * sizeof(float);
+        const size_t lds = wide_lds_floats(H, h->FWS, h->cfg.n_out, h->PS) * sizeof(float);
         if (lds > 160 * 1024) return fail(-3, "wide net needs %zu B of LDS (> 160 KiB)", lds);
         if (h->cfg.schedule == PTNN_SCHED_SPECULATIVE) return fail(-3, "the speculative schedule is built for n_hidden <= 64");
         h->wide = true; h->speculative = false; h->groups = 1;
@@ -364,6 +366,16 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         HIP_TRY(hipMalloc(&h->d_data, packed.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(h->d_data, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
         if (!h->d_wide_scratch) HIP_TRY(hipMalloc(&h->d_wide_scratch, (size_t)h->cfg.n_replicas_local * 3 * h->PS * sizeof(float)));
+        // transposed image Xt[k][Npad] for the MFMA forward pass (rows = data rows are the lanes of the B operand)
+        h->Npad = (Nall + 31) & ~31;
+        {
+            std::vector<float> xt((size_t)I * h->Npad, 0.0f);
+            for (int n = 0; n < Nall; ++n)
+                for (int k = 0; k < I; ++k) xt[(size_t)k * h->Npad + n] = packed[(size_t)n * IPY + k];
+            if (h->d_xt) { HIP_TRY(hipFree(h->d_xt)); h->d_xt = nullptr; }
+            HIP_TRY(hipMalloc(&h->d_xt, xt.size() * sizeof(float)));
+            HIP_TRY(hipMemcpy(h->d_xt, xt.data(), xt.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         if (lds > 64 * 1024) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->shape->seg_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->shape->model_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -61,6 +61,9 @@ struct SegParams {
     int* error_flag;         // != 0 after a launch: a bounded spin expired
     unsigned long long* stamps;   // diagnostic build only (PTNN_STAMPS): cycle sums per phase, else unused
     float* wide_scratch;     // [Rl][3][PS] proposal, its SGD epoch, noise (wide nets only: these do not fit in LDS)
+    const float* xt;         // wide nets: transposed data image Xt[k][Npad] (B operand of the MFMA forward pass), or null
+    int Npad;                // rows of Xt, Nall rounded up to 32
+    int forward_bf16;        // 1: forward GEMM operands rounded to bf16 (fp32 accumulate); 0: exact fp32 MFMA
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1062,8 +1065,12 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
 // the proposal and the reduction scratch; the data set is read through the scalar cache (wave-uniform rows) in the sweep
 // and through L2 in the forward pass.  Cooperative schedule only.
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ inline size_t wide_lds_floats(int H, int FWS, int O) {
-    return (size_t)(H + 1) * FWS + MAX_WAVES * 8 + 2 * MAX_WAVES * (size_t)((O + 3) & ~3) + 16;
+__host__ __device__ inline size_t wide_lds_floats(int H, int FWS, int O, int PS) {
+    const size_t img = ((size_t)(H + 1) * FWS > (size_t)PS) ? (size_t)(H + 1) * FWS : (size_t)PS;   // packed or flat image
+    return img + MAX_WAVES * 8 + 2 * MAX_WAVES * (size_t)((O + 3) & ~3) + 16;
+}
+__host__ __device__ inline size_t wide_img_floats(int H, int FWS, int PS) {
+    return ((size_t)(H + 1) * FWS > (size_t)PS) ? (size_t)(H + 1) * FWS : (size_t)PS;
 }
 
 // R5 for H > 64: thread h owns hidden unit h; the output pre-activation is a two-level sum (DPP inside the wave, then the
@@ -1145,6 +1152,173 @@ __device__ __forceinline__ void sgd_sweep_wide(const float* __restrict__ w_in, f
     __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------
+// R2/R3/R6 for wide nets on the matrix cores.  The product is taken transposed, Z^T[h][n] = sum_i W1[i][h] X[n][i], so
+// that in the 32x32 accumulator tile a LANE is a data row (column n = lane & 31) and the 16 REGISTERS are hidden units
+// (h = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)): bias, sigmoid and the product with W2 are applied in place and the sum
+// over hidden units stays in the lane across all H/32 tiles; one v_permlane32_swap at the end joins the two lane halves.
+// Operands: A[h][k] = W1[k][h] is read from the flat copy of w in LDS (lanes = consecutive h: conflict-free), B[k][n] from
+// the transposed data image Xt[k][n] in L2 (lanes = consecutive rows: coalesced), 2 k-values per v_mfma_f32_32x32x2_f32
+// (exact fp32, k-ordered fma chain) or 16 per v_mfma_f32_32x32x16_bf16 (BF16 = true: operands rounded to bf16,
+// fp32 accumulation; the tolerance study of BASELINE config 5).  Needs H % 32 == 0; I is zero-padded to IK.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ short f32_to_bf16(float f) {            // round to nearest even; inputs are finite
+    const unsigned u = __builtin_bit_cast(unsigned, f);
+    return (short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <int TASK, int I, int O, bool BF16>
+__device__ __forceinline__ EvalSums eval_rows_mfma(const float* __restrict__ wl, const float* __restrict__ xt,
+                                                   const float* __restrict__ data, int IPY, int H, int Ntr, int Nall,
+                                                   int Npad, float* __restrict__ red) {
+    constexpr int IK = BF16 ? ((I + 15) & ~15) : ((I + 1) & ~1);      // k extent actually multiplied
+    constexpr int KS = BF16 ? IK / 16 : IK / 2;                        // MFMA instructions per tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
+    float a_tr = 0.f, b_tr = 0.f, c_tr = 0.f, a_te = 0.f, b_te = 0.f, c_te = 0.f;
+    float b2[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) b2[o] = wl[oB2 + o];
+    const int ntiles = H >> 5;
+    for (int rb = wave; rb * 32 < Nall; rb += nw) {
+        const int n = rb * 32 + col;                                   // this lane's data row
+        // B fragments of this row block stay in registers for all hidden tiles
+        float bf[BF16 ? 1 : KS];
+        bf16x8 bh[BF16 ? KS : 1];
+        if (BF16) {
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * s_ + 8 * half + j;
+                    bh[s_][j] = (k < I) ? f32_to_bf16(xt[(size_t)k * Npad + n]) : (short)0;
+                }
+        } else {
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {
+                const int k = 2 * s_ + half;
+                bf[s_] = (k < I) ? xt[(size_t)k * Npad + n] : 0.0f;
+            }
+        }
+        float sum[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) sum[o] = 0.0f;
+        for (int t = 0; t < ntiles; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r_ = 0; r_ < 16; ++r_) acc[r_] = 0.0f;
+            const int hbase = t * 32;
+            if (BF16) {
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    bf16x8 ah;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 16 * s_ + 8 * half + j;
+                        ah[j] = (k < I) ? f32_to_bf16(wl[k * H + hbase + col]) : (short)0;
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s_], acc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int s_ = 0; s_ < KS; ++s_) {
+                    const int k = 2 * s_ + half;
+                    const float a = (k < I) ? wl[k * H + hbase + col] : 0.0f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[s_], acc, 0, 0, 0);
+                }
+            }
+            // epilogue in place: register r_ is hidden unit hbase + (r_ & 3) + 8 (r_ >> 2) + 4 half
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int h0 = hbase + 8 * q + 4 * half;
+                const float4 b1v = *reinterpret_cast<const float4*>(wl + oB1 + h0);
+                const float b1a[4] = {b1v.x, b1v.y, b1v.z, b1v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float hid = sigmoidf_fast(acc[4 * q + e] - b1a[e]);
+#pragma unroll
+                    for (int o = 0; o < O; ++o) sum[o] = fmaf(hid, wl[oW2 + (h0 + e) * O + o], sum[o]);
+                }
+            }
+        }
+        // join the two lane halves (hidden units 4..7, 12..15, ... live in lanes 32..63)
+        float tot[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            const unsigned u = __builtin_bit_cast(unsigned, sum[o]);
+            auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            tot[o] = __builtin_bit_cast(float, (unsigned)r2[0]) + __builtin_bit_cast(float, (unsigned)r2[1]) - b2[o];
+        }
+        if (half == 0 && n < Nall) {
+            const float y = data[(size_t)n * IPY + I];
+            float a, bb = 0.f, c = 0.f;
+            if (TASK == TASK_REG) {
+                const float d = y - sigmoidf_fast(tot[0]);
+                a = d * d;
+            } else {
+                ArgKey best = argmax_key(tot[0]);
+                float se = 0.0f, oy = 0.0f;
+                int arg = 0;
+                const int yi = (int)y;
+#pragma unroll
+                for (int o = 0; o < O; ++o) {
+                    const float out = sigmoidf_fast(tot[o]);
+                    const ArgKey key = argmax_key(tot[o]);
+                    if (argkey_greater(key, best)) { best = key; arg = o; }
+                    se += expf_fast(out);
+                    oy = (o == yi) ? out : oy;
+                }
+                a = oy - logf_fast(se);
+                const float dd = (float)arg - y;
+                bb = dd * dd;
+                c = ((float)arg == y) ? 1.0f : 0.0f;
+            }
+            if (n < Ntr) { a_tr += a; b_tr += bb; c_tr += c; }
+            else { a_te += a; b_te += bb; c_te += c; }
+        }
+    }
+    a_tr = wave_allsum(a_tr);
+    a_te = wave_allsum(a_te);
+    if (TASK == TASK_CLS) {
+        b_tr = wave_allsum(b_tr); c_tr = wave_allsum(c_tr);
+        b_te = wave_allsum(b_te); c_te = wave_allsum(c_te);
+    }
+    EvalSums s;
+    __syncthreads();
+    if (lane == 0) {
+        float* r = red + wave * 8;
+        r[0] = a_tr; r[1] = b_tr; r[2] = c_tr; r[3] = a_te; r[4] = b_te; r[5] = c_te;
+    }
+    __syncthreads();
+    s.a_tr = s.b_tr = s.c_tr = s.a_te = s.b_te = s.c_te = 0.f;
+    for (int k = 0; k < nw; ++k) {
+        const float* r = red + k * 8;
+        s.a_tr += r[0]; s.b_tr += r[1]; s.c_tr += r[2]; s.a_te += r[3]; s.b_te += r[4]; s.c_te += r[5];
+    }
+    return s;
+}
+
+// forward pass of a wide net under weight vector w (global): MFMA when the hidden layer tiles (H % 32 == 0), else the
+// lane-per-row VALU path on the packed image.  `img` is the LDS image area (max of both layouts).
+template <int TASK, int I, int O>
+__device__ __forceinline__ EvalSums wide_forward(const SegParams& p, const float* __restrict__ w, float* __restrict__ img,
+                                                 float* __restrict__ red) {
+    const int Nall = p.Ntr + p.Nte;
+    if ((p.H & 31) == 0 && p.xt != nullptr) {
+        for (int j = threadIdx.x; j < p.P; j += blockDim.x) img[j] = w[j];        // flat copy: the layout IS [k][h]
+        __syncthreads();
+        if (p.forward_bf16) return eval_rows_mfma<TASK, I, O, true>(img, p.xt, p.data, p.IPY, p.H, p.Ntr, Nall, p.Npad, red);
+        return eval_rows_mfma<TASK, I, O, false>(img, p.xt, p.data, p.IPY, p.H, p.Ntr, Nall, p.Npad, red);
+    }
+    build_fw<I, O>(w, img, p.H, p.FWS);
+    __syncthreads();
+    return eval_rows<TASK, I, O>(img, p.data, p.IPY, p.FWS, p.H, p.Ntr, Nall, red);
+}
+
 template <int TASK, int I, int O>
 __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegParams p, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1155,7 +1329,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
     const int Nall = p.Ntr + p.Nte;
     const int P = p.P, PS = p.PS, H = p.H;
     float* fw = smem;
-    float* red = fw + (size_t)(H + 1) * p.FWS;
+    float* red = fw + wide_img_floats(H, p.FWS, PS);
     float* part = red + MAX_WAVES * 8;
     float* scal = part + 2 * MAX_WAVES * OP;
     const float* xy = p.data;                                   // global (L2 / scalar cache)
@@ -1189,9 +1363,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
     for (int i = step_begin; i < step_begin + n_steps; ++i) {
         const float adapttemp = (p.switch_step >= 0 && i >= p.switch_step) ? 1.0f : T;
         if (i == p.switch_step) {
-            build_fw<I, O>(w_cur, fw, H, p.FWS);
-            __syncthreads();
-            const EvalSums sc = eval_rows<TASK, I, O>(fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, red);
+            const EvalSums sc = wide_forward<TASK, I, O>(p, w_cur, fw, red);
             float ll, r1, r2, a1, a2;
             finish_eval<TASK>(sc, p.Ntr, p.Nte, tau_eta_last, ll, r1, r2, a1, a2);
             lik = ll;
@@ -1220,9 +1392,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
         }
         float eta_pro = eta;
         if (TASK == TASK_REG) { eta_pro = fmaf(p.step_eta, n_eta, eta); tau_eta_last = eta_pro; }
-        build_fw<I, O>(w_prop, fw, H, p.FWS);
-        __syncthreads();
-        const EvalSums es = eval_rows<TASK, I, O>(fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, red);
+        const EvalSums es = wide_forward<TASK, I, O>(p, w_prop, fw, red);
         float ll, rm_tr, rm_te, ac_tr, ac_te;
         finish_eval<TASK>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
         const float lik_prop = ll / adapttemp;
@@ -1280,7 +1450,7 @@ __global__ void __launch_bounds__(MAX_THREADS) model_wide_kernel(const SegParams
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const int Nall = p.Ntr + p.Nte;
     float* fw = smem;
-    float* red = fw + (size_t)(p.H + 1) * p.FWS;
+    float* red = fw + wide_img_floats(p.H, p.FWS, p.PS);
     float* part = red + MAX_WAVES * 8;
     float* scal = part + 2 * MAX_WAVES * OP;
     if (mode == 2) {
@@ -1294,9 +1464,7 @@ __global__ void __launch_bounds__(MAX_THREADS) model_wide_kernel(const SegParams
         sgd_sweep_wide<TASK, I, O>(w, out + (size_t)b * p.P, p.data, p.IPY, p.Ntr, p.H, p.lr, part);
         return;
     }
-    build_fw<I, O>(w, fw, p.H, p.FWS);
-    __syncthreads();
-    const EvalSums s = eval_rows<TASK, I, O>(fw, p.data, p.IPY, p.FWS, p.H, p.Ntr, Nall, red);
+    const EvalSums s = wide_forward<TASK, I, O>(p, w, fw, red);
     const float eta = (TASK == TASK_REG) ? logf_fast(tau_sq[b]) : 0.0f;
     float ll, r1, r2, a_tr, a_te;
     finish_eval<TASK>(s, p.Ntr, p.Nte, eta, ll, r1, r2, a_tr, a_te);
