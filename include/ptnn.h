@@ -111,6 +111,10 @@ int ptnn_state_row_floats(ptnn_handle *h);
  * received into next_row before this call. */
 int ptnn_swap_apply(ptnn_handle *h, const int32_t *src_host, int phantom);
 
+/* the HIP stream (hipStream_t) all of this handle's work is queued on: lets the caller order its collectives after the
+ * segment / before the swap kernels on the device instead of synchronising the host */
+int ptnn_stream(ptnn_handle *h, void **hip_stream);
+
 /* ---- results ---- */
 /* traces of rows [step0, step0+nsteps) for all local replicas (row i+1 is written by MH step i; the rows must still be in
  * the ring: step0 >= steps_done + 1 - trace_capacity); any pointer may be NULL.

@@ -54,6 +54,7 @@ SYMBOLS = {
     "ptnn_swap_cascade": (C.c_int, [C.c_void_p, C.c_int, _ip]),
     "ptnn_swap_row_ptr": (C.c_int, [C.c_void_p, C.c_int, _vpp, _vpp]),
     "ptnn_state_row_floats": (C.c_int, [C.c_void_p]),
+    "ptnn_stream": (C.c_int, [C.c_void_p, _vpp]),
     "ptnn_swap_apply": (C.c_int, [C.c_void_p, _ip, C.c_int]),
     "ptnn_get_traces": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _ip]),
     "ptnn_get_swap_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _ip]),
@@ -176,6 +177,11 @@ class Sampler:
         a, b = C.c_void_p(), C.c_void_p()
         self._check(self.lib.ptnn_swap_row_ptr(self.h, int(local_replica), C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def stream_ptr(self):
+        p = C.c_void_p()
+        self._check(self.lib.ptnn_stream(self.h, C.byref(p)))
+        return p.value
 
     def state_row_floats(self):
         return self.lib.ptnn_state_row_floats(self.h)

@@ -588,6 +588,12 @@ int ptnn_swap_cascade(ptnn_handle* h, int phantom, int32_t* src_host) {
 
 int ptnn_state_row_floats(ptnn_handle* h) { return h ? h->PS : -1; }
 
+int ptnn_stream(ptnn_handle* h, void** hip_stream) {
+    if (!h || !hip_stream) return fail(-1, "null argument");
+    *hip_stream = reinterpret_cast<void*>(h->stream);
+    return 0;
+}
+
 int ptnn_swap_row_ptr(ptnn_handle* h, int local_replica, void** cur_row, void** next_row) {
     if (!h) return fail(-1, "null handle");
     if (local_replica < 0 || local_replica >= h->cfg.n_replicas_local) return fail(-1, "replica %d out of range", local_replica);

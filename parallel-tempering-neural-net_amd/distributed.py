@@ -30,6 +30,12 @@ class DeviceShard:
         self.first = sampler.cfg.first_global_replica
         self.S = sampler.S
         self.PS = sampler.state_row_floats()
+        # stream-ordered mode: collectives are issued on the library's own HIP stream (as a torch ExternalStream), so the
+        # segment kernel -> all-gather -> cascade -> row exchange -> apply chain is ordered on the device and the host only
+        # waits once per round for the 4 R-byte permutation.  Opt-in (PTNN_DIST_STREAM=1) until measured on several GPUs.
+        import os
+        self.stream_ordered = os.environ.get("PTNN_DIST_STREAM", "0") == "1"
+        self.ext_stream = torch.cuda.ExternalStream(sampler.stream_ptr(), device=self.dev) if self.stream_ordered else None
 
     def _view(self, ptr, n):
         class _Arr:            # __cuda_array_interface__ v2: zero-copy view of library-owned HBM
@@ -42,10 +48,18 @@ class DeviceShard:
         return self.s.run_segment()
 
     def sync(self):
-        self.s.sync()
+        if not self.stream_ordered:
+            self.s.sync()
 
     def fence_collectives(self):
-        self.torch.cuda.synchronize(self.dev)
+        if not self.stream_ordered:
+            self.torch.cuda.synchronize(self.dev)
+
+    def collective_context(self):
+        if self.stream_ordered:
+            return self.torch.cuda.stream(self.ext_stream)
+        import contextlib
+        return contextlib.nullcontext()
 
     def steps_done(self):
         return self.s.steps_done()
@@ -92,12 +106,15 @@ class ShardedLadder:
         self.bytes_moved = 0
 
     def swap_round(self, phantom):
+        import contextlib
         sh, dist = self.shard, self.dist
+        ctx = sh.collective_context() if hasattr(sh, "collective_context") else contextlib.nullcontext()
         sh.sync()                                           # L of the local block is written
         L = sh.L_tensor(phantom)
         Rl = sh.R_local
-        mine = L[self.rank * Rl:(self.rank + 1) * Rl].clone()
-        dist.all_gather(list(L.split(Rl)), mine)            # 4 R bytes, latency-bound
+        with ctx:
+            mine = L[self.rank * Rl:(self.rank + 1) * Rl].clone()
+            dist.all_gather(list(L.split(Rl)), mine)        # 4 R bytes, latency-bound
         if hasattr(sh, "fence_collectives"):
             sh.fence_collectives()
         src = sh.swap_cascade(phantom)                      # identical on every rank
@@ -109,8 +126,9 @@ class ShardedLadder:
             for local, peer in sends:
                 ops.append(dist.P2POp(dist.isend, sh.row_tensors(local)[0], peer))
             if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
+                with ctx:
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
                 if hasattr(sh, "fence_collectives"):
                     sh.fence_collectives()
                 self.bytes_moved += 4 * sh.PS * len(ops)
