@@ -127,9 +127,10 @@ int ptnn_get_swap_stats(ptnn_handle *h, int64_t *num_swap, int64_t *total_propos
 /* src permutation of every completed round, [rounds, R_global] (tests) */
 int ptnn_get_swap_log(ptnn_handle *h, int32_t *src, int max_rounds);
 /* current chain state per local replica: w [R,P], eta [R], likelihood [R] (tempered, possibly stale: Q12),
- * prior_current [R], num_accepted [R], langevin_count [R]; any pointer may be NULL */
+ * prior_current [R], num_accepted [R], langevin_count [R] (Langevin steps proposed, REG:347), langevin_accepted [R]
+ * (of those, accepted; speculative schedule only); any pointer may be NULL */
 int ptnn_get_state(ptnn_handle *h, float *w, float *eta, float *likelihood, float *prior, int32_t *num_accepted,
-                   int32_t *langevin_count);
+                   int32_t *langevin_count, int32_t *langevin_accepted);
 
 /* ---- the model functions on their own (same device code as the sampler) ---- */
 /* Network.evaluate_proposal + likelihood_func + prior_likelihood for n weight vectors w [n,P] (REG:120-134, 200-221;

@@ -59,7 +59,7 @@ SYMBOLS = {
     "ptnn_get_traces": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _ip]),
     "ptnn_get_swap_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _ip]),
     "ptnn_get_swap_log": (C.c_int, [C.c_void_p, _ip, C.c_int]),
-    "ptnn_get_state": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _ip, _ip]),
+    "ptnn_get_state": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _ip, _ip, _ip]),
     "ptnn_evaluate": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, _fp]),
     "ptnn_langevin_gradient": (C.c_int, [C.c_void_p, _fp, C.c_int, _fp]),
     "ptnn_tape": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp]),
@@ -219,9 +219,10 @@ class Sampler:
     def state(self):
         w = np.empty((self.R, self.P), np.float32)
         eta, lik, pri = (np.empty(self.R, np.float32) for _ in range(3))
-        nacc, lg = np.empty(self.R, np.int32), np.empty(self.R, np.int32)
-        self._check(self.lib.ptnn_get_state(self.h, _ptr(w), _ptr(eta), _ptr(lik), _ptr(pri), _ptr(nacc, _ip), _ptr(lg, _ip)))
-        return dict(w=w, eta=eta, likelihood=lik, prior=pri, num_accepted=nacc, langevin_count=lg)
+        nacc, lg, lga = (np.zeros(self.R, np.int32) for _ in range(3))
+        self._check(self.lib.ptnn_get_state(self.h, _ptr(w), _ptr(eta), _ptr(lik), _ptr(pri), _ptr(nacc, _ip), _ptr(lg, _ip),
+                                            _ptr(lga, _ip)))
+        return dict(w=w, eta=eta, likelihood=lik, prior=pri, num_accepted=nacc, langevin_count=lg, langevin_accepted=lga)
 
     def evaluate(self, w, tau_sq=None):
         w = _f32(np.atleast_2d(w))

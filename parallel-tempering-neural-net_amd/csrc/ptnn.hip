@@ -673,7 +673,7 @@ int ptnn_get_swap_log(ptnn_handle* h, int32_t* src, int max_rounds) {
 }
 
 int ptnn_get_state(ptnn_handle* h, float* w, float* eta, float* likelihood, float* prior, int32_t* num_accepted,
-                   int32_t* langevin_count) {
+                   int32_t* langevin_count, int32_t* langevin_accepted) {
     if (int rc = check_ready(h)) return rc;
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -690,6 +690,7 @@ int ptnn_get_state(ptnn_handle* h, float* w, float* eta, float* likelihood, floa
         if (prior) prior[r] = sf[(size_t)r * SF_COUNT + SF_PRIOR];
         if (num_accepted) num_accepted[r] = si[(size_t)r * SI_COUNT + SI_NACC];
         if (langevin_count) langevin_count[r] = si[(size_t)r * SI_COUNT + SI_LG_COUNT];
+        if (langevin_accepted) langevin_accepted[r] = si[(size_t)r * SI_COUNT + SI_LG_ACC];
     }
     return 0;
 }

@@ -28,7 +28,7 @@ constexpr uint32_t STREAM_STEP = 0, STREAM_WNOISE = 1, STREAM_SWAP = 2, STREAM_I
 
 // per-replica float state (st_f) and int state (st_i) slots
 enum { SF_LIK = 0, SF_PRIOR, SF_TAU_LAST, SF_REC_RMSE_TR, SF_REC_RMSE_TE, SF_REC_ACC_TR, SF_REC_ACC_TE, SF_COUNT = 8 };
-enum { SI_NACC = 0, SI_GD_VALID, SI_LG_COUNT, SI_COUNT = 4 };
+enum { SI_NACC = 0, SI_GD_VALID, SI_LG_COUNT, SI_LG_ACC, SI_COUNT = 4 };   // SI_LG_ACC: accepted Langevin steps
 
 struct SegParams {
     int H, P, PS;            // hidden units, parameters, state row length (P + 1 rounded up to 4)
@@ -813,8 +813,9 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
     float* sf = p.st_f + (size_t)r * SF_COUNT;
     int* si = p.st_i + (size_t)r * SI_COUNT;
     float lik, prior_cur, tau_eta_last, rec_rmse_tr, rec_rmse_te, rec_acc_tr, rec_acc_te;
-    int nacc, gd_valid, lg_count;
+    int nacc, gd_valid, lg_count, lg_acc;
     if (step_begin == 0) {
+        lg_acc = 0;
         if (wave == 0) {                                       // one wave alone: independent of wave and group count
             chain_startup<TASK, I, O, true>(p, xy, w_cur, my_fw, red, T, eta, lik, prior_cur);
             if (lane == 0) { red[0] = eta; red[1] = lik; red[2] = prior_cur; }
@@ -829,7 +830,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
         lik = sf[SF_LIK]; prior_cur = sf[SF_PRIOR]; tau_eta_last = sf[SF_TAU_LAST];
         rec_rmse_tr = sf[SF_REC_RMSE_TR]; rec_rmse_te = sf[SF_REC_RMSE_TE];
         rec_acc_tr = sf[SF_REC_ACC_TR]; rec_acc_te = sf[SF_REC_ACC_TE];
-        nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT];
+        nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT]; lg_acc = si[SI_LG_ACC];
     }
 
 #ifdef PTNN_STAMPS
@@ -991,6 +992,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
             lik = sm[SL_LIKPROP]; prior_cur = sm[SL_PRIORPROP]; eta = sm[SL_ETAPRO];
             rec_rmse_tr = sm[SL_RM_TR]; rec_rmse_te = sm[SL_RM_TE]; rec_acc_tr = sm[SL_AC_TR]; rec_acc_te = sm[SL_AC_TE];
             gd_valid = p.use_lg ? 1 : 0;
+            lg_acc += (sm[SL_LG] != 0.0f) ? 1 : 0;
             const int owner = m / NW;
             bool ok = true;
             if (owner == grp) {
@@ -1051,7 +1053,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
             sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur; sf[SF_TAU_LAST] = tau_eta_last;
             sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;
             sf[SF_REC_ACC_TR] = rec_acc_tr; sf[SF_REC_ACC_TE] = rec_acc_te;
-            si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count;
+            si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count; si[SI_LG_ACC] = lg_acc;
             p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;
             p.L_final[gid] = lik;
         }
