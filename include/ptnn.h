@@ -55,6 +55,9 @@ typedef struct ptnn_config {
                                    * value the caller drains with ptnn_get_traces at least every trace_capacity steps */
     int32_t forward_bf16;         /* wide nets (n_hidden > 64, multiple of 32): 1 = forward-pass GEMM operands rounded to
                                    * bf16 with fp32 accumulation (v_mfma_f32_32x32x16_bf16), 0 = exact fp32 MFMA */
+    int32_t swap_rule;            /* 0 = the reference's cascade (REG:659-690, default); 1 = even/odd Metropolis exchange
+                                   * min(1, exp((1/T_k - 1/T_k+1)(L_k+1 - L_k))) on untempered log-likelihoods, the moved state
+                                   * brings its likelihood and prior along, no phantom round (not in the reference) */
     float l_prob;                 /* langevin_prob (REG:174); CLS fixes 0.5 (CLS:192) */
     float learn_rate;             /* SGD step of langevin_gradient (REG:33) */
     float step_w;                 /* 0.025 (REG:258) */
@@ -81,6 +84,9 @@ int ptnn_set_data(ptnn_handle *h, const float *train, int ntr, const float *test
 /* w0 [R_local, P] (REG:649) and temperatures [R_local] (REG:615-636).  Also runs the chain start-up on the device:
  * eta0 = log var(fx_train(w0) - y) for REG (REG:270), initial prior and tempered likelihood (REG:280-285). */
 int ptnn_set_state(ptnn_handle *h, const float *w0, const float *temperatures);
+
+/* all R_global temperatures (needed by swap_rule 1 only) */
+int ptnn_set_ladder(ptnn_handle *h, const float *temperatures_global);
 
 /* Advances every local replica by up to n_steps MH steps (ptReplica.run loop body, REG:313-437) and performs the
  * swap rounds that fall inside (ParallelTempering.swap_procedure + round loop, REG:659-690, 719-752), including the

@@ -386,7 +386,8 @@ class PTOracle:
     """
 
     def __init__(self, task, topo, train, test, num_chains, maxtemp, NumSample, swap_interval,
-                 use_lg=False, l_prob=0.5, lr=0.1, seed=1, w0=None, faithful=False):
+                 use_lg=False, l_prob=0.5, lr=0.1, seed=1, w0=None, faithful=False, swap_rule=0):
+        self.swap_rule = swap_rule          # 0 = the reference's cascade; 1 = even/odd Metropolis (NOT in the reference)
         self.task, self.topo = task, tuple(topo)
         self.train = np.asarray(train, dtype=np.float64)
         self.test = np.asarray(test, dtype=np.float64)
@@ -406,7 +407,39 @@ class PTOracle:
         self.rounds_done = 0
         self.src_log = []
 
+    def swap_round_even_odd(self):
+        """Option swap_rule = 1, parity unpinned: the reference has no such rule; this restates the textbook
+        exchange of adjacent pairs with probability min(1, exp((1/T_k - 1/T_k+1)(L_k+1 - L_k))) on untempered
+        log-likelihoods, pairs of alternating parity per round; a moved state brings its likelihood (re-tempered for its
+        new slot) and prior along."""
+        R = self.R
+        u = self.tape.swap_uniforms(self.rounds_done, R - 1)
+        raw = [rep.likelihood * rep.adapttemp for rep in self.replicas]
+        T = self.temperatures
+        src = list(range(R))
+        par = self.rounds_done & 1
+        nsw = 0
+        for k in range(par, R - 1, 2):
+            d = (1.0 / T[k] - 1.0 / T[k + 1]) * (raw[k + 1] - raw[k])
+            p = 1.0 if d != d else min(1.0, math.exp(min(d, 80.0)))
+            if u[k] < p:
+                src[k], src[k + 1] = k + 1, k
+                nsw += 1
+        self.num_swap += nsw
+        self.total_swap_proposals += (R - par) // 2
+        self.rounds_done += 1
+        self.src_log.append(list(src))
+        old = [(rep.w, rep.eta, raw[i], rep.prior_current) for i, rep in enumerate(self.replicas)]
+        for k, rep in enumerate(self.replicas):
+            if src[k] != k:
+                w, eta, lraw, pri = old[src[k]]
+                rep.w, rep.eta, rep.prior_current = w, eta, pri
+                rep.likelihood = lraw / rep.adapttemp
+        return src
+
     def swap_round(self, L=None, apply=True):
+        if self.swap_rule == 1:
+            return self.swap_round_even_odd()
         R = self.R
         if L is None:
             L = [rep.posted_L() for rep in self.replicas]
@@ -434,7 +467,7 @@ class PTOracle:
         # Q13 phantom round: the parent loops int(S/si) rounds; extra ones consume the end-of-chain
         # vectors (L = final tempered likelihood, REG:442 / CLS:451) and are counted but discarded.
         rounds = int(S / si) if si > 0 else 0
-        if rounds > self.rounds_done:
+        if self.swap_rule == 0 and rounds > self.rounds_done:
             self.swap_round(L=[rep.likelihood for rep in self.replicas], apply=False)
         return self
 

@@ -19,7 +19,7 @@ class Config(C.Structure):
         ("n_in", C.c_int32), ("n_hidden", C.c_int32), ("n_out", C.c_int32),
         ("n_replicas_local", C.c_int32), ("n_replicas_global", C.c_int32), ("first_global_replica", C.c_int32),
         ("n_samples", C.c_int32), ("swap_interval", C.c_int32), ("pt_switch_step", C.c_int32),
-        ("use_langevin", C.c_int32), ("waves_per_replica", C.c_int32), ("schedule", C.c_int32), ("groups_per_replica", C.c_int32), ("trace_capacity", C.c_int32), ("forward_bf16", C.c_int32),
+        ("use_langevin", C.c_int32), ("waves_per_replica", C.c_int32), ("schedule", C.c_int32), ("groups_per_replica", C.c_int32), ("trace_capacity", C.c_int32), ("forward_bf16", C.c_int32), ("swap_rule", C.c_int32),
         ("l_prob", C.c_float), ("learn_rate", C.c_float), ("step_w", C.c_float), ("step_eta", C.c_float),
         ("sigma_squared", C.c_float), ("nu_1", C.c_float), ("nu_2", C.c_float),
         ("seed", C.c_uint64),
@@ -45,6 +45,7 @@ SYMBOLS = {
     "ptnn_destroy": (C.c_int, [C.c_void_p]),
     "ptnn_set_data": (C.c_int, [C.c_void_p, _fp, C.c_int, _fp, C.c_int, C.c_int]),
     "ptnn_set_state": (C.c_int, [C.c_void_p, _fp, _fp]),
+    "ptnn_set_ladder": (C.c_int, [C.c_void_p, _fp]),
     "ptnn_run": (C.c_int, [C.c_void_p, C.c_int]),
     "ptnn_sync": (C.c_int, [C.c_void_p]),
     "ptnn_steps_done": (C.c_int, [C.c_void_p]),
@@ -142,6 +143,12 @@ class Sampler:
         if w0.shape != (self.R, self.P) or t.shape != (self.R,):
             raise ValueError(f"w0 must be [{self.R},{self.P}], temperatures [{self.R}]")
         self._check(self.lib.ptnn_set_state(self.h, _ptr(w0), _ptr(t)))
+
+    def set_ladder(self, temperatures_global):
+        t = _f32(temperatures_global)
+        if t.shape != (self.cfg.n_replicas_global,):
+            raise ValueError("temperatures_global must have n_replicas_global entries")
+        self._check(self.lib.ptnn_set_ladder(self.h, _ptr(t)))
 
     def run(self, n_steps=-1):
         self._check(self.lib.ptnn_run(self.h, int(n_steps)))

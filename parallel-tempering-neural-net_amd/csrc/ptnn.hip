@@ -109,6 +109,8 @@ struct ptnn_handle {
     int* d_gd_valid[2] = {nullptr, nullptr};
     int* d_st_i = nullptr;
     float *d_L_handoff = nullptr, *d_L_final = nullptr;
+    float *d_L_raw = nullptr, *d_prior_post = nullptr, *d_temps_global = nullptr;   // swap_rule 1
+    bool have_ladder = false;
     float *d_pos_w = nullptr, *d_likeh = nullptr, *d_rmse_tr = nullptr, *d_rmse_te = nullptr, *d_acc_tr = nullptr,
           *d_acc_te = nullptr;
     int* d_accept = nullptr;
@@ -140,6 +142,7 @@ struct ptnn_handle {
         p.data = d_data; p.w_state = d_state[flip]; p.rec_w = d_rec_w; p.gd_w = d_gd_w[flip]; p.gd_valid = d_gd_valid[flip];
         p.st_f = d_st_f; p.st_i = d_st_i; p.temps = d_temps;
         p.L_handoff = d_L_handoff; p.L_final = d_L_final;
+        p.L_raw = (cfg.swap_rule == 1) ? d_L_raw : nullptr; p.prior_post = d_prior_post;
         p.tr_pos_w = d_pos_w; p.tr_likeh = d_likeh; p.tr_rmse_tr = d_rmse_tr; p.tr_rmse_te = d_rmse_te;
         p.tr_acc_tr = d_acc_tr; p.tr_acc_te = d_acc_te; p.tr_accept = d_accept;
         p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.xt = d_xt; p.Npad = Npad; p.forward_bf16 = cfg.forward_bf16;
@@ -216,6 +219,9 @@ int launch_swap(ptnn_handle* h, bool phantom, int mode, bool want_src) {
     sp.gd_valid_cur = h->d_gd_valid[h->flip]; sp.gd_valid_next = h->d_gd_valid[h->flip ^ 1];
     sp.src_out = want_src ? h->d_src : nullptr;
     sp.counters = h->d_counters; sp.src_log = h->d_src_log; sp.log_capacity = h->max_rounds;
+    sp.rule = h->cfg.swap_rule; sp.L_raw = h->d_L_raw; sp.prior_post = h->d_prior_post; sp.temps_global = h->d_temps_global;
+    sp.st_f = h->d_st_f;
+    sp.canonical = (h->cfg.pt_switch_step >= 0 && h->cur - 1 >= h->cfg.pt_switch_step) ? 1 : 0;
     const size_t lds = (size_t)(3 * sp.R + 1) * sizeof(float);
     hipLaunchKernelGGL(swap_kernel, dim3(sp.Rl), dim3(64), lds, h->stream, sp, h->rounds_done, mode);
     HIP_TRY(hipGetLastError());
@@ -259,6 +265,9 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
                     cfg->n_replicas_global, cfg->first_global_replica);
     if (cfg->n_samples < 2) return fail(-1, "n_samples must be >= 2");
     if (cfg->swap_interval < 1) return fail(-1, "swap_interval must be >= 1 (the reference divides by it, REG:427)");
+    if (cfg->swap_rule != 0 && cfg->swap_rule != 1) return fail(-1, "swap_rule must be 0 (reference cascade) or 1 (even/odd Metropolis)");
+    if (cfg->swap_rule == 1 && cfg->n_replicas_local != cfg->n_replicas_global)
+        return fail(-3, "swap_rule 1 is single-GPU for now: the moved state's likelihood and prior are not yet part of the row exchange");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(-2, "device %d not present (%d devices)", cfg->device_id, ndev);
@@ -296,6 +305,9 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
     HIP_TRY(hipMalloc(&h->d_temps, Rl * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_L_handoff, R * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_L_final, R * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_L_raw, R * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_prior_post, R * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_temps_global, R * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_pos_w, Rl * S * h->P * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_likeh, Rl * S * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_rmse_tr, Rl * S * sizeof(float)));
@@ -323,7 +335,7 @@ int ptnn_destroy(ptnn_handle* h) {
     (void)hipSetDevice(h->cfg.device_id);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = {h->d_data, h->d_state[0], h->d_state[1], h->d_rec_w, h->d_gd_w[0], h->d_gd_w[1], h->d_gd_valid[0], h->d_gd_valid[1], h->d_st_f, h->d_st_i, h->d_temps,
-                    h->d_L_handoff, h->d_L_final, h->d_pos_w, h->d_likeh, h->d_rmse_tr, h->d_rmse_te, h->d_acc_tr,
+                    h->d_L_handoff, h->d_L_final, h->d_L_raw, h->d_prior_post, h->d_temps_global, h->d_pos_w, h->d_likeh, h->d_rmse_tr, h->d_rmse_te, h->d_acc_tr,
                     h->d_acc_te, h->d_accept, h->d_src, h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_stamps, h->d_wide_scratch, h->d_xt};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -491,12 +503,21 @@ int ptnn_set_state(ptnn_handle* h, const float* w0, const float* temperatures) {
     return 0;
 }
 
+int ptnn_set_ladder(ptnn_handle* h, const float* temperatures_global) {
+    if (!h || !temperatures_global) return fail(-1, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipMemcpy(h->d_temps_global, temperatures_global, h->cfg.n_replicas_global * sizeof(float), hipMemcpyHostToDevice));
+    h->have_ladder = true;
+    return 0;
+}
+
 int ptnn_steps_done(ptnn_handle* h) { return h ? h->cur : -1; }
 
 int ptnn_run(ptnn_handle* h, int n_steps) {
     if (int rc = check_ready(h)) return rc;
     if (h->cfg.n_replicas_local != h->cfg.n_replicas_global)
         return fail(-1, "ptnn_run drives a whole ladder on one GPU; use ptnn_run_segment + ptnn_swap_* for a sharded ladder");
+    if (h->cfg.swap_rule == 1 && !h->have_ladder) return fail(-1, "swap_rule 1 needs ptnn_set_ladder (all temperatures)");
     const int S = h->cfg.n_samples;
     const int last = S - 1;                                  // steps are i = 0 .. S-2
     int end = (n_steps < 0) ? last : std::min(last, h->cur + n_steps);
@@ -519,7 +540,7 @@ int ptnn_run(ptnn_handle* h, int n_steps) {
     if (h->cur == last && !h->finalized) {
         // Q13: the parent loops int(S/si) rounds; a round beyond the replicas' hand-offs consumes the end-of-chain
         // vectors, is counted in swap_perc and its result is discarded
-        if (S / h->cfg.swap_interval > h->rounds_done) {
+        if (h->cfg.swap_rule == 0 && S / h->cfg.swap_interval > h->rounds_done) {
             if (int rc = launch_swap(h, true, 2, false)) return rc;
             h->rounds_done += 1;
         }

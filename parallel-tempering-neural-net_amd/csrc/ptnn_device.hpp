@@ -49,6 +49,8 @@ struct SegParams {
     const float* temps;      // [Rl]
     float* L_handoff;        // [Rglobal] posted scalar at a hand-off (REG:430 / CLS:439)
     float* L_final;          // [Rglobal] end-of-chain scalar (REG:442 / CLS:451)
+    float* L_raw;            // [Rglobal] untempered log-likelihood of the current state (swap_rule 1 only)
+    float* prior_post;       // [Rglobal] prior of the current state (swap_rule 1 only)
     float* tr_pos_w;         // [Rl][S][P]
     float* tr_likeh;         // [Rl][S]
     float* tr_rmse_tr; float* tr_rmse_te; float* tr_acc_tr; float* tr_acc_te;   // [Rl][S]
@@ -524,6 +526,15 @@ __device__ __forceinline__ void tape_step(const SegParams& p, int gid, int step,
     }
 }
 
+// swap_rule 1 (textbook exchange) works on untempered quantities: the likelihood held by the chain is tempered
+// by the adapttemp of the last executed step (T before the switch step, 1 from it on)
+__device__ __forceinline__ void post_raw(const SegParams& p, int gid, float lik, float prior_cur, float T, int last_step) {
+    if (p.L_raw == nullptr) return;
+    const float a = (p.switch_step >= 0 && last_step >= p.switch_step) ? 1.0f : T;
+    p.L_raw[gid] = lik * a;
+    p.prior_post[gid] = prior_cur;
+}
+
 // R14 chain start-up: eta0 = log var(fx_train(w0) - y) (REG:270), prior (REG:280), tempered likelihood (REG:284).
 // WL = false: the whole work-group shares the rows; WL = true: the calling wave does it alone (the speculative
 // schedule uses wave 0 so that the result does not depend on the number of waves).
@@ -702,6 +713,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
         si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count;
         p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;      // Q11
         p.L_final[gid] = lik;
+        post_raw(p, gid, lik, prior_cur, T, step_begin + n_steps - 1);
     }
 }
 
@@ -1056,6 +1068,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
             si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count; si[SI_LG_ACC] = lg_acc;
             p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;
             p.L_final[gid] = lik;
+            post_raw(p, gid, lik, prior_cur, T, step_begin + n_steps - 1);
         }
     }
 }
@@ -1438,6 +1451,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
         si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count;
         p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;
         p.L_final[gid] = lik;
+        post_raw(p, gid, lik, prior_cur, T, step_begin + n_steps - 1);
     }
 }
 
@@ -1498,6 +1512,13 @@ struct SwapParams {
     long long* counters;       // [0] num_swap, [1] total_swap_proposals
     int* src_log;              // [max_rounds][R] (may be null)
     int log_capacity;
+    // swap_rule 1: even/odd Metropolis exchange exp((1/T_k - 1/T_k+1)(L_k+1 - L_k)) on untempered log-likelihoods; the
+    // moved state brings its likelihood and prior along (no stale values), no phantom round
+    int rule, canonical;       // canonical: the chains are past the temperature switch (likelihoods untempered)
+    const float* L_raw;        // [R]
+    const float* prior_post;   // [R]
+    const float* temps_global; // [R]
+    float* st_f;               // [Rl][SF_COUNT]
 };
 
 // sSrc has R + 1 ints: the last one carries the number of accepted swaps
@@ -1512,6 +1533,19 @@ __device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, floa
         }
     }
     __syncthreads();
+    if (sp.rule == 1) {
+        // independent pairs (k, k+1), k of the round's parity
+        for (int k = threadIdx.x; k < R; k += blockDim.x) sSrc[k] = k;
+        if (threadIdx.x == 0) sSrc[R] = 0;
+        __syncthreads();
+        for (int k = (round & 1) + 2 * threadIdx.x; k < R - 1; k += 2 * blockDim.x) {
+            const float d = (1.0f / sp.temps_global[k] - 1.0f / sp.temps_global[k + 1]) * (sp.L_raw[k + 1] - sp.L_raw[k]);
+            const float pr = (d != d) ? 1.0f : fminf(1.0f, expf_fast(fminf(d, 80.0f)));
+            if (sU[k] < pr) { sSrc[k] = k + 1; sSrc[k + 1] = k; atomicAdd(&sSrc[R], 1); }
+        }
+        __syncthreads();
+        return sSrc[R];
+    }
     if (threadIdx.x == 0) {
         int c = 0, nsw = 0;
         for (int k = 0; k < R - 1; ++k) {
@@ -1552,13 +1586,21 @@ __global__ void swap_kernel(const SwapParams sp, const int round, const int mode
             valid = sp.gd_valid_cur[sl];
         }
         if (threadIdx.x == 0) sp.gd_valid_next[b] = valid;
+        if (sp.rule == 1 && s != k && threadIdx.x == 0) {
+            // the arriving state brings its own likelihood (re-tempered for this slot) and prior
+            sp.st_f[(size_t)b * SF_COUNT + SF_LIK] = sp.canonical ? sp.L_raw[s] : sp.L_raw[s] / sp.temps_global[k];
+            sp.st_f[(size_t)b * SF_COUNT + SF_PRIOR] = sp.prior_post[s];
+        }
     }
     if (b == 0) {
         if (sp.src_out) for (int k = threadIdx.x; k < sp.R; k += blockDim.x) sp.src_out[k] = sSrc[k];
         if (mode & 2) {
             if (sp.src_log && round < sp.log_capacity)
                 for (int k = threadIdx.x; k < sp.R; k += blockDim.x) sp.src_log[(size_t)round * sp.R + k] = sSrc[k];
-            if (threadIdx.x == 0) { sp.counters[0] += nsw; sp.counters[1] += sp.R - 1; }
+            if (threadIdx.x == 0) {
+                sp.counters[0] += nsw;
+                sp.counters[1] += (sp.rule == 1) ? (sp.R - 1 - (round & 1) + 1) / 2 : sp.R - 1;      // pairs proposed
+            }
         }
     }
 }

@@ -513,3 +513,50 @@ def test_config5_bf16_forward_tolerance_study():
     print("bf16 forward: %d chains, %d comparable MH decisions, %d first flips (%.1f %% per decision)"
           % (a32.shape[0], total, flips, 100.0 * flips / max(total, 1)))
     assert flips / max(total, 1) < 0.15
+
+
+@pytest.mark.parametrize("task", [0, 1])
+def test_even_odd_swap_rule_option(task):
+    """swap_rule = 1 (default off): even/odd Metropolis exchange on untempered log-likelihoods.  The reference
+    has no such rule (parity unpinned for this option); the kernel is held to the oracle's restatement of the textbook
+    rule on the same tape: identical permutations and MH decisions up to fp32 coin tosses."""
+    d = ds()
+    if task == 0:
+        topo, name, lg, lr, mt = (4, 5, 1), "sunspot", True, 0.1, 2
+    else:
+        topo, name, lg, lr, mt = (4, 12, 3), "iris", False, 0.01, 10
+    R, S, si, seed = 6, 100, 5, 61
+    train, test = d[name + "_train"], d[name + "_test"]
+    pt = orc.PTOracle(task, topo, train, test, R, mt, R * S, si, use_lg=lg, l_prob=0.5, lr=lr, seed=seed, swap_rule=1)
+    w0 = np.stack([rep.w for rep in pt.replicas]).astype(np.float32)
+    for rep, w in zip(pt.replicas, w0):
+        rep.__init__(task, topo, pt.train, pt.test, w.astype(np.float64), rep.T, S, lg, 0.5, lr, pt.tape, rep.gid)
+    o = parity.OracleRun(pt).run()
+    s = parity.make_sampler(task, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=lg, lr=lr, seed=seed,
+                            swap_rule=1)
+    s.set_state(w0, np.array(pt.temperatures, dtype=np.float32))
+    s.set_ladder(pt.temperatures)
+    s.run(-1)
+    s.sync()
+    tr = s.traces()
+    nsw, tot, rounds = s.swap_stats()
+    assert rounds == pt.rounds_done == orc.count_handoffs(task, S, si)          # no phantom round under this rule
+    assert tot == pt.total_swap_proposals
+    log = s.swap_log()
+    for k, row in enumerate(log):
+        assert sorted(row.tolist()) == list(range(R))
+        par = k & 1
+        for j in range(R):                                                      # only pairs of this round's parity move
+            assert row[j] == j or (row[j] == j + 1 and j % 2 == par) or (row[j] == j - 1 and (j - 1) % 2 == par)
+    firsts = [parity.compare_replica_trace(tr, r, pt.replicas[r], f"evenodd r{r} ") for r in range(R)]
+    if all(f is None for f in firsts) and all((log[k] == np.array(pt.src_log[k])).all() for k in range(rounds)):
+        assert nsw == pt.num_swap
+        st = s.state()
+        np.testing.assert_allclose(st["likelihood"], [rep.likelihood for rep in pt.replicas], rtol=5e-5, atol=5e-3)
+        np.testing.assert_allclose(st["prior"], [rep.prior_current for rep in pt.replicas], rtol=1e-5, atol=1e-3)
+    else:
+        div = [f for f in firsts if f is not None]
+        if div:
+            r = firsts.index(min(div))
+            i = min(div) - 2
+            assert abs(o.logalpha[r, i] - o.logu[r, i]) < parity.LOGALPHA_SLACK
