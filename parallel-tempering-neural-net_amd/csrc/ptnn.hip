@@ -79,7 +79,6 @@ struct ptnn_handle {
     ptnn_config cfg{};
     const Shape* shape = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int P = 0, PS = 0, IPY = 0, FWS = 0, Ntr = 0, Nte = 0, nthreads = 64;
     size_t seg_lds = 0, model_lds = 0;
     int model_threads = 64;

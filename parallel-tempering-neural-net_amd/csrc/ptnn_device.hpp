@@ -28,7 +28,7 @@ constexpr uint32_t STREAM_STEP = 0, STREAM_WNOISE = 1, STREAM_SWAP = 2, STREAM_I
 
 // per-replica float state (st_f) and int state (st_i) slots
 enum { SF_LIK = 0, SF_PRIOR, SF_TAU_LAST, SF_REC_RMSE_TR, SF_REC_RMSE_TE, SF_REC_ACC_TR, SF_REC_ACC_TE, SF_COUNT = 8 };
-enum { SI_NACC = 0, SI_GD_VALID, SI_LG_COUNT, SI_LG_ACC, SI_COUNT = 4 };   // SI_LG_ACC: accepted Langevin steps
+enum { SI_NACC = 0, SI_UNUSED, SI_LG_COUNT, SI_LG_ACC, SI_COUNT = 4 };   // accepted steps, -, Langevin steps proposed / accepted
 
 struct SegParams {
     int H, P, PS;            // hidden units, parameters, state row length (P + 1 rounded up to 4)

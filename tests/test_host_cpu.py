@@ -150,3 +150,37 @@ def test_split_and_normalise(pt):
     allx = np.vstack([tr, te])[:, :4]
     np.testing.assert_allclose(allx.mean(0), 0, atol=1e-12)
     np.testing.assert_allclose(allx.std(0), 1, atol=1e-12)
+
+
+def test_create_validates_before_touching_the_gpu(pt):
+    """Every malformed configuration is refused with a message (negative code + ptnn_last_error), no device needed."""
+    import ctypes as C
+    from ptnn_amd import _lib
+    lib = pt.load_library()
+
+    def create(**over):
+        cfg = _lib.Config()
+        base = dict(struct_bytes=C.sizeof(_lib.Config), device_id=0, task=0, n_in=4, n_hidden=5, n_out=1, n_replicas_local=4,
+                    n_replicas_global=4, first_global_replica=0, n_samples=100, swap_interval=10, pt_switch_step=60,
+                    use_langevin=1, l_prob=0.5, learn_rate=0.1, step_w=0.025, step_eta=0.2, sigma_squared=25.0, seed=1)
+        base.update(over)
+        for k, v in base.items():
+            setattr(cfg, k, v)
+        h = C.c_void_p()
+        rc = lib.ptnn_create(C.byref(cfg), C.byref(h))
+        msg = lib.ptnn_last_error().decode()
+        if rc == 0:
+            lib.ptnn_destroy(h)
+        return rc, msg
+
+    for over, needle in [(dict(struct_bytes=8), "size mismatch"), (dict(task=7), "unknown task"), (dict(n_out=2), "n_out == 1"),
+                         (dict(n_in=7), "no gfx950 kernel compiled"), (dict(n_hidden=513), "n_hidden=513"),
+                         (dict(n_replicas_global=1, n_replicas_local=1), "replica partition"),
+                         (dict(first_global_replica=2), "replica partition"), (dict(n_samples=1), "n_samples"),
+                         (dict(swap_interval=0), "swap_interval"), (dict(swap_rule=3), "swap_rule"),
+                         (dict(swap_rule=1, n_replicas_global=8), "single-GPU"), (dict(n_in=0), "bad topology")]:
+        rc, msg = create(**over)
+        assert rc < 0 and needle in msg, (over, rc, msg)
+    assert lib.ptnn_create(None, None) < 0
+    assert lib.ptnn_destroy(None) == 0
+    assert lib.ptnn_sync(None) < 0 and lib.ptnn_steps_done(None) == -1
