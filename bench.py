@@ -108,6 +108,68 @@ def cpu_baseline(train, test, n_steps=40):
                       f"{cores} processes, {sum(busy):.1f} s of CPU work, no swap rounds"}
 
 
+# ------------------------------------------------------------------------------------------------ config 5 shape
+def bench_synthetic512(a):
+    """BASELINE config 5 shape on one GPU: FNN 32-512-1 (P = 17 409), 1024 train + 256 test rows (SURVEY 8d recipe),
+    128 replicas, random-walk proposals: a step is dominated by the per-replica forward GEMM 1280 x 32 x 512 on MFMA."""
+    import ptnn_amd
+    from ptnn_amd import _lib, ladder, philox
+    rng = np.random.default_rng(5)
+    I, H, R, si = 32, 512, 128, 20
+    Pw = I * H + H + H + 1
+    X = rng.uniform(0, 1, (1280, I))
+    wt = np.concatenate([rng.standard_normal(I * H) / np.sqrt(I), rng.standard_normal(H) / np.sqrt(H),
+                         rng.standard_normal(H) / np.sqrt(I), rng.standard_normal(1) / np.sqrt(H)])
+    sig = lambda z: 1.0 / (1.0 + np.exp(-z))
+    y = np.clip(sig(sig(X @ wt[:I * H].reshape(I, H) - wt[I * H + H:I * H + 2 * H]) @ wt[I * H:I * H + H] - wt[-1])
+                + rng.normal(0, 0.02, 1280), 0, 1)
+    data = np.hstack([X, y[:, None]])
+    K, W = a.steps, a.warmup
+    S = (W + K + 1) * si + 2
+    s = _lib.Sampler(device_id=int(os.environ.get("LOCAL_RANK", "0")), task=_lib.TASK_REG, n_in=I, n_hidden=H, n_out=1,
+                     n_replicas_local=R, n_replicas_global=R, first_global_replica=0, n_samples=S, swap_interval=si,
+                     pt_switch_step=switch_step(S), use_langevin=0, l_prob=0.5, learn_rate=0.1, step_w=0.025, step_eta=0.2,
+                     sigma_squared=25.0, seed=SEED, forward_bf16=int(a.bf16), trace_capacity=4 * si)
+    s.set_data(data[:1024], data[1024:])
+    s.set_state(0.3 * np.stack([philox.initial_weights(SEED, r, Pw) for r in range(R)]), ladder.temperatures(R, MAXTEMP))
+    drained = 0
+
+    def advance(n_intervals):
+        nonlocal drained
+        for _ in range(n_intervals):                        # the trace ring holds 4 intervals: drain as we go
+            s.run(si)
+            hi = s.steps_done() + 1
+            s.traces(drained, hi - drained, pos_w=False)
+            drained = hi
+    s.run(1)
+    advance(W)
+    s.sync()
+    s.kernel_time(reset=True)
+    t0 = time.perf_counter()
+    advance(K)
+    s.sync()
+    dt = time.perf_counter() - t0
+    launches, kms = s.kernel_time()
+    value = R * K * si / dt
+    flops_step = 2.0 * 1280 * I * H                          # the forward GEMM of one MH step of one replica
+    avg_launch_s = kms / max(launches, 1) * 1e-3
+    achieved = R * si * flops_step / avg_launch_s / 1e12
+    peak = 2500.0 if a.bf16 else 157.3                      # MI355X_MICROARCH.md: dense bf16 MFMA / fp32 MFMA (= vector) peak
+    print(json.dumps({
+        "metric": "MCMC samples/sec (all replicas); synthetic 32-512-1, 128 replicas (BASELINE config 5 shape, one GPU)",
+        "value": value, "unit": "samples/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.bf16 else "f32",
+        "data": "synthetic (SURVEY.md 8d config-5 recipe, rng 5)",
+        "config": {"workload": f"FNN 32-512-1, 1024/256 rows, {R} replicas, random-walk, swap every {si} steps; "
+                               f"1 bench step = 1 swap interval; forward GEMM on MFMA ({'bf16' if a.bf16 else 'fp32'})"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "traffic": None, "kernel": "ptnn::segment_wide_kernel<0,32,1>", "avg_launch_ms": avg_launch_s * 1e3,
+                     "launches": launches, "algorithmic_flops_per_launch": R * si * flops_step,
+                     "note": "flops of the forward GEMM only; the launch also generates 17 409 normals, streams five 70 KB "
+                             "vectors and writes a 70 KB trace row per step and replica"}}), flush=True)
+    s.close()
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -116,6 +178,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rw", action="store_true", help="random-walk proposals only (extra data point)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="sunspot64", choices=["sunspot64", "synthetic512"],
+                    help="sunspot64 = the BASELINE metric (default); synthetic512 = BASELINE config 5 shape (FNN 32-512-1, "
+                         "1024/256 rows, 128 replicas per GPU, random-walk): the MFMA forward pass, roofline bound 'mfma'")
+    ap.add_argument("--bf16", action="store_true", help="synthetic512: forward GEMM operands in bf16")
     ap.add_argument("--schedule", type=int, default=0, help="0 auto, 1 cooperative, 2 speculative")
     ap.add_argument("--waves", type=int, default=0, help="wavefronts per work-group (0 = auto)")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded-ladder driver even at world size 1 (rehearsal)")
@@ -129,6 +195,8 @@ def main():
         if world == 1 and N > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         N = world
+    if a.workload == "synthetic512":
+        return bench_synthetic512(a)
     train, test, data_desc = load_sunspot()
     si = SWAP_INTERVAL
     S = (W + K + 1) * si + 2

@@ -1341,7 +1341,6 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
     const int r = blockIdx.x;
     const int gid = p.first_global + r;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int Nall = p.Ntr + p.Nte;
     const int P = p.P, PS = p.PS, H = p.H;
     float* fw = smem;
     float* red = fw + wide_img_floats(H, p.FWS, PS);
@@ -1463,8 +1462,7 @@ __global__ void __launch_bounds__(MAX_THREADS) model_wide_kernel(const SegParams
                                                                   int a1) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int OP = (O + 3) & ~3;
-    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-    const int Nall = p.Ntr + p.Nte;
+    const int b = blockIdx.x, tid = threadIdx.x;
     float* fw = smem;
     float* red = fw + wide_img_floats(p.H, p.FWS, p.PS);
     float* part = red + MAX_WAVES * 8;
