@@ -1097,7 +1097,7 @@ __device__ __forceinline__ void sgd_sweep_wide(const float* __restrict__ w_in, f
                                                float* __restrict__ part) {
     constexpr float C = -LOG2E, IC = -LN2;
     constexpr int OP = (O + 3) & ~3;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool act = t < H;
     const int hl = act ? t : 0;
     const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
@@ -1111,29 +1111,32 @@ __device__ __forceinline__ void sgd_sweep_wide(const float* __restrict__ w_in, f
 #pragma unroll
     for (int o = 0; o < O; ++o) cl[o] = -C * w_in[oB2 + o];          // replicated in every thread, updated identically
     int par = 0;
-    for (int n = 0; n < Ntr; ++n) {
-        const float* __restrict__ row = data + (size_t)n * IPY;       // wave-uniform: scalar loads
-        float x[I + 1];
-#pragma unroll
-        for (int i = 0; i <= I; ++i) x[i] = row[i];
+    static_assert(MAX_WAVES == 8, "the partial sums are read as two float4");
+    for (int e = t; e < 2 * MAX_WAVES * OP; e += blockDim.x) part[e] = 0.0f;
+    __syncthreads();
+    // the rows come from L2 (wave-uniform addresses): keep two rows in flight so that their latency hides behind the row
+    // being computed.  The data image carries two padding rows, so the look-ahead never leaves it.
+    auto row_step = [&](const float (&x)[I + 1]) {
         float z = fmaf(x[0], w1[0], -b1);
 #pragma unroll
         for (int i = 1; i < I; ++i) z = fmaf(x[i], w1[i], z);
         const float hid = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
         const float ldh = lr * fmaf(-hid, hid, hid);
-        float* mypart = part + (size_t)par * MAX_WAVES * OP;
+        float* mypart = part + (size_t)par * MAX_WAVES * OP;          // [o][wave]: the partials of one output are contiguous
 #pragma unroll
         for (int o = 0; o < O; ++o) {
             const float s_ = wave_allsum(hid * w2[o]);
-            if (lane == 0) mypart[wave * OP + o] = s_;
+            if (lane == 0) mypart[o * MAX_WAVES + wave] = s_;
         }
         __syncthreads();
         float g = 0.0f;
         float lod[O];
 #pragma unroll
         for (int o = 0; o < O; ++o) {
-            float zo = cl[o];
-            for (int w = 0; w < nw; ++w) zo += mypart[w * OP + o];
+            // all MAX_WAVES partials with two 16-byte reads (entries of absent waves are zero), summed in a fixed order
+            const float4 pa = *reinterpret_cast<const float4*>(mypart + o * MAX_WAVES);
+            const float4 pb = *reinterpret_cast<const float4*>(mypart + o * MAX_WAVES + 4);
+            const float zo = cl[o] + (((pa.x + pa.y) + (pa.z + pa.w)) + ((pb.x + pb.y) + (pb.z + pb.w)));
             const float out = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zo));
             float tt;
             if (TASK == TASK_CLS) tt = ((int)x[I] == o) ? 1.0f : 0.0f;
@@ -1152,7 +1155,23 @@ __device__ __forceinline__ void sgd_sweep_wide(const float* __restrict__ w_in, f
         for (int i = 0; i < I; ++i) w1[i] = fmaf(lhd, x[i], w1[i]);
         b1 -= lhd;
         par ^= 1;
+    };
+    auto load_row = [&](int n, float (&x)[I + 1]) {
+        const float* __restrict__ row = data + (size_t)n * IPY;
+#pragma unroll
+        for (int i = 0; i <= I; ++i) x[i] = row[i];
+    };
+    float xa[I + 1], xb[I + 1];
+    load_row(0, xa);
+    load_row(1, xb);
+    int n = 0;
+    for (; n + 1 < Ntr; n += 2) {
+        row_step(xa);
+        load_row(n + 2, xa);
+        row_step(xb);
+        load_row(n + 3, xb);
     }
+    if (n < Ntr) row_step(xa);
     if (act) {
 #pragma unroll
         for (int i = 0; i < I; ++i) w_out[i * H + t] = IC * w1[i];
