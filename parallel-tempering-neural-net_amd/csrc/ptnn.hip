@@ -423,7 +423,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         if (h->cfg.groups_per_replica > 0) G = h->cfg.groups_per_replica;
         else { while (G < 4 && Rl * (G * 2) <= h->num_cus) G *= 2; }
         if (G != 1 && G != 2 && G != 4 && G != 8) return fail(-1, "groups_per_replica must be 0 (auto), 1, 2, 4 or 8");
-        if (Rl * G > h->num_cus * 2)
+        if (G > 1 && Rl * G > h->num_cus * 2)              // groups of one replica wait for each other: all must be resident
             return fail(-3, "%d replicas x %d work-groups cannot all be resident on %d CUs", Rl, G, h->num_cus);
         int k = nw ? nw : (G > 1 ? 4 : 8);
         while (k > 1 && spec_lds_floats(Nall, IPY, h->PS, H, h->FWS, k, G) * sizeof(float) > LDS_MAX) k >>= 1;
