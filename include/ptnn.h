@@ -29,6 +29,7 @@ extern "C" {
 #define PTNN_SCHED_AUTO 0
 #define PTNN_SCHED_COOPERATIVE 1
 #define PTNN_SCHED_SPECULATIVE 2
+#define PTNN_SCHED_PACKED 3      /* speculative, all slots of a round on one CU (n_hidden <= 8) */
 
 typedef struct ptnn_handle ptnn_handle;
 
@@ -48,7 +49,8 @@ typedef struct ptnn_config {
     int32_t use_langevin;         /* use_langevin_gradients (REG:329) */
     int32_t waves_per_replica;    /* 0 = auto; 1,2,4,8: wavefronts per work-group */
     int32_t schedule;             /* 0 = auto, 1 = cooperative (all waves share one MH step), 2 = speculative
-                                   * (wave v pre-computes step i+v; identical chain) */
+                                   * (wave v pre-computes step i+v; identical chain), 3 = packed
+                                   * speculative (n_hidden <= 8: 16 slots on one CU, SGD epochs in lane groups) */
     int32_t groups_per_replica;   /* speculative schedule: work-groups (CUs) cooperating on one replica; 0 = auto
                                    * (as many of 1, 2, 4 as keeps replicas x groups <= number of CUs) */
     int32_t trace_capacity;       /* rows per replica kept on the device (ring); 0 = all n_samples rows.  With a smaller

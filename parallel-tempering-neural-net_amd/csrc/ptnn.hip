@@ -57,10 +57,11 @@ struct Shape {
     model_fn model;
     seg_fn seg_wide;        // 64 < H <= MAX_HIDDEN
     model_fn model_wide;
+    seg_fn pack;            // H <= 8: packed speculative schedule
 };
 
 #define X_ENTRY(T, I, O) {T, I, O, &segment_kernel<T, I, O>, &segment_spec_kernel<T, I, O>, &model_kernel<T, I, O>, \
-                          &segment_wide_kernel<T, I, O>, &model_wide_kernel<T, I, O>},
+                          &segment_wide_kernel<T, I, O>, &model_wide_kernel<T, I, O>, &segment_pack_kernel<T, I, O>},
 constexpr int MAX_HIDDEN = MAX_WAVES * WAVE;    // one thread per hidden unit
 const Shape g_shapes[] = {PTNN_SHAPES(X_ENTRY)};
 #undef X_ENTRY
@@ -84,6 +85,7 @@ struct ptnn_handle {
     int model_threads = 64;
     bool speculative = false;
     bool wide = false;              // 64 < H: vectors in HBM, one thread per hidden unit
+    bool packed = false;            // H <= 8: packed speculative schedule on one CU
     float* d_wide_scratch = nullptr;
     float* d_xt = nullptr;          // transposed data image for the MFMA forward pass
     int Npad = 0;
@@ -175,9 +177,9 @@ int launch_segment(ptnn_handle* h, int begin, int n) {
     const bool timed = h->timing_stride > 0 && (h->launch_count++ % h->timing_stride) == 0;
     if (!timed) {
         const SegParams p = h->seg_params();
-        const int grid = h->cfg.n_replicas_local * (h->speculative ? h->groups : 1);
-        hipLaunchKernelGGL(h->wide ? h->shape->seg_wide : (h->speculative ? h->shape->spec : h->shape->seg), dim3(grid),
-                           dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
+        const int grid = h->cfg.n_replicas_local * ((h->speculative && !h->packed) ? h->groups : 1);
+        hipLaunchKernelGGL(h->wide ? h->shape->seg_wide : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg)),
+                           dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
         h->epoch_base += (unsigned)n + 1u;
         HIP_TRY(hipGetLastError());
         return 0;
@@ -196,9 +198,9 @@ int launch_segment(ptnn_handle* h, int begin, int n) {
     auto& ev = h->timing[h->timing_used++];
     const SegParams p = h->seg_params();
     HIP_TRY(hipEventRecord(ev.first, h->stream));
-    const int grid = h->cfg.n_replicas_local * (h->speculative ? h->groups : 1);
-    hipLaunchKernelGGL(h->wide ? h->shape->seg_wide : (h->speculative ? h->shape->spec : h->shape->seg), dim3(grid),
-                       dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
+    const int grid = h->cfg.n_replicas_local * ((h->speculative && !h->packed) ? h->groups : 1);
+    hipLaunchKernelGGL(h->wide ? h->shape->seg_wide : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg)),
+                       dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
     h->epoch_base += (unsigned)n + 1u;                    // granule tags never repeat across launches
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, h->stream));
@@ -406,7 +408,27 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
     int sched = h->cfg.schedule;
     if (sched == PTNN_SCHED_AUTO)
         sched = (h->cfg.task == PTNN_TASK_REG || h->cfg.use_langevin) ? PTNN_SCHED_SPECULATIVE : PTNN_SCHED_COOPERATIVE;
-    if (sched != PTNN_SCHED_COOPERATIVE && sched != PTNN_SCHED_SPECULATIVE) return fail(-1, "unknown schedule %d", sched);
+    if (sched != PTNN_SCHED_COOPERATIVE && sched != PTNN_SCHED_SPECULATIVE && sched != PTNN_SCHED_PACKED)
+        return fail(-1, "unknown schedule %d", sched);
+    h->packed = false;
+    {
+        // packed speculative: 16 slots on one CU, the SGD epochs of all slots in the lane groups of two waves.  Taken
+        // automatically for Langevin runs of nets with <= 8 hidden units (same speed as 4 CUs per replica on a quarter of
+        // the GPU, twice the throughput once there are more replicas than CUs); random-walk-only runs have no epochs to pack
+        // and keep the multi-CU speculative schedule.
+        const size_t pk = pack_lds_floats(Nall, IPY, h->PS, H, h->FWS) * sizeof(float);
+        const bool fits = H <= (1 << PK_NRED) && pk <= LDS_MAX;
+        if (sched == PTNN_SCHED_PACKED && !fits)
+            return fail(-3, "the packed schedule needs n_hidden <= %d and %zu B of LDS <= 160 KiB", 1 << PK_NRED, pk);
+        if (sched == PTNN_SCHED_PACKED ||
+            (h->cfg.schedule == PTNN_SCHED_AUTO && sched == PTNN_SCHED_SPECULATIVE && fits && h->cfg.use_langevin &&
+             h->cfg.waves_per_replica == 0 && h->cfg.groups_per_replica == 0)) {
+            h->packed = true; h->speculative = true; h->groups = 1;
+            h->nthreads = PK_WAVES * WAVE;
+            h->seg_lds = pk;
+            sched = PTNN_SCHED_PACKED;
+        }
+    }
     int nw = h->cfg.waves_per_replica;
     if (nw != 0 && nw != 1 && nw != 2 && nw != 4 && nw != 8)
         return fail(-1, "waves_per_replica must be 0 (auto), 1, 2, 4 or 8");
@@ -415,6 +437,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
     coop_nw = std::min(pow2, 8);
     h->model_threads = coop_nw * 64;
     if (sched == PTNN_SCHED_SPECULATIVE) {
+        h->packed = false;
         // Two waves on one SIMD slow each other ~1.65x (the SGD sweep is VALU-issue bound), so speculation depth comes
         // from more CUs first: G work-groups of 4 waves (one per SIMD) per replica while R*G <= number of CUs, and
         // 8 waves on a single CU otherwise.
@@ -458,7 +481,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
     HIP_TRY(hipMalloc(&h->d_data, packed.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(h->d_data, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
     if (h->seg_lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->speculative ? h->shape->spec : h->shape->seg),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg)),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->seg_lds));
     if (h->model_lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->shape->model), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->model_lds));

@@ -172,16 +172,25 @@ __device__ __forceinline__ void lds_load(const float* __restrict__ p, float (&v)
 // ------------------------------------------------------------------------------------------------
 template <int TASK, int I, int O, int NRED>
 __device__ __forceinline__ void sgd_sweep(const float* __restrict__ w_in, float* __restrict__ w_out,
-                                          const float* __restrict__ xy, int IPY, int Ntr, int H, float lr) {
+                                          const float* __restrict__ xy, int IPY, int Ntr, int H, float lr,
+                                          int ngroups = 1, int gstride = 0) {
     // All weights are kept pre-multiplied by c = -log2(e): the pre-activation then IS the exponent of
     // sigmoid(z) = 1 / (1 + 2^(c z)), and every update rule keeps its shape with lr folded into two constants:
     //   W1' += lr (g' dh) x,  B1' -= lr g' dh      with g' = sum_o od W2'[.,o]  (= c g)
     //   W2' += (c lr) od hid, B2' -= (c lr) od
     // B2' lives negated in lane 0 of a per-lane constant that rides along in the wave reduction of hid * W2'.
+    // Lane groups: the wave is cut into aligned groups of 2^NRED lanes; group g < ngroups runs its OWN sweep on the
+    // vectors at w_in + g gstride -> w_out + g gstride (same data rows for all: the loads stay wave-uniform), so a
+    // 5-unit net fills a wave with 8 independent sweeps at the cost of one.
     constexpr float C = -LOG2E, IC = -LN2;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const bool act = lane < H;
+    const int wlane = threadIdx.x & (WAVE - 1);
+    const int lane = wlane & ((1 << NRED) - 1);                // lane inside its group = hidden unit
+    const int grp = wlane >> NRED;
+    const bool gact = grp < ngroups;
+    const bool act = gact && (lane < H);
     const int hl = act ? lane : 0;
+    w_in += (size_t)(gact ? grp : 0) * gstride;
+    w_out += (size_t)(gact ? grp : 0) * gstride;
     const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
     const float clr = C * lr;
     const float m0 = (lane == 0) ? 1.0f : 0.0f;
@@ -248,7 +257,7 @@ __device__ __forceinline__ void sgd_sweep(const float* __restrict__ w_in, float*
         for (int o = 0; o < O; ++o) w_out[oW2 + lane * O + o] = IC * w2[o];
         w_out[oB1 + lane] = IC * b1;
     }
-    if (lane == 0) {
+    if (lane == 0 && gact) {
 #pragma unroll
         for (int o = 0; o < O; ++o) w_out[oB2 + o] = -IC * cl[o];
     }
@@ -1070,6 +1079,225 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
             p.L_final[gid] = lik;
             post_raw(p, gid, lik, prior_cur, T, step_begin + n_steps - 1);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Packed speculative schedule (H <= 8): the whole round of PK_SLOTS speculative steps lives on ONE CU.  A net with <= 8
+// hidden units uses 8 lanes of a wave, so waves 0 and 1 run the SGD epochs of all 16 slots at once (8 lane groups each,
+// see sgd_sweep) -- for every slot, random-walk ones included, so an accepted step always brings langevin_gradient(new w)
+// with it -- while waves 2 and 3 run the 16 forward passes in the meantime; no work-group of another CU is involved, hence
+// no cross-CU exchange on the critical path.  Per-slot arithmetic is the same code as in segment_spec_kernel, so the
+// committed chain is bit-identical to it (tested).
+// ------------------------------------------------------------------------------------------------
+constexpr int PK_SLOTS = 16, PK_NRED = 3, PK_NG = 8, PK_WAVES = 4, PK_SWEEP_WAVES = 2;
+
+__host__ __device__ inline size_t pack_slot_floats(int PS) { return 3 * (size_t)PS + 8; }
+__host__ __device__ inline size_t pack_lds_floats(int Nall, int IPY, int PS, int H, int FWS) {
+    return (size_t)(Nall + 2) * IPY + 3 * (size_t)PS + MAX_WAVES * 8 + (size_t)PK_SLOTS * SL_COUNT +
+           (size_t)PK_SLOTS * pack_slot_floats(PS) + (size_t)PK_WAVES * (H + 1) * FWS;
+}
+
+template <int TASK, int I, int O>
+__global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const SegParams p, const int step_begin, const int n_steps) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int r = blockIdx.x;
+    const int gid = p.first_global + r;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int Nall = p.Ntr + p.Nte;
+    const int P = p.P, PS = p.PS, H = p.H;
+    float* q = smem;
+    float* xy = q; q += (Nall + 2) * p.IPY;
+    float* w_cur = q; q += PS;
+    float* w_gd = q; q += PS;
+    float* rec_w = q; q += PS;
+    float* red = q; q += MAX_WAVES * 8;
+    float* slots = q; q += PK_SLOTS * SL_COUNT;
+    const size_t SLF = pack_slot_floats(PS);                // per slot: proposal, its SGD epoch, noise, 8 scalars
+    float* sl0 = q; q += PK_SLOTS * SLF;
+    float* my_fw = q + (size_t)wave * (H + 1) * p.FWS;
+    auto s_prop = [&](int s_) { return sl0 + (size_t)s_ * SLF; };
+    auto s_pgd = [&](int s_) { return sl0 + (size_t)s_ * SLF + PS; };
+    auto s_noise = [&](int s_) { return sl0 + (size_t)s_ * SLF + 2 * PS; };
+    auto s_scal = [&](int s_) { return sl0 + (size_t)s_ * SLF + 3 * PS; };
+
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.data);
+        float4* dst = reinterpret_cast<float4*>(xy);
+        for (int e = tid; e < ((Nall + 2) * p.IPY) >> 2; e += nthr) dst[e] = src[e];
+    }
+    float* gw = p.w_state + (size_t)r * PS;
+    for (int j = tid; j < PS; j += nthr) {
+        w_cur[j] = gw[j];
+        rec_w[j] = p.rec_w[(size_t)r * PS + j];
+        w_gd[j] = p.gd_w[(size_t)r * PS + j];
+    }
+    __syncthreads();
+
+    const float T = p.temps[r];
+    float eta = (TASK == TASK_REG) ? w_cur[P] : 0.0f;
+    float* sf = p.st_f + (size_t)r * SF_COUNT;
+    int* si = p.st_i + (size_t)r * SI_COUNT;
+    float lik, prior_cur, tau_eta_last, rec_rmse_tr, rec_rmse_te, rec_acc_tr, rec_acc_te;
+    int nacc, gd_valid, lg_count, lg_acc;
+    if (step_begin == 0) {
+        lg_acc = 0;
+        if (wave == 0) {
+            chain_startup<TASK, I, O, true>(p, xy, w_cur, my_fw, red, T, eta, lik, prior_cur);
+            if (lane == 0) { red[0] = eta; red[1] = lik; red[2] = prior_cur; }
+        }
+        __syncthreads();
+        eta = red[0]; lik = red[1]; prior_cur = red[2];
+        tau_eta_last = eta;
+        rec_rmse_tr = rec_rmse_te = rec_acc_tr = rec_acc_te = 0.f;
+        nacc = 0; gd_valid = 0; lg_count = 0;
+        __syncthreads();
+    } else {
+        lik = sf[SF_LIK]; prior_cur = sf[SF_PRIOR]; tau_eta_last = sf[SF_TAU_LAST];
+        rec_rmse_tr = sf[SF_REC_RMSE_TR]; rec_rmse_te = sf[SF_REC_RMSE_TE];
+        rec_acc_tr = sf[SF_REC_ACC_TR]; rec_acc_te = sf[SF_REC_ACC_TE];
+        nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT]; lg_acc = si[SI_LG_ACC];
+    }
+
+    const size_t trow = (size_t)r * p.trace_cap;
+    const int end = step_begin + n_steps;
+    const bool sweeping = p.use_lg != 0;
+    // forward passes: waves 2,3 while waves 0,1 sweep; all four waves when there is nothing to sweep
+    const int ev_first = sweeping ? PK_SWEEP_WAVES : 0, ev_n = PK_WAVES - ev_first;
+    int i = step_begin;
+    while (i < end) {
+        if (i == p.switch_step) {
+            if (wave == 0) {
+                build_fw<I, O, true>(w_cur, my_fw, H, p.FWS);
+                gsync<true>();
+                const EvalSums sc = eval_rows<TASK, I, O, true>(my_fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, nullptr);
+                float l2, r1, r2, a1, a2;
+                finish_eval<TASK>(sc, p.Ntr, p.Nte, tau_eta_last, l2, r1, r2, a1, a2);
+                if (lane == 0) red[0] = l2;
+            }
+            __syncthreads();
+            lik = red[0];
+            __syncthreads();
+        }
+        int k = min(PK_SLOTS, end - i);
+        if (p.switch_step > i) k = min(k, p.switch_step - i);
+        if (sweeping && !gd_valid) {                       // chain start, or w arrived from another GPU
+            if (wave == 0) sgd_sweep_dispatch<TASK, I, O>(w_cur, w_gd, xy, p.IPY, p.Ntr, H, p.lr);
+            gd_valid = 1;
+            __syncthreads();
+        }
+        // phase 1: random tape and proposal of every slot (slot s = step i + s)
+        for (int s_ = wave; s_ < k; s_ += PK_WAVES) {
+            tape_step<true>(p, gid, i + s_, s_noise(s_), s_scal(s_));
+            gsync<true>();
+            const bool lg = sweeping && (s_scal(s_)[0] < p.l_prob);
+            const float* base = lg ? w_gd : w_cur;
+            float* pr = s_prop(s_);
+            const float* nz = s_noise(s_);
+            for (int e = lane; e < P; e += WAVE) pr[e] = fmaf(p.step_w, nz[e], base[e]);
+            if (lane == 0) slots[s_ * SL_COUNT + SL_LG] = lg ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        // phase 2: SGD epochs of all slots in lane groups || forward passes
+        if (sweeping && wave < PK_SWEEP_WAVES) {
+            const int ng = min(PK_NG, k - wave * PK_NG);
+            if (ng > 0)
+                sgd_sweep<TASK, I, O, PK_NRED>(s_prop(wave * PK_NG), s_pgd(wave * PK_NG), xy, p.IPY, p.Ntr, H, p.lr, ng, (int)SLF);
+        }
+        if (wave >= ev_first) {
+            for (int s_ = wave - ev_first; s_ < k; s_ += ev_n) {
+                const int j = i + s_;
+                const float adapttemp = (p.switch_step >= 0 && j >= p.switch_step) ? 1.0f : T;
+                float eta_pro = eta;
+                if (TASK == TASK_REG) eta_pro = fmaf(p.step_eta, s_scal(s_)[2], eta);
+                build_fw<I, O, true>(s_prop(s_), my_fw, H, p.FWS);
+                gsync<true>();
+                const EvalSums es = eval_rows<TASK, I, O, true>(my_fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, nullptr);
+                float ll, rm_tr, rm_te, ac_tr, ac_te;
+                finish_eval<TASK>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
+                const float ssq = block_sumsq<true>(s_prop(s_), P, nullptr);
+                const float prior_prop = prior_value<TASK>(p, ssq, eta_pro);
+                if (lane == 0) {
+                    float* sl = slots + s_ * SL_COUNT;
+                    sl[SL_LIKPROP] = ll / adapttemp; sl[SL_PRIORPROP] = prior_prop; sl[SL_ETAPRO] = eta_pro;
+                    sl[SL_RM_TR] = rm_tr; sl[SL_RM_TE] = rm_te; sl[SL_AC_TR] = ac_tr; sl[SL_AC_TE] = ac_te;
+                    sl[SL_ADAPT] = adapttemp;
+                }
+                gsync<true>();
+            }
+        }
+        __syncthreads();
+        // phase 3: Metropolis-Hastings ratio of every slot
+        for (int s_ = wave; s_ < k; s_ += PK_WAVES) {
+            float* sl = slots + s_ * SL_COUNT;
+            float diff_prop = 0.0f;
+            if (sl[SL_LG] != 0.0f) {
+                const float d1 = block_sumsq_diff<true>(w_cur, s_pgd(s_), P, nullptr);
+                const float d2 = block_sumsq<true>(s_noise(s_), P, nullptr);
+                diff_prop = (-0.5f * d1 / (p.step_w * p.step_w) + 0.5f * d2) / sl[SL_ADAPT];
+            }
+            const float logalpha = (sl[SL_LIKPROP] - lik) + (sl[SL_PRIORPROP] - prior_cur) + diff_prop;
+            const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
+            if (lane == 0) sl[SL_ACCEPT] = (s_scal(s_)[1] < mh) ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        // commit the prefix up to and including the first accepted step
+        const bool f_acc = (lane < k) && (slots[lane * SL_COUNT + SL_ACCEPT] != 0.0f);
+        const bool f_lg = (lane < k) && (slots[lane * SL_COUNT + SL_LG] != 0.0f);
+        const unsigned long long bal_acc = __ballot(f_acc), bal_lg = __ballot(f_lg);
+        const int m = bal_acc ? (__ffsll((long long)bal_acc) - 1) : k;
+        const int ncommit = (m < k) ? m + 1 : k;
+        for (int s_ = wave; s_ < ncommit; s_ += PK_WAVES) {
+            const bool acc_me = (s_ == m);
+            const float* sl = slots + s_ * SL_COUNT;
+            const float* srcw = acc_me ? s_prop(s_) : rec_w;
+            const size_t tpos = trow + (size_t)((i + s_ + 1) % p.trace_cap);
+            float* prow = p.tr_pos_w + tpos * (size_t)P;
+            for (int e = lane; e < P; e += WAVE) prow[e] = srcw[e];
+            if (lane == 0) {
+                p.tr_likeh[tpos] = (TASK == TASK_REG) ? sl[SL_LIKPROP] : sl[SL_LIKPROP] * sl[SL_ADAPT];
+                p.tr_accept[tpos] = nacc;
+                p.tr_rmse_tr[tpos] = acc_me ? sl[SL_RM_TR] : rec_rmse_tr;
+                p.tr_rmse_te[tpos] = acc_me ? sl[SL_RM_TE] : rec_rmse_te;
+                p.tr_acc_tr[tpos] = acc_me ? sl[SL_AC_TR] : rec_acc_tr;
+                p.tr_acc_te[tpos] = acc_me ? sl[SL_AC_TE] : rec_acc_te;
+            }
+        }
+        lg_count += __popcll(bal_lg & ((1ull << ncommit) - 1ull));
+        if (TASK == TASK_REG) tau_eta_last = slots[(ncommit - 1) * SL_COUNT + SL_ETAPRO];
+        __syncthreads();
+        if (m < k) {
+            const float* sm = slots + m * SL_COUNT;
+            nacc += 1;
+            lik = sm[SL_LIKPROP]; prior_cur = sm[SL_PRIORPROP]; eta = sm[SL_ETAPRO];
+            rec_rmse_tr = sm[SL_RM_TR]; rec_rmse_te = sm[SL_RM_TE]; rec_acc_tr = sm[SL_AC_TR]; rec_acc_te = sm[SL_AC_TE];
+            lg_acc += (sm[SL_LG] != 0.0f) ? 1 : 0;
+            gd_valid = sweeping ? 1 : 0;
+            const float* wacc = s_prop(m);
+            for (int e = tid; e < P; e += nthr) {
+                const float v = wacc[e];
+                w_cur[e] = v; rec_w[e] = v;
+                if (sweeping) w_gd[e] = wacc[PS + e];
+            }
+        }
+        __syncthreads();
+        i += ncommit;
+    }
+
+    for (int j = tid; j < PS; j += nthr) {
+        gw[j] = (j == P) ? eta : w_cur[j];
+        p.rec_w[(size_t)r * PS + j] = rec_w[j];
+        p.gd_w[(size_t)r * PS + j] = w_gd[j];
+    }
+    if (tid == 0) {
+        sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur; sf[SF_TAU_LAST] = tau_eta_last;
+        sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;
+        sf[SF_REC_ACC_TR] = rec_acc_tr; sf[SF_REC_ACC_TE] = rec_acc_te;
+        si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count; si[SI_LG_ACC] = lg_acc;
+        p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;
+        p.L_final[gid] = lik;
+        post_raw(p, gid, lik, prior_cur, T, step_begin + n_steps - 1);
     }
 }
 

@@ -113,7 +113,7 @@ TRAJ = ["reg_rw", "reg_lg", "reg_lg_mackey", "cls_rw", "cls_lg", "cls_rw_ions", 
 
 
 @pytest.mark.parametrize("key", TRAJ)
-@pytest.mark.parametrize("schedule,waves", [(1, 1), (1, 4), (2, 1), (2, 0)])
+@pytest.mark.parametrize("schedule,waves", [(1, 1), (1, 4), (2, 1), (2, 0), (0, 0)])
 def test_single_replica_trajectory(key, schedule, waves):
     """F4: one chain (no swaps) against the trace the reference's ptReplica.run produced on the same random tape."""
     g = parity.golden(f"trajectory_{key}.npz")
@@ -308,7 +308,7 @@ def test_invariants_at_full_size():
     s.close(); s2.close(); s3.close()
 
 
-@pytest.mark.parametrize("case", ["sunspot_lg", "iris_lg", "ions_rw"])
+@pytest.mark.parametrize("case", ["sunspot_lg", "sunspot_rw", "iris_lg", "ions_rw"])
 def test_speculative_schedule_is_wave_count_invariant(case):
     """Slot s = (work-group g, wave v) pre-computes step i+s; only the prefix up to the first accept is committed.  The
     committed chain must not depend on how many steps were speculated nor on how the slots are spread over CUs: every
@@ -316,6 +316,8 @@ def test_speculative_schedule_is_wave_count_invariant(case):
     d = ds()
     if case == "sunspot_lg":
         task, topo, name, lg, lr, R, S, si, mt = 0, (4, 5, 1), "sunspot", True, 0.1, 8, 400, 20, 2
+    elif case == "sunspot_rw":
+        task, topo, name, lg, lr, R, S, si, mt = 0, (4, 5, 1), "sunspot", False, 0.1, 8, 400, 20, 2
     elif case == "iris_lg":
         task, topo, name, lg, lr, R, S, si, mt = 1, (4, 12, 3), "iris", True, 0.01, 6, 300, 10, 10
     else:
@@ -346,6 +348,20 @@ def test_speculative_schedule_is_wave_count_invariant(case):
             assert (got[0][k] == ref[0][k]).all(), (waves, groups, k)
         for k in got[3]:
             assert (got[3][k] == ref[3][k]).all(), (waves, groups, k)
+    if topo[1] <= 8:
+        # the packed schedule (16 slots on one CU, SGD epochs of all slots in lane groups) commits the same chain too
+        s = parity.make_sampler(task, topo, d[name + "_train"], d[name + "_test"], R_local=R, R_global=R, first=0, S=S, si=si,
+                                use_lg=lg, lr=lr, seed=77, schedule=3)
+        s.set_state(w0, T)
+        s.run(-1)
+        s.sync()
+        got = (s.traces(), s.swap_stats(), s.swap_log().copy(), s.state())
+        s.close()
+        assert got[1] == ref[1] and (got[2] == ref[2]).all()
+        for k in got[0]:
+            assert (got[0][k] == ref[0][k]).all(), ("packed", k)
+        for k in got[3]:
+            assert (got[3][k] == ref[3][k]).all(), ("packed", k)
     assert ref is not None
 
 
