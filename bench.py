@@ -258,7 +258,13 @@ def main():
         flops_per_launch = R_PER_GPU * (mh_steps / max(launches, 1)) * (F_STEP if use_lg else 42811)
         # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE, separate runs of this same command, gfx950 FETCH_SIZE x2 correction applied)
-        traffic, kname = None, ("ptnn::segment_spec_kernel<0,4,1>" if (a.schedule != 1) else "ptnn::segment_kernel<0,4,1>")
+        if a.schedule == 1:
+            kname = "ptnn::segment_kernel<0,4,1>"
+        elif a.schedule == 3 or (a.schedule == 0 and use_lg and a.waves == 0 and a.groups == 0):
+            kname = "ptnn::segment_pack_kernel<0,4,1>"          # what schedule 0 resolves to for this workload
+        else:
+            kname = "ptnn::segment_spec_kernel<0,4,1>"
+        traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "current_pmc.json")))
             for kn, e in pmc["kernels"].items():
@@ -284,8 +290,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "valu_tflops": flops_per_launch / avg_launch_s / 1e12 if launches else 0.0,
                          "valu_frac": (flops_per_launch / avg_launch_s / 1e12) / VALU_PEAK_TFLOPS if launches else 0.0,
-                         "traffic_source": "profiles/current_pmc.json (bytes per launch; includes the sc1 granule exchange between "
-                                           "the work-groups of a replica and their polling loads)",
+                         "traffic_source": "profiles/current_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch)",
                          "note": "instruction-issue bound by construction (sequential SGD rows, AI 627 flop/B); the HBM "
                                  "fraction is reported because BASELINE.json asks for it"},
         }
