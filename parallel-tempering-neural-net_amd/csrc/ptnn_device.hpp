@@ -1187,10 +1187,32 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
             gd_valid = 1;
             __syncthreads();
         }
-        // phase 1: random tape and proposal of every slot (slot s = step i + s)
+        // phase 1: random tape and proposal of every slot (slot s = step i + s).  One Philox counter quad per lane:
+        // a wave covers 64 / (quads per step) slots in one pass
+        {
+            const int nq1 = ((P + 3) >> 2) + 1;                 // noise quads + the scalar quad
+            if (nq1 <= WAVE) {
+                const int per_pass = WAVE / nq1, ls = lane / nq1, q_ = lane - ls * nq1;
+                for (int sb = wave * per_pass; sb < k; sb += PK_WAVES * per_pass) {
+                    const int s_ = sb + ls;
+                    if (ls < per_pass && s_ < k) {
+                        const bool sc = (q_ == nq1 - 1);
+                        uint32_t x[4];
+                        philox4x32_10(sc ? 0u : (uint32_t)q_, (uint32_t)(i + s_), (uint32_t)gid, sc ? STREAM_STEP : STREAM_WNOISE,
+                                      p.seed_lo, p.seed_hi, x);
+                        float n0, n1, n2, n3;
+                        box_muller(x[0], x[1], n0, n1);
+                        box_muller(x[2], x[3], n2, n3);
+                        if (sc) { float* sc_ = s_scal(s_); sc_[0] = u23(x[0]); sc_[1] = u23(x[1]); sc_[2] = n2; }
+                        else *reinterpret_cast<float4*>(s_noise(s_) + 4 * q_) = make_float4(n0, n1, n2, n3);
+                    }
+                }
+            } else {
+                for (int s_ = wave; s_ < k; s_ += PK_WAVES) tape_step<true>(p, gid, i + s_, s_noise(s_), s_scal(s_));
+            }
+        }
+        __syncthreads();
         for (int s_ = wave; s_ < k; s_ += PK_WAVES) {
-            tape_step<true>(p, gid, i + s_, s_noise(s_), s_scal(s_));
-            gsync<true>();
             const bool lg = sweeping && (s_scal(s_)[0] < p.l_prob);
             const float* base = lg ? w_gd : w_cur;
             float* pr = s_prop(s_);
