@@ -3,7 +3,7 @@
 // Replaces, for the hot path only, what the reference does with one forked ptReplica process per chain plus the
 // parent's swap loop (REG = multicore-pt-regression/pt_timeseries_regression.py:223-485, 659-771;
 // CLS = multicore-pt-classification/pt_classification.py:232-494, 668-776).
-#include "ptnn_device.hpp"
+#include "ptnn_shapes.hpp"
 #include "../../include/ptnn.h"
 
 #include <algorithm>
@@ -16,16 +16,6 @@
 #include <vector>
 
 using namespace ptnn;
-
-// ---------------------------------------------------------------------------------------------------------------
-// compiled (task, n_in, n_out) shapes.  n_hidden is a run-time value in [1, 64].
-// REG: the shipped time series have 4 lag inputs (REG:916); 5 and 32 cover BASELINE.json's literal [5,H,1] and the
-// synthetic [32,H,1].  CLS: the reference's problem table (CLS:909-995): iris 4/3, ionosphere 34/2, cancer 9/2,
-// wine 11/10, bank 20/2, pendigit 16/10, chess 6/18.
-// ---------------------------------------------------------------------------------------------------------------
-#ifndef PTNN_SHAPES
-#define PTNN_SHAPES(X) X(0, 4, 1) X(0, 5, 1) X(0, 32, 1) X(1, 4, 3) X(1, 34, 2) X(1, 9, 2) X(1, 11, 10) X(1, 20, 2) X(1, 16, 10) X(1, 6, 18)
-#endif
 
 namespace {
 
@@ -47,28 +37,23 @@ int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-typedef void (*seg_fn)(const SegParams, int, int);
-typedef void (*model_fn)(const SegParams, int, const float*, const float*, float*, int, int);
+}  // namespace
 
-struct Shape {
-    int task, I, O;
-    seg_fn seg;
-    seg_fn spec;
-    model_fn model;
-    seg_fn seg_wide;        // 64 < H <= MAX_HIDDEN
-    model_fn model_wide;
-    seg_fn pack;            // H <= 8: packed speculative schedule
-};
+// one table per shape, each defined in its own translation unit (ptnn_shape.hip)
+#define X_DECL(T, I, O) extern "C" const ptnn::Shape ptnn_shape_##T##_##I##_##O;
+PTNN_SHAPES(X_DECL)
+#undef X_DECL
 
-#define X_ENTRY(T, I, O) {T, I, O, &segment_kernel<T, I, O>, &segment_spec_kernel<T, I, O>, &model_kernel<T, I, O>, \
-                          &segment_wide_kernel<T, I, O>, &model_wide_kernel<T, I, O>, &segment_pack_kernel<T, I, O>},
-constexpr int MAX_HIDDEN = MAX_WAVES * WAVE;    // one thread per hidden unit
-const Shape g_shapes[] = {PTNN_SHAPES(X_ENTRY)};
+namespace {
+
+#define X_ENTRY(T, I, O) &ptnn_shape_##T##_##I##_##O,
+const Shape* const g_shapes[] = {PTNN_SHAPES(X_ENTRY)};
 #undef X_ENTRY
+constexpr int MAX_HIDDEN = MAX_WAVES * WAVE;    // wide nets: one thread per hidden unit
 
 const Shape* find_shape(int task, int I, int O) {
-    for (const Shape& s : g_shapes)
-        if (s.task == task && s.I == I && s.O == O) return &s;
+    for (const Shape* s : g_shapes)
+        if (s->task == task && s->I == I && s->O == O) return s;
     return nullptr;
 }
 

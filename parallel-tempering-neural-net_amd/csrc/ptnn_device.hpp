@@ -1829,6 +1829,7 @@ __device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, floa
     return sSrc[R];
 }
 
+#ifndef PTNN_SHAPE_TU      // non-template kernel: defined in the main translation unit only
 // mode bit 0: apply the local moves; bit 1: count the round and log it
 __global__ void swap_kernel(const SwapParams sp, const int round, const int mode) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1871,6 +1872,8 @@ __global__ void swap_kernel(const SwapParams sp, const int round, const int mode
         }
     }
 }
+
+#endif  // PTNN_SHAPE_TU
 
 // ------------------------------------------------------------------------------------------------
 // stand-alone model functions (same device code): mode 0 = evaluate, 1 = langevin_gradient, 2 = tape
