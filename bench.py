@@ -170,6 +170,73 @@ def bench_synthetic512(a):
     s.close()
 
 
+# ------------------------------------------------------------------------------------------------ BASELINE configs 2-4
+# name: (task, topology, data set, replicas, Langevin, lr, maxtemp, swap interval, description)
+OTHER_CONFIGS = {
+    "iris16": (1, (4, 12, 3), "iris", 16, False, 0.01, 10, 100, "BASELINE config 2: Iris FNN 4-12-3, 16 replicas, random-walk"),
+    "mackey64": (0, (4, 10, 1), "mackey", 64, True, 0.1, 2, 100, "BASELINE config 3: Mackey-Glass FNN 4-10-1, 64 replicas, Langevin p=0.5"),
+    "ionosphere256": (1, (34, 50, 2), "ions", 256, False, 0.01, 10, 100,
+                      "BASELINE config 4 shape on one GPU: Ionosphere FNN 34-50-2, 256 replicas, random-walk, swap every 100 steps"),
+}
+
+
+def bench_other_config(a):
+    """Single-GPU measurement of the other BASELINE configs (parity-test cases; same JSON shape as the headline)."""
+    import ptnn_amd
+    from ptnn_amd import _lib, ladder, philox
+    task, topo, dname, R, use_lg, lr, maxtemp, si, desc = OTHER_CONFIGS[a.workload]
+    d = np.load(os.path.join(ROOT, "tests", "golden", "datasets.npz"))
+    train, test = d[dname + "_train"], d[dname + "_test"]
+    Pw = topo[0] * topo[1] + topo[1] * topo[2] + topo[1] + topo[2]
+    K, W = a.steps, a.warmup
+    S = (W + K + 1) * si + 2
+    s = _lib.Sampler(device_id=int(os.environ.get("LOCAL_RANK", "0")), task=task, n_in=topo[0], n_hidden=topo[1], n_out=topo[2],
+                     n_replicas_local=R, n_replicas_global=R, first_global_replica=0, n_samples=S, swap_interval=si,
+                     pt_switch_step=switch_step(S), use_langevin=int(use_lg), waves_per_replica=a.waves, schedule=a.schedule,
+                     groups_per_replica=a.groups, l_prob=0.5, learn_rate=lr, step_w=0.025, step_eta=0.2, sigma_squared=25.0,
+                     seed=SEED, trace_capacity=8 * si if Pw > 500 else 0)
+    s.set_data(train, test)
+    s.set_state(np.stack([philox.initial_weights(SEED, r, Pw) for r in range(R)]), ladder.temperatures(R, maxtemp))
+    drained = 0
+
+    def advance(n_steps):
+        nonlocal drained
+        left = n_steps
+        while left > 0:                                      # drain the trace ring when there is one
+            n = min(left, 4 * si)
+            s.run(n)
+            left -= n
+            if Pw > 500:
+                hi = s.steps_done() + 1
+                s.traces(drained, hi - drained, pos_w=False)
+                drained = hi
+    advance(W * si + (1 if task == 0 else 0))               # REG hands off after step k*si, CLS after step k*si - 1
+    s.sync()
+    s.kernel_time(reset=True)
+    nsw0, tot0, _ = s.swap_stats()
+    t0 = time.perf_counter()
+    advance(K * si)
+    s.sync()
+    dt = time.perf_counter() - t0
+    launches, kms = s.kernel_time()
+    nsw1, tot1, _ = s.swap_stats()
+    value = R * K * si / dt
+    avg_launch_s = kms / max(launches, 1) * 1e-3
+    bytes_per_launch = R * (K * si / max(launches, 1)) * 4 * (Pw + 7) + R * 4 * (Pw + 2)
+    achieved = bytes_per_launch / avg_launch_s / 1e9
+    print(json.dumps({
+        "metric": "MCMC samples/sec (all replicas) + swap-accept rate; " + desc, "value": value, "unit": "samples/s", "n_gpus": 1,
+        "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": f"{dname} data set shipped as tests/golden/datasets.npz ({train.shape[0]}/{test.shape[0]} rows)",
+        "config": {"workload": desc + f"; 1 bench step = 1 swap interval of {si} MH steps", "replicas": R},
+        "swap_accept_pct": 100.0 * (nsw1 - nsw0) / max(tot1 - tot0, 1),
+        "mh_accept_pct": float(100.0 * np.mean(s.state()["num_accepted"]) / max(s.steps_done(), 1)),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
+                     "algorithmic_bytes_per_launch": bytes_per_launch}}), flush=True)
+    s.close()
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -178,7 +245,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rw", action="store_true", help="random-walk proposals only (extra data point)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="sunspot64", choices=["sunspot64", "synthetic512"],
+    ap.add_argument("--workload", default="sunspot64", choices=["sunspot64", "synthetic512", "iris16", "mackey64", "ionosphere256"],
                     help="sunspot64 = the BASELINE metric (default); synthetic512 = BASELINE config 5 shape (FNN 32-512-1, "
                          "1024/256 rows, 128 replicas per GPU, random-walk): the MFMA forward pass, roofline bound 'mfma'")
     ap.add_argument("--bf16", action="store_true", help="synthetic512: forward GEMM operands in bf16")
@@ -197,6 +264,8 @@ def main():
         N = world
     if a.workload == "synthetic512":
         return bench_synthetic512(a)
+    if a.workload in OTHER_CONFIGS:
+        return bench_other_config(a)
     train, test, data_desc = load_sunspot()
     si = SWAP_INTERVAL
     S = (W + K + 1) * si + 2
