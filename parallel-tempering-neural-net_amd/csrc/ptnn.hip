@@ -271,7 +271,7 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
     const int I = cfg->n_in, H = cfg->n_hidden, O = cfg->n_out;
     h->P = I * H + H * O + H + O;
     h->PS = round_up4(h->P + 1);
-    h->IPY = round_up4(I + 1);
+    h->IPY = round_up4(I + 2);                             // x[I], y, then 1 + x[n].x[n-1] for the pipelined SGD epoch
     h->FWS = round_up4(I + 1 + O);
     h->max_rounds = cfg->n_samples / cfg->swap_interval + 2;
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -343,6 +343,11 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
     for (int n = 0; n < Nall; ++n) {
         const float* row = (n < ntr) ? train + (size_t)n * ncols : test + (size_t)(n - ntr) * ncols;
         for (int c = 0; c <= I; ++c) packed[(size_t)n * IPY + c] = row[c];
+        if (n > 0) {                                                 // see sgd_sweep: z[n] = zpart + lhd[n-1] * (1 + x[n].x[n-1])
+            float d = 1.0f;
+            for (int c = 0; c < I; ++c) d = std::fmaf(row[c], packed[(size_t)(n - 1) * IPY + c], d);
+            packed[(size_t)n * IPY + I + 1] = d;
+        }
         if (h->cfg.task == PTNN_TASK_CLS) {
             const float y = row[I];
             if (!(y >= 0.0f) || y >= (float)h->cfg.n_out || y != std::floor(y))

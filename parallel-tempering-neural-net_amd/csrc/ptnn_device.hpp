@@ -165,6 +165,121 @@ __device__ __forceinline__ void lds_load(const float* __restrict__ p, float (&v)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Hand-scheduled SGD rows for the reference's time-series nets (TASK_REG, I = 4, O = 1, lane groups of 8 hidden units).
+// A lone wave issues ONE instruction of any kind per 4 cycles, so the cost of a row is its instruction count; the
+// compiler's version of the loop carries ~38-44 instructions per row (address arithmetic, register copies of the row
+// ring, s_nop in the VALU->DPP and transcendental->use hazard slots).  Here a row is 27 VALU + 1 s_load + 1 s_waitcnt
+// with every hazard slot holding useful work, and 4 scalar instructions of loop control per 3 rows:
+//   * rows come from the global copy of the data image through the scalar cache (wave-uniform address): s_load_dwordx8
+//     puts x0..x3, y, d = 1 + x[n].x[n-1] into SGPRs that feed the VALU directly; ring of three rows A, B, C
+//     (previous, current, next), row n+2 is fetched during row n into the buffer of row n-1;
+//   * the W1/B1 update of row n-1 and the partial pre-activation of row n+1 fill the hazard slots of row n
+//     (deferred update, see sgd_sweep);
+//   * {B2' (lane 0), W2'} and {W1'[0],W1'[1]}, {W1'[2],W1'[3]} are updated with v_pk_fma_f32.
+// Physical registers are fixed (v100-v125, s40-s68) and declared as clobbers; the state enters and leaves through
+// operands.  Processes rows 0 .. 3 iters - 1 and applies the pending update of the last one.
+// Hazards honoured by construction (gfx950): transcendental result -> 1 slot before a non-transcendental use,
+// VALU result -> 2 slots before a DPP read, SMEM result -> s_waitcnt lgkmcnt(0) before use and before the block ends.
+// ------------------------------------------------------------------------------------------------
+#define PTNN_SW_STEP(P0, P2, X4, X5, N0, N1, N2, N3, PLO, ZP, ZN, OFF)                                              \
+    "v_fmac_f32_e32 " ZP ", " X5 ", v110\n"                             /*  z = zp + lhd d                       */ \
+    "v_exp_f32_e32 v117, " ZP "\n"                                                                                  \
+    "v_pk_fma_f32 v[100:101], v[110:111], " P0 ", v[100:101] op_sel_hi:[0,1,1]\n" /* W1[0:1] += lhd x[n-1]       */ \
+    "v_add_f32_e32 v117, 1.0, v117\n"                                                                               \
+    "v_rcp_f32_e32 v107, v117\n"                                        /*  hid                                  */ \
+    "v_pk_fma_f32 v[102:103], v[110:111], " P2 ", v[102:103] op_sel_hi:[0,1,1]\n"                                   \
+    "v_fma_f32 v118, v107, v105, v104\n"                                /*  hid W2 + B2(lane 0)                  */ \
+    "s_load_dwordx8 " PLO ", s[64:65], " OFF "\n"                       /*  row n+2 -> buffer of row n-1         */ \
+    "v_add_f32_e32 v108, v108, v110\n"                                  /*  -B1 += lhd                           */ \
+    "v_fma_f32 " ZN ", " N0 ", v100, v108\n"                            /*  partial z of row n+1 ...             */ \
+    "v_add_f32_dpp v118, v118, v118 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                  \
+    "v_fmac_f32_e32 " ZN ", " N1 ", v101\n"                                                                         \
+    "v_fmac_f32_e32 " ZN ", " N2 ", v102\n"                                                                         \
+    "v_add_f32_dpp v118, v118, v118 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                  \
+    "v_fmac_f32_e32 " ZN ", " N3 ", v103\n"                                                                         \
+    "v_fma_f32 v119, -v107, v107, v107\n"                               /*  hid (1 - hid)                        */ \
+    "v_add_f32_dpp v118, v118, v118 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                      \
+    "v_exp_f32_e32 v117, v118\n"                                                                                    \
+    "v_mul_f32_e32 v120, s67, v119\n"                                   /*  lr hid (1 - hid)                     */ \
+    "v_add_f32_e32 v117, 1.0, v117\n"                                                                               \
+    "v_rcp_f32_e32 v121, v117\n"                                        /*  out                                  */ \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                        \
+    "v_sub_f32_e32 v122, " X4 ", v121\n"                                /*  y - out                              */ \
+    "v_fma_f32 v123, -v121, v121, v121\n"                                                                           \
+    "v_mul_f32_e32 v124, v122, v123\n"                                  /*  od                                   */ \
+    "v_mul_f32_e32 v125, v124, v105\n"                                  /*  g' = od W2' (pre-update)             */ \
+    "v_mul_f32_e32 v112, s68, v124\n"                                   /*  (c lr) od                            */ \
+    "v_mul_f32_e32 v110, v125, v120\n"                                  /*  lhd                                  */ \
+    "v_pk_fma_f32 v[104:105], v[112:113], v[106:107], v[104:105] op_sel_hi:[0,1,1]\n" /* {B2',W2'} += lod {m0,hid} */
+
+__device__ __forceinline__ void sweep_rows_reg41(float (&w1)[4], float& nb1, float& w2, float& cl, float m0, float lr,
+                                                 float clr, const float* gdata, int iters) {
+    const unsigned long long gp = (unsigned long long)(uintptr_t)gdata;
+    const unsigned end_lo = (unsigned)gp + (unsigned)iters * 96u;      // low word of the running pointer after the last pass
+    const float lr_u = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lr)));
+    const float clr_u = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, clr)));
+    float o0, o1, o2, o3, onb, ow2, ocl;
+    asm volatile(
+        "s_mov_b64 s[64:65], %[gp]\n"
+        "s_mov_b32 s66, %[endlo]\n"
+        "s_mov_b32 s67, %[lr]\n"
+        "s_mov_b32 s68, %[clr]\n"
+        "s_load_dwordx8 s[48:55], s[64:65], 0x0\n"                      // B = row 0
+        "s_load_dwordx8 s[56:63], s[64:65], 0x20\n"                     // C = row 1
+        "s_mov_b64 s[40:41], 0\n"                                       // A: nothing to apply yet
+        "s_mov_b64 s[42:43], 0\n"
+        "v_mov_b32_e32 v100, %[w0]\n"
+        "v_mov_b32_e32 v101, %[w1]\n"
+        "v_mov_b32_e32 v102, %[w2]\n"
+        "v_mov_b32_e32 v103, %[w3]\n"
+        "v_mov_b32_e32 v104, %[cl]\n"
+        "v_mov_b32_e32 v105, %[v2]\n"
+        "v_mov_b32_e32 v106, %[m0]\n"
+        "v_mov_b32_e32 v107, 0\n"
+        "v_mov_b32_e32 v108, %[nb]\n"
+        "v_mov_b32_e32 v110, 0\n"
+        "v_mov_b32_e32 v111, 0\n"
+        "v_mov_b32_e32 v113, 0\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_fma_f32 v114, s48, v100, v108\n"
+        "v_fmac_f32_e32 v114, s49, v101\n"
+        "v_fmac_f32_e32 v114, s50, v102\n"
+        "v_fmac_f32_e32 v114, s51, v103\n"
+        "L_ptnn_sweep_%=:\n"
+        PTNN_SW_STEP("s[40:41]", "s[42:43]", "s52", "s53", "s56", "s57", "s58", "s59", "s[40:47]", "v114", "v115", "0x40")
+        PTNN_SW_STEP("s[48:49]", "s[50:51]", "s60", "s61", "s40", "s41", "s42", "s43", "s[48:55]", "v115", "v116", "0x60")
+        PTNN_SW_STEP("s[56:57]", "s[58:59]", "s44", "s45", "s48", "s49", "s50", "s51", "s[56:63]", "v116", "v114", "0x80")
+        "s_add_u32 s64, s64, 0x60\n"
+        "s_addc_u32 s65, s65, 0\n"
+        "s_cmp_lg_u32 s64, s66\n"
+        "s_cbranch_scc1 L_ptnn_sweep_%=\n"
+        // the update of the last row (its inputs are in A) is still pending
+        "v_pk_fma_f32 v[100:101], v[110:111], s[40:41], v[100:101] op_sel_hi:[0,1,1]\n"
+        "v_pk_fma_f32 v[102:103], v[110:111], s[42:43], v[102:103] op_sel_hi:[0,1,1]\n"
+        "v_add_f32_e32 v108, v108, v110\n"
+        "s_nop 1\n"
+        "v_mov_b32_e32 %[o0], v100\n"
+        "v_mov_b32_e32 %[o1], v101\n"
+        "v_mov_b32_e32 %[o2], v102\n"
+        "v_mov_b32_e32 %[o3], v103\n"
+        "v_mov_b32_e32 %[ocl], v104\n"
+        "v_mov_b32_e32 %[ow2], v105\n"
+        "v_mov_b32_e32 %[onb], v108\n"
+        : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [onb] "=&v"(onb), [ow2] "=&v"(ow2), [ocl] "=&v"(ocl)
+        : [gp] "s"(gp), [endlo] "s"(end_lo), [lr] "s"(lr_u), [clr] "s"(clr_u), [w0] "v"(w1[0]), [w1] "v"(w1[1]),
+          [w2] "v"(w1[2]), [w3] "v"(w1[3]), [cl] "v"(cl), [v2] "v"(w2), [m0] "v"(m0), [nb] "v"(nb1)
+        : "memory", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
+          "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125",
+          "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+          "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68");
+    w1[0] = o0; w1[1] = o1; w1[2] = o2; w1[3] = o3; nb1 = onb; w2 = ow2; cl = ocl;
+}
+
+// row stride of the data image in floats: x[0..I-1], y, 1 + x[n].x[n-1] (see sgd_sweep), padded to a multiple of 4
+__host__ __device__ constexpr int sweep_row_stride(int I) { return (I + 2 + 3) & ~3; }
+typedef __attribute__((address_space(4))) float cfloat;    // constant address space: uniform loads become s_load
+
+// ------------------------------------------------------------------------------------------------
 // R5  Network.langevin_gradient (REG:99-118 / CLS:114-132) on wave 0: lane h owns hidden unit h
 // (column h of W1, row h of W2, B1[h]); B2 and the outputs are replicated in every lane.  Rows are visited
 // in file order, each row is a dependent chain; the next row's inputs are fetched while this one computes.
@@ -172,8 +287,8 @@ __device__ __forceinline__ void lds_load(const float* __restrict__ p, float (&v)
 // ------------------------------------------------------------------------------------------------
 template <int TASK, int I, int O, int NRED>
 __device__ __forceinline__ void sgd_sweep(const float* __restrict__ w_in, float* __restrict__ w_out,
-                                          const float* __restrict__ xy, int IPY, int Ntr, int H, float lr,
-                                          int ngroups = 1, int gstride = 0) {
+                                          const float* __restrict__ xy, const float* __restrict__ gdata, int Ntr, int H,
+                                          float lr, int ngroups = 1, int gstride = 0) {
     // All weights are kept pre-multiplied by c = -log2(e): the pre-activation then IS the exponent of
     // sigmoid(z) = 1 / (1 + 2^(c z)), and every update rule keeps its shape with lr folded into two constants:
     //   W1' += lr (g' dh) x,  B1' -= lr g' dh      with g' = sum_o od W2'[.,o]  (= c g)
@@ -203,11 +318,41 @@ __device__ __forceinline__ void sgd_sweep(const float* __restrict__ w_in, float*
 #pragma unroll
     for (int o = 0; o < O; ++o) cl[o] = (lane == 0) ? -C * w_in[oB2 + o] : 0.0f;
 
-    auto row_step = [&](const float (&x)[I + 1]) {
-        float z = fmaf(x[0], w1[0], -b1);
+    // A lone wave issues one instruction (of any kind) per 4 cycles, so the epoch costs (instructions per row) x 4 cycles
+    // and every hazard slot (VALU -> DPP needs two, transcendental -> use one) that holds no useful instruction is lost.
+    // The row chain is therefore software-pipelined so that it carries independent work: the W1/B1 update of row n-1 is
+    // applied DURING row n, and the pre-activation of row n+1 is started from the weights of row n-1,
+    //     z[n+1] = (x[n+1] . W1[n-1] - B1[n-1])  +  lhd[n] (x[n+1] . x[n] + 1),
+    // the second factor being a property of the data (column I+1 of the image, filled by the host).  Exact algebra; the
+    // rounding differs from the plain chain by O(eps).
+    constexpr int RW = I + 2;
+    float nb1 = -b1;
+    float lhd_p = 0.0f, zp;
+    auto zpart = [&](const float (&x)[RW]) {
+        float z = fmaf(x[0], w1[0], nb1);
 #pragma unroll
         for (int i = 1; i < I; ++i) z = fmaf(x[i], w1[i], z);
-        const float hid = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
+        return z;
+    };
+    constexpr int IPY = sweep_row_stride(I);
+    int n = 0;
+    if constexpr (TASK == TASK_REG && I == 4 && O == 1 && NRED == 3) {
+        // the reference's time-series nets (4 lags -> <= 8 hidden units -> 1 output): rows 0 .. 3 floor(Ntr/3) - 1 in a
+        // hand-scheduled loop (sweep_rows_reg41), whatever is left by the generic code below
+        const int iters = Ntr / 3;
+        if (iters > 0) {
+            sweep_rows_reg41(w1, nb1, w2[0], cl[0], m0, lr, clr, gdata, iters);
+            n = 3 * iters;
+        }
+    }
+    auto row_step = [&](const float (&xprev)[RW], const float (&x)[RW], const float (&xnext)[RW]) {
+        const float z = fmaf(lhd_p, x[I + 1], zp);
+        const float e = __builtin_amdgcn_exp2f(z);
+#pragma unroll
+        for (int i = 0; i < I; ++i) w1[i] = fmaf(lhd_p, xprev[i], w1[i]);     // row n-1's update
+        nb1 += lhd_p;
+        zp = zpart(xnext);
+        const float hid = __builtin_amdgcn_rcpf(1.0f + e);
         const float dh = fmaf(-hid, hid, hid);                 // hid (1 - hid)
         const float ldh = lr * dh;
         float g = 0.0f;
@@ -223,32 +368,63 @@ __device__ __forceinline__ void sgd_sweep(const float* __restrict__ w_in, float*
             g = fmaf(od, w2[o], g);                                      // pre-update W2 (Q4)
             lod[o] = clr * od;
         }
-        const float lhd = g * ldh;
+        lhd_p = g * ldh;
 #pragma unroll
         for (int o = 0; o < O; ++o) {
             w2[o] = fmaf(lod[o], hid, w2[o]);
             cl[o] = fmaf(lod[o], m0, cl[o]);
         }
-#pragma unroll
-        for (int i = 0; i < I; ++i) w1[i] = fmaf(lhd, x[i], w1[i]);
-        b1 -= lhd;
     };
 
-    // two rows in flight: while one is computed the other's inputs (and the row after) are already on their way.
-    // The data image carries two padding rows, so the look-ahead never leaves it.
-    float xa[I + 1], xb[I + 1];
-    lds_load<I + 1>(xy, xa);
-    lds_load<I + 1>(xy + IPY, xb);
-    const float* pr = xy + 2 * IPY;
-    int n = 0;
-    for (; n + 1 < Ntr; n += 2) {
-        row_step(xa);
-        lds_load<I + 1>(pr, xa);
-        row_step(xb);
-        lds_load<I + 1>(pr + IPY, xb);
-        pr += 2 * IPY;
+    // ring of four row buffers: previous, current, next, and the one being fetched (row n+2).  The data image carries
+    // two padding rows, so the look-ahead never leaves it.
+    float xa[RW], xb[RW], xc[RW], xd[RW];
+    const float* pr = xy + (size_t)n * IPY;
+    lds_load<RW>(pr, xb);
+    lds_load<RW>(pr + IPY, xc);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) xa[i] = 0.0f;
+    zp = zpart(xb);
+    pr += 2 * IPY;
+    for (; n + 3 < Ntr; n += 4) {
+        lds_load<RW>(pr, xd);
+        row_step(xa, xb, xc);
+        lds_load<RW>(pr + IPY, xa);
+        row_step(xb, xc, xd);
+        lds_load<RW>(pr + 2 * IPY, xb);
+        row_step(xc, xd, xa);
+        lds_load<RW>(pr + 3 * IPY, xc);
+        row_step(xd, xa, xb);
+        pr += 4 * IPY;
     }
-    if (n < Ntr) row_step(xa);
+    // tail: up to three rows; afterwards the update of the very last row is still pending
+    float xl[RW];
+    const int rem = Ntr - n;
+    if (rem == 0) {
+#pragma unroll
+        for (int i = 0; i < RW; ++i) xl[i] = xa[i];
+    } else if (rem == 1) {
+        row_step(xa, xb, xc);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) xl[i] = xb[i];
+    } else if (rem == 2) {
+        lds_load<RW>(pr, xd);
+        row_step(xa, xb, xc);
+        row_step(xb, xc, xd);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) xl[i] = xc[i];
+    } else {
+        lds_load<RW>(pr, xd);
+        row_step(xa, xb, xc);
+        lds_load<RW>(pr + IPY, xa);
+        row_step(xb, xc, xd);
+        row_step(xc, xd, xa);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) xl[i] = xd[i];
+    }
+#pragma unroll
+    for (int i = 0; i < I; ++i) w1[i] = fmaf(lhd_p, xl[i], w1[i]);
+    b1 = -(nb1 + lhd_p);
 
     if (act) {
 #pragma unroll
@@ -264,13 +440,13 @@ __device__ __forceinline__ void sgd_sweep(const float* __restrict__ w_in, float*
 }
 
 template <int TASK, int I, int O>
-__device__ __forceinline__ void sgd_sweep_dispatch(const float* w_in, float* w_out, const float* xy, int IPY, int Ntr,
+__device__ __forceinline__ void sgd_sweep_dispatch(const float* w_in, float* w_out, const float* xy, const float* gdata, int Ntr,
                                                    int H, float lr) {
-    if (H <= 4) sgd_sweep<TASK, I, O, 2>(w_in, w_out, xy, IPY, Ntr, H, lr);
-    else if (H <= 8) sgd_sweep<TASK, I, O, 3>(w_in, w_out, xy, IPY, Ntr, H, lr);
-    else if (H <= 16) sgd_sweep<TASK, I, O, 4>(w_in, w_out, xy, IPY, Ntr, H, lr);
-    else if (H <= 32) sgd_sweep<TASK, I, O, 5>(w_in, w_out, xy, IPY, Ntr, H, lr);
-    else sgd_sweep<TASK, I, O, 6>(w_in, w_out, xy, IPY, Ntr, H, lr);
+    if (H <= 4) sgd_sweep<TASK, I, O, 2>(w_in, w_out, xy, gdata, Ntr, H, lr);
+    else if (H <= 8) sgd_sweep<TASK, I, O, 3>(w_in, w_out, xy, gdata, Ntr, H, lr);
+    else if (H <= 16) sgd_sweep<TASK, I, O, 4>(w_in, w_out, xy, gdata, Ntr, H, lr);
+    else if (H <= 32) sgd_sweep<TASK, I, O, 5>(w_in, w_out, xy, gdata, Ntr, H, lr);
+    else sgd_sweep<TASK, I, O, 6>(w_in, w_out, xy, gdata, Ntr, H, lr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -644,13 +820,13 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
             // Langevin proposal (REG:329-347): w_gd = SGD epoch from w (cached while w is unchanged),
             // w_proposal = w_gd + step_w * noise, w_prop_gd = SGD epoch from w_proposal
             if (!gd_valid) {
-                if (tid < WAVE) sgd_sweep_dispatch<TASK, I, O>(l.w_cur, l.w_gd, l.xy, p.IPY, p.Ntr, H, p.lr);
+                if (tid < WAVE) sgd_sweep_dispatch<TASK, I, O>(l.w_cur, l.w_gd, l.xy, p.data, p.Ntr, H, p.lr);
                 gd_valid = 1;
                 __syncthreads();
             }
             for (int j = tid; j < P; j += nthr) l.w_prop[j] = fmaf(p.step_w, l.noise[j], l.w_gd[j]);
             __syncthreads();
-            if (tid < WAVE) sgd_sweep_dispatch<TASK, I, O>(l.w_prop, l.w_pgd, l.xy, p.IPY, p.Ntr, H, p.lr);
+            if (tid < WAVE) sgd_sweep_dispatch<TASK, I, O>(l.w_prop, l.w_pgd, l.xy, p.data, p.Ntr, H, p.lr);
             __syncthreads();
             // first - second = [-0.5 |w - w_prop_gd|^2 + 0.5 |w_proposal - w_gd|^2] / step_w^2; the second norm is
             // step_w^2 |noise|^2 exactly in real arithmetic
@@ -908,7 +1084,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
         if (p.use_lg && !gd_valid) {
             // w_gd = langevin_gradient(w) is missing (chain start, or w arrived from another GPU): every work-group
             // recomputes it for itself.  Decided from state all groups share, so they all take this branch together.
-            if (wave == 0) sgd_sweep_dispatch<TASK, I, O>(w_cur, w_gd, xy, p.IPY, p.Ntr, H, p.lr);
+            if (wave == 0) sgd_sweep_dispatch<TASK, I, O>(w_cur, w_gd, xy, p.data, p.Ntr, H, p.lr);
             gd_valid = 1;
             __syncthreads();
         }
@@ -921,7 +1097,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
             if (lg) {
                 for (int e = lane; e < P; e += WAVE) my_prop[e] = fmaf(p.step_w, my_noise[e], w_gd[e]);
                 gsync<true>();
-                sgd_sweep_dispatch<TASK, I, O>(my_prop, my_pgd, xy, p.IPY, p.Ntr, H, p.lr);
+                sgd_sweep_dispatch<TASK, I, O>(my_prop, my_pgd, xy, p.data, p.Ntr, H, p.lr);
                 gsync<true>();
                 const float d1 = block_sumsq_diff<true>(w_cur, my_pgd, P, nullptr);
                 const float d2 = block_sumsq<true>(my_noise, P, nullptr);
@@ -948,7 +1124,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
             if (p.use_lg && !lg && acc_mine) {
                 // an accepted random-walk step: run the SGD epoch from its proposal now, so langevin_gradient(new w)
                 // is already there when the step is committed (the Langevin waves of this round are sweeping anyway)
-                sgd_sweep_dispatch<TASK, I, O>(my_prop, my_pgd, xy, p.IPY, p.Ntr, H, p.lr);
+                sgd_sweep_dispatch<TASK, I, O>(my_prop, my_pgd, xy, p.data, p.Ntr, H, p.lr);
                 gsync<true>();
             }
             if (lane == 0) {
@@ -1160,6 +1336,14 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
         nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT]; lg_acc = si[SI_LG_ACC];
     }
 
+#ifdef PTNN_STAMPS
+    const bool stamp_on = (blockIdx.x == 0 && wave == 0);
+    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    unsigned long long stamp_rounds = 0, stamp_eval = 0;
+    const unsigned long long stamp_t0 = stamp_last;
+#endif
     const size_t trow = (size_t)r * p.trace_cap;
     const int end = step_begin + n_steps;
     const bool sweeping = p.use_lg != 0;
@@ -1182,8 +1366,12 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
         }
         int k = min(PK_SLOTS, end - i);
         if (p.switch_step > i) k = min(k, p.switch_step - i);
+#ifdef PTNN_STAMPS
+        stamp_rounds += 1;
+#endif
+        STAMP(0);
         if (sweeping && !gd_valid) {                       // chain start, or w arrived from another GPU
-            if (wave == 0) sgd_sweep_dispatch<TASK, I, O>(w_cur, w_gd, xy, p.IPY, p.Ntr, H, p.lr);
+            if (wave == 0) sgd_sweep_dispatch<TASK, I, O>(w_cur, w_gd, xy, p.data, p.Ntr, H, p.lr);
             gd_valid = 1;
             __syncthreads();
         }
@@ -1212,6 +1400,7 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
             }
         }
         __syncthreads();
+        STAMP(1);                                           // tape
         for (int s_ = wave; s_ < k; s_ += PK_WAVES) {
             const bool lg = sweeping && (s_scal(s_)[0] < p.l_prob);
             const float* base = lg ? w_gd : w_cur;
@@ -1221,12 +1410,17 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
             if (lane == 0) slots[s_ * SL_COUNT + SL_LG] = lg ? 1.0f : 0.0f;
         }
         __syncthreads();
+        STAMP(2);                                           // proposal
         // phase 2: SGD epochs of all slots in lane groups || forward passes
         if (sweeping && wave < PK_SWEEP_WAVES) {
             const int ng = min(PK_NG, k - wave * PK_NG);
             if (ng > 0)
-                sgd_sweep<TASK, I, O, PK_NRED>(s_prop(wave * PK_NG), s_pgd(wave * PK_NG), xy, p.IPY, p.Ntr, H, p.lr, ng, (int)SLF);
+                sgd_sweep<TASK, I, O, PK_NRED>(s_prop(wave * PK_NG), s_pgd(wave * PK_NG), xy, p.data, p.Ntr, H, p.lr, ng, (int)SLF);
         }
+        STAMP(3);                                           // sweep
+#ifdef PTNN_STAMPS
+        const unsigned long long ev_t0 = __builtin_amdgcn_s_memtime();
+#endif
         if (wave >= ev_first) {
             for (int s_ = wave - ev_first; s_ < k; s_ += ev_n) {
                 const int j = i + s_;
@@ -1249,7 +1443,11 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
                 gsync<true>();
             }
         }
+#ifdef PTNN_STAMPS
+        if (wave == ev_first) stamp_eval += __builtin_amdgcn_s_memtime() - ev_t0;
+#endif
         __syncthreads();
+        STAMP(4);                                           // waiting for the forward passes
         // phase 3: Metropolis-Hastings ratio of every slot
         for (int s_ = wave; s_ < k; s_ += PK_WAVES) {
             float* sl = slots + s_ * SL_COUNT;
@@ -1264,6 +1462,7 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
             if (lane == 0) sl[SL_ACCEPT] = (s_scal(s_)[1] < mh) ? 1.0f : 0.0f;
         }
         __syncthreads();
+        STAMP(5);                                           // MH
         // commit the prefix up to and including the first accepted step
         const bool f_acc = (lane < k) && (slots[lane * SL_COUNT + SL_ACCEPT] != 0.0f);
         const bool f_lg = (lane < k) && (slots[lane * SL_COUNT + SL_LG] != 0.0f);
@@ -1305,7 +1504,20 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
         }
         __syncthreads();
         i += ncommit;
+        STAMP(6);                                           // commit
     }
+#ifdef PTNN_STAMPS
+    if (stamp_on && lane == 0 && p.stamps) {
+        for (int q_ = 0; q_ < 9; ++q_) atomicAdd(p.stamps + q_, stamp_acc[q_]);
+        atomicAdd(p.stamps + 9, stamp_rounds);
+        atomicAdd(p.stamps + 10, __builtin_amdgcn_s_memtime() - stamp_t0);
+    }
+    if (blockIdx.x == 0 && wave == ev_first && lane == 0 && p.stamps) atomicAdd(p.stamps + 11, stamp_eval);
+    if (tid == 0 && p.stamps && r < 64) {
+        atomicAdd(p.stamps + 16 + 2 * r, __builtin_amdgcn_s_memtime() - stamp_t0);
+        atomicAdd(p.stamps + 17 + 2 * r, stamp_rounds);
+    }
+#endif
 
     for (int j = tid; j < PS; j += nthr) {
         gw[j] = (j == P) ? eta : w_cur[j];
@@ -1900,7 +2112,7 @@ __global__ void __launch_bounds__(MAX_THREADS) model_kernel(const SegParams p, c
     for (int j = tid; j < p.P; j += nthr) l.w_cur[j] = w_in[(size_t)b * p.P + j];
     __syncthreads();
     if (mode == 1) {
-        if (tid < WAVE) sgd_sweep_dispatch<TASK, I, O>(l.w_cur, l.w_gd, l.xy, p.IPY, p.Ntr, p.H, p.lr);
+        if (tid < WAVE) sgd_sweep_dispatch<TASK, I, O>(l.w_cur, l.w_gd, l.xy, p.data, p.Ntr, p.H, p.lr);
         __syncthreads();
         for (int j = tid; j < p.P; j += nthr) out[(size_t)b * p.P + j] = l.w_gd[j];
         return;

@@ -27,3 +27,17 @@ for k in (16, 32, 64):
     print(f"k={k}: rounds per interval: mean over replicas {per.mean():.2f}, replica 0 {per[:,0].mean():.2f}; max over replicas: mean {mx.mean():.2f} median {np.median(mx):.1f} min {mx.min()} max {mx.max()}; argmax histogram (top 8):", np.bincount(per.argmax(axis=1), minlength=64).argsort()[::-1][:8].tolist())
 A = np.array([[flags[r, 1001 + i*100: 1101 + i*100].sum() for r in range(64)] for i in range(100)])
 print("accepts per interval: mean over replicas %.2f, max over replicas mean %.2f, overall max %d" % (A.mean(), A.max(axis=1).mean(), A.max()))
+
+# dataflow schedule: replica j may start interval t+1 once replicas 0..j+1 have finished interval t (the bubble pass decides
+# pair (k,k+1) from positions <= k+1 only).  Longest path through that DAG vs the synchronous barrier, in rounds of 16 slots.
+per = np.array([[rounds_for(flags[r, 1001 + it * 100: 1101 + it * 100], 16) for r in range(64)] for it in range(100)], dtype=np.float64)
+F = np.zeros(64)
+for t in range(100):
+    M = np.maximum.accumulate(F)                       # M[j] = max_{i<=j} F[i]
+    need = np.concatenate([M[1:], M[-1:]])             # max over 0..j+1
+    F = need + per[t]
+print("k=16: barrier schedule %.1f rounds per interval (sum of per-interval maxima / 100); dataflow schedule %.1f; replica 0 alone %.1f; mean replica %.1f"
+      % (per.max(axis=1).sum() / 100, F.max() / 100, per[:, 0].sum() / 100, per.mean()))
+for lag in (1, 2, 4):
+    # variant: swap decisions made on L that is `lag` intervals old is NOT the reference's algorithm; not evaluated
+    pass
