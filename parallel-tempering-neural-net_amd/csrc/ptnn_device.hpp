@@ -1350,6 +1350,8 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
     // forward passes: waves 2,3 while waves 0,1 sweep; all four waves when there is nothing to sweep
     const int ev_first = sweeping ? PK_SWEEP_WAVES : 0, ev_n = PK_WAVES - ev_first;
     int i = step_begin;
+    int tpos0 = (step_begin + 1) % p.trace_cap;            // ring position of the trace row of step i
+    const float inv_P = 1.0f / (float)P;
     while (i < end) {
         if (i == p.switch_step) {
             if (wave == 0) {
@@ -1401,13 +1403,11 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
         }
         __syncthreads();
         STAMP(1);                                           // tape
-        for (int s_ = wave; s_ < k; s_ += PK_WAVES) {
+        for (int item = tid; item < k * P; item += nthr) {  // all (slot, element) pairs at once
+            const int s_ = (int)(((float)item + 0.5f) * inv_P), e = item - s_ * P;
             const bool lg = sweeping && (s_scal(s_)[0] < p.l_prob);
-            const float* base = lg ? w_gd : w_cur;
-            float* pr = s_prop(s_);
-            const float* nz = s_noise(s_);
-            for (int e = lane; e < P; e += WAVE) pr[e] = fmaf(p.step_w, nz[e], base[e]);
-            if (lane == 0) slots[s_ * SL_COUNT + SL_LG] = lg ? 1.0f : 0.0f;
+            s_prop(s_)[e] = fmaf(p.step_w, s_noise(s_)[e], (lg ? w_gd : w_cur)[e]);
+            if (e == 0) slots[s_ * SL_COUNT + SL_LG] = lg ? 1.0f : 0.0f;
         }
         __syncthreads();
         STAMP(2);                                           // proposal
@@ -1449,17 +1449,35 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
         __syncthreads();
         STAMP(4);                                           // waiting for the forward passes
         // phase 3: Metropolis-Hastings ratio of every slot
-        for (int s_ = wave; s_ < k; s_ += PK_WAVES) {
-            float* sl = slots + s_ * SL_COUNT;
+        // one 16-lane row per slot, all 16 slots at once.  The two sums of squares are taken in the association order of
+        // block_sumsq<true> (element j in lane j of a wave: rows of 16, then (row0 + row1) + (row2 + row3)), so the
+        // decision is bit-identical to the one-wave-per-slot schedule.
+        {
+            const int s_ = wave * (WAVE / 16) + (lane >> 4), l16 = lane & 15;
+            const bool on = s_ < k;
+            float* sl = slots + (on ? s_ : 0) * SL_COUNT;
             float diff_prop = 0.0f;
-            if (sl[SL_LG] != 0.0f) {
-                const float d1 = block_sumsq_diff<true>(w_cur, s_pgd(s_), P, nullptr);
-                const float d2 = block_sumsq<true>(s_noise(s_), P, nullptr);
-                diff_prop = (-0.5f * d1 / (p.step_w * p.step_w) + 0.5f * d2) / sl[SL_ADAPT];
+            if (sweeping) {
+                const float* pg = s_pgd(on ? s_ : 0);
+                const float* nz = s_noise(on ? s_ : 0);
+                float r1[4], r2[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {                 // row c of the wave layout: elements 16 c + l16 (+ 64 t)
+                    float a1 = 0.0f, a2 = 0.0f;
+                    for (int e = 16 * c + l16; e < P; e += WAVE) {
+                        const float d = w_cur[e] - pg[e], z = nz[e];
+                        a1 = fmaf(d, d, a1);
+                        a2 = fmaf(z, z, a2);
+                    }
+                    r1[c] = group_allsum<4>(a1);
+                    r2[c] = group_allsum<4>(a2);
+                }
+                const float d1 = (r1[0] + r1[1]) + (r1[2] + r1[3]), d2 = (r2[0] + r2[1]) + (r2[2] + r2[3]);
+                if (sl[SL_LG] != 0.0f) diff_prop = (-0.5f * d1 / (p.step_w * p.step_w) + 0.5f * d2) / sl[SL_ADAPT];
             }
             const float logalpha = (sl[SL_LIKPROP] - lik) + (sl[SL_PRIORPROP] - prior_cur) + diff_prop;
             const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
-            if (lane == 0) sl[SL_ACCEPT] = (s_scal(s_)[1] < mh) ? 1.0f : 0.0f;
+            if (on && l16 == 0) sl[SL_ACCEPT] = (s_scal(s_)[1] < mh) ? 1.0f : 0.0f;
         }
         __syncthreads();
         STAMP(5);                                           // MH
@@ -1469,14 +1487,20 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
         const unsigned long long bal_acc = __ballot(f_acc), bal_lg = __ballot(f_lg);
         const int m = bal_acc ? (__ffsll((long long)bal_acc) - 1) : k;
         const int ncommit = (m < k) ? m + 1 : k;
-        for (int s_ = wave; s_ < ncommit; s_ += PK_WAVES) {
+        for (int item = tid; item < ncommit * P; item += nthr) {     // trace rows: all (slot, element) pairs at once
+            const int s_ = (int)(((float)item + 0.5f) * inv_P), e = item - s_ * P;
+            int tp = tpos0 + s_;
+            if (tp >= p.trace_cap) tp -= p.trace_cap;
+            p.tr_pos_w[(trow + (size_t)tp) * (size_t)P + e] = ((s_ == m) ? s_prop(s_) : rec_w)[e];
+        }
+        if (tid < ncommit) {
+            const int s_ = tid;
             const bool acc_me = (s_ == m);
             const float* sl = slots + s_ * SL_COUNT;
-            const float* srcw = acc_me ? s_prop(s_) : rec_w;
-            const size_t tpos = trow + (size_t)((i + s_ + 1) % p.trace_cap);
-            float* prow = p.tr_pos_w + tpos * (size_t)P;
-            for (int e = lane; e < P; e += WAVE) prow[e] = srcw[e];
-            if (lane == 0) {
+            int tp = tpos0 + s_;
+            if (tp >= p.trace_cap) tp -= p.trace_cap;
+            const size_t tpos = trow + (size_t)tp;
+            {
                 p.tr_likeh[tpos] = (TASK == TASK_REG) ? sl[SL_LIKPROP] : sl[SL_LIKPROP] * sl[SL_ADAPT];
                 p.tr_accept[tpos] = nacc;
                 p.tr_rmse_tr[tpos] = acc_me ? sl[SL_RM_TR] : rec_rmse_tr;
@@ -1504,6 +1528,8 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
         }
         __syncthreads();
         i += ncommit;
+        tpos0 += ncommit;
+        if (tpos0 >= p.trace_cap) tpos0 -= p.trace_cap;
         STAMP(6);                                           // commit
     }
 #ifdef PTNN_STAMPS
