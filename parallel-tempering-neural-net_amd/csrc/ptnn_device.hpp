@@ -168,94 +168,104 @@ __device__ __forceinline__ void lds_load(const float* __restrict__ p, float (&v)
 // Hand-scheduled SGD rows for the reference's time-series nets (TASK_REG, I = 4, O = 1, lane groups of 8 hidden units).
 // A lone wave issues ONE instruction of any kind per 4 cycles, so the cost of a row is its instruction count; the
 // compiler's version of the loop carries ~38-44 instructions per row (address arithmetic, register copies of the row
-// ring, s_nop in the VALU->DPP and transcendental->use hazard slots).  Here a row is 27 VALU + 1 s_load + 1 s_waitcnt
-// with every hazard slot holding useful work, and 4 scalar instructions of loop control per 3 rows:
+// ring, s_nop in the VALU->DPP and transcendental->use hazard slots).  Here a row is 25 VALU + 1 s_load + 1 s_waitcnt
+// with every hazard slot holding useful work, and 4 scalar instructions of loop control per 4 rows:
 //   * rows come from the global copy of the data image through the scalar cache (wave-uniform address): s_load_dwordx8
-//     puts x0..x3, y, d = 1 + x[n].x[n-1] into SGPRs that feed the VALU directly; ring of three rows A, B, C
-//     (previous, current, next), row n+2 is fetched during row n into the buffer of row n-1;
-//   * the W1/B1 update of row n-1 and the partial pre-activation of row n+1 fill the hazard slots of row n
-//     (deferred update, see sgd_sweep);
-//   * {B2' (lane 0), W2'} and {W1'[0],W1'[1]}, {W1'[2],W1'[3]} are updated with v_pk_fma_f32.
-// Physical registers are fixed (v100-v125, s40-s68) and declared as clobbers; the state enters and leaves through
-// operands.  Processes rows 0 .. 3 iters - 1 and applies the pending update of the last one.
+//     puts x0..x3, y, d = 1 + x[n].x[n-1] into SGPRs that feed the VALU directly; ring of four rows A..D (previous,
+//     current, next, arriving); row n+3 is requested during row n into the buffer of row n-1, right after the wait for
+//     row n+2, so a request has a whole row of time;
+//   * the W1/B1 update of row n-1 and the partial pre-activation of row n+1 (two v_pk_fma_f32 + one add) fill the
+//     hazard slots of row n (deferred update, see sgd_sweep);
+//   * {B2' (lane 0), W} and {W1'[0],W1'[1]}, {W1'[2],W1'[3]} are updated with v_pk_fma_f32;
+//   * scaling that removes two multiplies: with a = (lr log2 e)^-1/2 the loop keeps W = a W2' and computes
+//     HN = -hid / a = rcp(-a (1 + 2^z)) (the "+1" of the sigmoid becomes an fma), so that
+//         hid W2' = -HN W,    W += od HN  (is  W2' += (c lr) od hid),    lhd = (od W) HN fma(HN, -lr a, -lr).
+// Physical registers are fixed (v100-v126, s36-s72) and declared as clobbers; the state enters and leaves through
+// operands.  Processes rows 0 .. 4 iters - 1 and applies the pending update of the last one.
 // Hazards honoured by construction (gfx950): transcendental result -> 1 slot before a non-transcendental use,
 // VALU result -> 2 slots before a DPP read, SMEM result -> s_waitcnt lgkmcnt(0) before use and before the block ends.
 // ------------------------------------------------------------------------------------------------
-#define PTNN_SW_STEP(P0, P2, X4, X5, N0, N1, N2, N3, PLO, ZP, ZN, OFF)                                              \
-    "v_fmac_f32_e32 " ZP ", " X5 ", v110\n"                             /*  z = zp + lhd d                       */ \
+#define PTNN_SW_STEP(P01, P23, PALL, XY, XD, N01, N23, ZP, ZN, OFF)                                                 \
+    "v_fmac_f32_e32 " ZP ", " XD ", v110\n"                             /*  z = zp + lhd d                       */ \
     "v_exp_f32_e32 v117, " ZP "\n"                                                                                  \
-    "v_pk_fma_f32 v[100:101], v[110:111], " P0 ", v[100:101] op_sel_hi:[0,1,1]\n" /* W1[0:1] += lhd x[n-1]       */ \
-    "v_add_f32_e32 v117, 1.0, v117\n"                                                                               \
-    "v_rcp_f32_e32 v107, v117\n"                                        /*  hid                                  */ \
-    "v_pk_fma_f32 v[102:103], v[110:111], " P2 ", v[102:103] op_sel_hi:[0,1,1]\n"                                   \
-    "v_fma_f32 v118, v107, v105, v104\n"                                /*  hid W2 + B2(lane 0)                  */ \
-    "s_load_dwordx8 " PLO ", s[64:65], " OFF "\n"                       /*  row n+2 -> buffer of row n-1         */ \
-    "v_add_f32_e32 v108, v108, v110\n"                                  /*  -B1 += lhd                           */ \
-    "v_fma_f32 " ZN ", " N0 ", v100, v108\n"                            /*  partial z of row n+1 ...             */ \
+    "v_pk_fma_f32 v[100:101], v[110:111], " P01 ", v[100:101] op_sel_hi:[0,1,1]\n" /* W1[0:1] += lhd x[n-1]      */ \
+    "v_fma_f32 v117, v117, s71, s71\n"                                  /*  -a (1 + 2^z)                         */ \
+    "v_rcp_f32_e32 v107, v117\n"                                        /*  HN = -hid / a                        */ \
+    "v_pk_fma_f32 v[102:103], v[110:111], " P23 ", v[102:103] op_sel_hi:[0,1,1]\n"                                  \
+    "v_fma_f32 v118, -v107, v105, v104\n"                               /*  hid W2' + B2'(lane 0)                */ \
+    "s_waitcnt lgkmcnt(0)\n"                                            /*  row n+2 has arrived                  */ \
+    "s_load_dwordx8 " PALL ", s[68:69], " OFF "\n"                      /*  row n+3 -> buffer of row n-1         */ \
     "v_add_f32_dpp v118, v118, v118 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                  \
-    "v_fmac_f32_e32 " ZN ", " N1 ", v101\n"                                                                         \
-    "v_fmac_f32_e32 " ZN ", " N2 ", v102\n"                                                                         \
+    "v_add_f32_e32 v108, v108, v110\n"                                  /*  -B1' += lhd                          */ \
+    "v_fma_f32 v119, v107, s72, v126\n"                                 /*  -lr a HN - lr                        */ \
     "v_add_f32_dpp v118, v118, v118 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                  \
-    "v_fmac_f32_e32 " ZN ", " N3 ", v103\n"                                                                         \
-    "v_fma_f32 v119, -v107, v107, v107\n"                               /*  hid (1 - hid)                        */ \
+    "v_pk_fma_f32 v[112:113], " N01 ", v[100:101], v[108:109]\n"        /*  partial z of row n+1 ...             */ \
+    "v_mul_f32_e32 v120, v107, v119\n"                                  /*  lr hid (1 - hid) / a                 */ \
     "v_add_f32_dpp v118, v118, v118 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                      \
     "v_exp_f32_e32 v117, v118\n"                                                                                    \
-    "v_mul_f32_e32 v120, s67, v119\n"                                   /*  lr hid (1 - hid)                     */ \
+    "v_pk_fma_f32 v[112:113], " N23 ", v[102:103], v[112:113]\n"                                                    \
     "v_add_f32_e32 v117, 1.0, v117\n"                                                                               \
     "v_rcp_f32_e32 v121, v117\n"                                        /*  out                                  */ \
-    "s_waitcnt lgkmcnt(0)\n"                                                                                        \
-    "v_sub_f32_e32 v122, " X4 ", v121\n"                                /*  y - out                              */ \
+    "v_add_f32_e32 " ZN ", v112, v113\n"                                                                            \
+    "v_sub_f32_e32 v122, " XY ", v121\n"                                /*  y - out                              */ \
     "v_fma_f32 v123, -v121, v121, v121\n"                                                                           \
     "v_mul_f32_e32 v124, v122, v123\n"                                  /*  od                                   */ \
-    "v_mul_f32_e32 v125, v124, v105\n"                                  /*  g' = od W2' (pre-update)             */ \
-    "v_mul_f32_e32 v112, s68, v124\n"                                   /*  (c lr) od                            */ \
+    "v_mul_f32_e32 v125, v124, v105\n"                                  /*  od W (pre-update)                    */ \
     "v_mul_f32_e32 v110, v125, v120\n"                                  /*  lhd                                  */ \
-    "v_pk_fma_f32 v[104:105], v[112:113], v[106:107], v[104:105] op_sel_hi:[0,1,1]\n" /* {B2',W2'} += lod {m0,hid} */
+    "v_pk_fma_f32 v[104:105], v[124:125], v[106:107], v[104:105] op_sel_hi:[0,1,1]\n" /* {B2',W} += od {c lr m0, HN} */
 
 __device__ __forceinline__ void sweep_rows_reg41(float (&w1)[4], float& nb1, float& w2, float& cl, float m0, float lr,
                                                  float clr, const float* gdata, int iters) {
     const unsigned long long gp = (unsigned long long)(uintptr_t)gdata;
-    const unsigned end_lo = (unsigned)gp + (unsigned)iters * 96u;      // low word of the running pointer after the last pass
+    const unsigned end_lo = (unsigned)gp + (unsigned)iters * 128u;     // low word of the running pointer after the last pass
     const float lr_u = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lr)));
-    const float clr_u = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, clr)));
+    const float sa = __builtin_amdgcn_rsqf(LOG2E * lr_u), sb = __builtin_amdgcn_sqrtf(LOG2E * lr_u);   // a, 1 / a
+    auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    const float kb = uni(-sa), k1 = uni(-lr_u * sa), k2 = -lr_u;
     float o0, o1, o2, o3, onb, ow2, ocl;
     asm volatile(
-        "s_mov_b64 s[64:65], %[gp]\n"
-        "s_mov_b32 s66, %[endlo]\n"
-        "s_mov_b32 s67, %[lr]\n"
-        "s_mov_b32 s68, %[clr]\n"
-        "s_load_dwordx8 s[48:55], s[64:65], 0x0\n"                      // B = row 0
-        "s_load_dwordx8 s[56:63], s[64:65], 0x20\n"                     // C = row 1
-        "s_mov_b64 s[40:41], 0\n"                                       // A: nothing to apply yet
-        "s_mov_b64 s[42:43], 0\n"
+        "s_mov_b64 s[68:69], %[gp]\n"
+        "s_mov_b32 s70, %[endlo]\n"
+        "s_mov_b32 s71, %[kb]\n"
+        "s_mov_b32 s72, %[k1]\n"
+        "s_load_dwordx8 s[44:51], s[68:69], 0x0\n"                      // B = row 0
+        "s_load_dwordx8 s[52:59], s[68:69], 0x20\n"                     // C = row 1
+        "s_load_dwordx8 s[60:67], s[68:69], 0x40\n"                     // D = row 2
+        "s_mov_b64 s[36:37], 0\n"                                       // A: nothing to apply yet
+        "s_mov_b64 s[38:39], 0\n"
         "v_mov_b32_e32 v100, %[w0]\n"
         "v_mov_b32_e32 v101, %[w1]\n"
         "v_mov_b32_e32 v102, %[w2]\n"
         "v_mov_b32_e32 v103, %[w3]\n"
         "v_mov_b32_e32 v104, %[cl]\n"
         "v_mov_b32_e32 v105, %[v2]\n"
-        "v_mov_b32_e32 v106, %[m0]\n"
+        "v_mov_b32_e32 v106, %[cm0]\n"
         "v_mov_b32_e32 v107, 0\n"
         "v_mov_b32_e32 v108, %[nb]\n"
+        "v_mov_b32_e32 v109, 0\n"
         "v_mov_b32_e32 v110, 0\n"
         "v_mov_b32_e32 v111, 0\n"
-        "v_mov_b32_e32 v113, 0\n"
+        "v_mov_b32_e32 v126, %[k2]\n"
         "s_waitcnt lgkmcnt(0)\n"
-        "v_fma_f32 v114, s48, v100, v108\n"
-        "v_fmac_f32_e32 v114, s49, v101\n"
-        "v_fmac_f32_e32 v114, s50, v102\n"
-        "v_fmac_f32_e32 v114, s51, v103\n"
+        "v_pk_fma_f32 v[112:113], s[44:45], v[100:101], v[108:109]\n"
+        "s_nop 1\n"
+        "v_pk_fma_f32 v[112:113], s[46:47], v[102:103], v[112:113]\n"
+        "s_nop 1\n"
+        "v_add_f32_e32 v114, v112, v113\n"
         "L_ptnn_sweep_%=:\n"
-        PTNN_SW_STEP("s[40:41]", "s[42:43]", "s52", "s53", "s56", "s57", "s58", "s59", "s[40:47]", "v114", "v115", "0x40")
-        PTNN_SW_STEP("s[48:49]", "s[50:51]", "s60", "s61", "s40", "s41", "s42", "s43", "s[48:55]", "v115", "v116", "0x60")
-        PTNN_SW_STEP("s[56:57]", "s[58:59]", "s44", "s45", "s48", "s49", "s50", "s51", "s[56:63]", "v116", "v114", "0x80")
-        "s_add_u32 s64, s64, 0x60\n"
-        "s_addc_u32 s65, s65, 0\n"
-        "s_cmp_lg_u32 s64, s66\n"
+        //            prev (x01, x23, all)                  cur (y, d)    next (x01, x23)           zp      zn     request
+        PTNN_SW_STEP("s[36:37]", "s[38:39]", "s[36:43]", "s48", "s49", "s[52:53]", "s[54:55]", "v114", "v115", "0x60")
+        PTNN_SW_STEP("s[44:45]", "s[46:47]", "s[44:51]", "s56", "s57", "s[60:61]", "s[62:63]", "v115", "v114", "0x80")
+        PTNN_SW_STEP("s[52:53]", "s[54:55]", "s[52:59]", "s64", "s65", "s[36:37]", "s[38:39]", "v114", "v115", "0xa0")
+        PTNN_SW_STEP("s[60:61]", "s[62:63]", "s[60:67]", "s40", "s41", "s[44:45]", "s[46:47]", "v115", "v114", "0xc0")
+        "s_add_u32 s68, s68, 0x80\n"
+        "s_addc_u32 s69, s69, 0\n"
+        "s_cmp_lg_u32 s68, s70\n"
         "s_cbranch_scc1 L_ptnn_sweep_%=\n"
         // the update of the last row (its inputs are in A) is still pending
-        "v_pk_fma_f32 v[100:101], v[110:111], s[40:41], v[100:101] op_sel_hi:[0,1,1]\n"
-        "v_pk_fma_f32 v[102:103], v[110:111], s[42:43], v[102:103] op_sel_hi:[0,1,1]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_pk_fma_f32 v[100:101], v[110:111], s[36:37], v[100:101] op_sel_hi:[0,1,1]\n"
+        "v_pk_fma_f32 v[102:103], v[110:111], s[38:39], v[102:103] op_sel_hi:[0,1,1]\n"
         "v_add_f32_e32 v108, v108, v110\n"
         "s_nop 1\n"
         "v_mov_b32_e32 %[o0], v100\n"
@@ -266,13 +276,14 @@ __device__ __forceinline__ void sweep_rows_reg41(float (&w1)[4], float& nb1, flo
         "v_mov_b32_e32 %[ow2], v105\n"
         "v_mov_b32_e32 %[onb], v108\n"
         : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [onb] "=&v"(onb), [ow2] "=&v"(ow2), [ocl] "=&v"(ocl)
-        : [gp] "s"(gp), [endlo] "s"(end_lo), [lr] "s"(lr_u), [clr] "s"(clr_u), [w0] "v"(w1[0]), [w1] "v"(w1[1]),
-          [w2] "v"(w1[2]), [w3] "v"(w1[3]), [cl] "v"(cl), [v2] "v"(w2), [m0] "v"(m0), [nb] "v"(nb1)
+        : [gp] "s"(gp), [endlo] "s"(end_lo), [kb] "s"(kb), [k1] "s"(k1), [k2] "v"(k2), [w0] "v"(w1[0]), [w1] "v"(w1[1]),
+          [w2] "v"(w1[2]), [w3] "v"(w1[3]), [cl] "v"(cl), [v2] "v"(w2 * sa), [cm0] "v"(clr * m0), [nb] "v"(nb1)
         : "memory", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
           "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125",
-          "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
-          "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68");
-    w1[0] = o0; w1[1] = o1; w1[2] = o2; w1[3] = o3; nb1 = onb; w2 = ow2; cl = ocl;
+          "v126", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",
+          "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66",
+          "s67", "s68", "s69", "s70", "s71", "s72");
+    w1[0] = o0; w1[1] = o1; w1[2] = o2; w1[3] = o3; nb1 = onb; w2 = ow2 * sb; cl = ocl;
 }
 
 // row stride of the data image in floats: x[0..I-1], y, 1 + x[n].x[n-1] (see sgd_sweep), padded to a multiple of 4
@@ -337,12 +348,12 @@ __device__ __forceinline__ void sgd_sweep(const float* __restrict__ w_in, float*
     constexpr int IPY = sweep_row_stride(I);
     int n = 0;
     if constexpr (TASK == TASK_REG && I == 4 && O == 1 && NRED == 3) {
-        // the reference's time-series nets (4 lags -> <= 8 hidden units -> 1 output): rows 0 .. 3 floor(Ntr/3) - 1 in a
+        // the reference's time-series nets (4 lags -> <= 8 hidden units -> 1 output): rows 0 .. 4 floor(Ntr/4) - 1 in a
         // hand-scheduled loop (sweep_rows_reg41), whatever is left by the generic code below
-        const int iters = Ntr / 3;
+        const int iters = Ntr / 4;
         if (iters > 0) {
             sweep_rows_reg41(w1, nb1, w2[0], cl[0], m0, lr, clr, gdata, iters);
-            n = 3 * iters;
+            n = 4 * iters;
         }
     }
     auto row_step = [&](const float (&xprev)[RW], const float (&x)[RW], const float (&xnext)[RW]) {
