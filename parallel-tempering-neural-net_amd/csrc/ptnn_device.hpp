@@ -8,6 +8,7 @@
 //
 // Written for gfx950 only: wave size 64, DPP row operations, v_permlane{16,32}_swap.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -517,13 +518,19 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
 #pragma unroll
     for (int o = 0; o < O; ++o) b2[o] = fw[H * FWS + o];
     const int stride = gsize<WL>();
-    for (int n0 = gtid<WL>(); n0 < Nall; n0 += stride * RB) {
-        float x[RB][I + 1];
-        float acc[RB][O];
+    // one block = RBK rows of this lane (rows tid + (b0 + b) stride); the last rows of a lane take the smaller blockings,
+    // so a small data set spread over many lanes costs one row per lane, not RB.  Every lane adds its rows in ascending
+    // order whatever the blocking, so the sums do not depend on it.
+    auto block = [&](auto rbk, int b0) {
+        constexpr int RBK = decltype(rbk)::value;
+        const int n0 = gtid<WL>() + b0 * stride;
+        const int nc = n0 < Nall ? n0 : 0;
+        float x[RBK][I + 1];
+        float acc[RBK][O];
 #pragma unroll
-        for (int b = 0; b < RB; ++b) {
+        for (int b = 0; b < RBK; ++b) {
             const int n = n0 + b * stride;
-            lds_load<I + 1>(xy + (n < Nall ? n : n0) * IPY, x[b]);
+            lds_load<I + 1>(xy + (n < Nall ? n : nc) * IPY, x[b]);
 #pragma unroll
             for (int o = 0; o < O; ++o) acc[b][o] = -b2[o];
         }
@@ -531,7 +538,7 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
             float f[K];
             lds_load<K>(fw + h * FWS, f);                  // wave-uniform address: broadcast reads
 #pragma unroll
-            for (int b = 0; b < RB; ++b) {
+            for (int b = 0; b < RBK; ++b) {
                 float z = -f[I];
 #pragma unroll
                 for (int i = 0; i < I; ++i) z = fmaf(x[b][i], f[i], z);
@@ -541,7 +548,7 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
             }
         }
 #pragma unroll
-        for (int b = 0; b < RB; ++b) {
+        for (int b = 0; b < RBK; ++b) {
             const int n = n0 + b * stride;
             if (n >= Nall) continue;
             const float y = x[b][I];
@@ -570,7 +577,13 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
             if (n < Ntr) { a_tr += a; b_tr += bb; c_tr += c; }
             else { a_te += a; b_te += bb; c_te += c; }
         }
-    }
+    };
+    const int cnt = (Nall + stride - 1) / stride;          // rows of the busiest lane (uniform over the group)
+    int b0 = 0;
+    for (; cnt - b0 >= RB; b0 += RB) block(std::integral_constant<int, RB>{}, b0);
+    if (RB >= 8 && cnt - b0 >= 4) { block(std::integral_constant<int, 4>{}, b0); b0 += 4; }
+    if (RB >= 4 && cnt - b0 >= 2) { block(std::integral_constant<int, 2>{}, b0); b0 += 2; }
+    if (RB >= 2 && cnt - b0 >= 1) { block(std::integral_constant<int, 1>{}, b0); b0 += 1; }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     a_tr = wave_allsum(a_tr);
     a_te = wave_allsum(a_te);
