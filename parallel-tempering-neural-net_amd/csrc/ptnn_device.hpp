@@ -166,7 +166,8 @@ __device__ __forceinline__ void lds_load(const float* __restrict__ p, float (&v)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Hand-scheduled SGD rows for the reference's time-series nets (TASK_REG, I = 4, O = 1, lane groups of 8 hidden units).
+// Hand-scheduled SGD rows for the reference's time-series nets (TASK_REG, I = 4, O = 1, lane groups of 8 or 16 hidden
+// units: Sunspot/Lazer 4-5-1, Mackey-Glass 4-10-1).
 // A lone wave issues ONE instruction of any kind per 4 cycles, so the cost of a row is its instruction count; the
 // compiler's version of the loop carries ~38-44 instructions per row (address arithmetic, register copies of the row
 // ring, s_nop in the VALU->DPP and transcendental->use hazard slots).  Here a row is 25 VALU + 1 s_load + 1 s_waitcnt
@@ -186,7 +187,7 @@ __device__ __forceinline__ void lds_load(const float* __restrict__ p, float (&v)
 // Hazards honoured by construction (gfx950): transcendental result -> 1 slot before a non-transcendental use,
 // VALU result -> 2 slots before a DPP read, SMEM result -> s_waitcnt lgkmcnt(0) before use and before the block ends.
 // ------------------------------------------------------------------------------------------------
-#define PTNN_SW_STEP(P01, P23, PALL, XY, XD, N01, N23, ZP, ZN, OFF)                                                 \
+#define PTNN_SW_STEP(P01, P23, PALL, XY, XD, N01, N23, ZP, ZN, OFF, DPP4)                                               \
     "v_fmac_f32_e32 " ZP ", " XD ", v110\n"                             /*  z = zp + lhd d                       */ \
     "v_exp_f32_e32 v117, " ZP "\n"                                                                                  \
     "v_pk_fma_f32 v[100:101], v[110:111], " P01 ", v[100:101] op_sel_hi:[0,1,1]\n" /* W1[0:1] += lhd x[n-1]      */ \
@@ -203,6 +204,7 @@ __device__ __forceinline__ void lds_load(const float* __restrict__ p, float (&v)
     "v_pk_fma_f32 v[112:113], " N01 ", v[100:101], v[108:109]\n"        /*  partial z of row n+1 ...             */ \
     "v_mul_f32_e32 v120, v107, v119\n"                                  /*  lr hid (1 - hid) / a                 */ \
     "v_add_f32_dpp v118, v118, v118 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                      \
+    DPP4                                                                /*  16-lane groups: one more stage       */ \
     "v_exp_f32_e32 v117, v118\n"                                                                                    \
     "v_pk_fma_f32 v[112:113], " N23 ", v[102:103], v[112:113]\n"                                                    \
     "v_add_f32_e32 v117, 1.0, v117\n"                                                                               \
@@ -215,6 +217,69 @@ __device__ __forceinline__ void lds_load(const float* __restrict__ p, float (&v)
     "v_mul_f32_e32 v110, v125, v120\n"                                  /*  lhd                                  */ \
     "v_pk_fma_f32 v[104:105], v[124:125], v[106:107], v[104:105] op_sel_hi:[0,1,1]\n" /* {B2',W} += od {c lr m0, HN} */
 
+#define PTNN_SW_ASM(DPP4) \
+    asm volatile( \
+        "s_mov_b64 s[68:69], %[gp]\n" \
+        "s_mov_b32 s70, %[endlo]\n" \
+        "s_mov_b32 s71, %[kb]\n" \
+        "s_mov_b32 s72, %[k1]\n" \
+        "s_load_dwordx8 s[44:51], s[68:69], 0x0\n" \
+        "s_load_dwordx8 s[52:59], s[68:69], 0x20\n" \
+        "s_load_dwordx8 s[60:67], s[68:69], 0x40\n" \
+        "s_mov_b64 s[36:37], 0\n" \
+        "s_mov_b64 s[38:39], 0\n" \
+        "v_mov_b32_e32 v100, %[w0]\n" \
+        "v_mov_b32_e32 v101, %[w1]\n" \
+        "v_mov_b32_e32 v102, %[w2]\n" \
+        "v_mov_b32_e32 v103, %[w3]\n" \
+        "v_mov_b32_e32 v104, %[cl]\n" \
+        "v_mov_b32_e32 v105, %[v2]\n" \
+        "v_mov_b32_e32 v106, %[cm0]\n" \
+        "v_mov_b32_e32 v107, 0\n" \
+        "v_mov_b32_e32 v108, %[nb]\n" \
+        "v_mov_b32_e32 v109, 0\n" \
+        "v_mov_b32_e32 v110, 0\n" \
+        "v_mov_b32_e32 v111, 0\n" \
+        "v_mov_b32_e32 v126, %[k2]\n" \
+        "s_waitcnt lgkmcnt(0)\n" \
+        "v_pk_fma_f32 v[112:113], s[44:45], v[100:101], v[108:109]\n" \
+        "s_nop 1\n" \
+        "v_pk_fma_f32 v[112:113], s[46:47], v[102:103], v[112:113]\n" \
+        "s_nop 1\n" \
+        "v_add_f32_e32 v114, v112, v113\n" \
+        "L_ptnn_sweep_%=:\n" \
+ \
+        PTNN_SW_STEP("s[36:37]", "s[38:39]", "s[36:43]", "s48", "s49", "s[52:53]", "s[54:55]", "v114", "v115", "0x60", DPP4) \
+        PTNN_SW_STEP("s[44:45]", "s[46:47]", "s[44:51]", "s56", "s57", "s[60:61]", "s[62:63]", "v115", "v114", "0x80", DPP4) \
+        PTNN_SW_STEP("s[52:53]", "s[54:55]", "s[52:59]", "s64", "s65", "s[36:37]", "s[38:39]", "v114", "v115", "0xa0", DPP4) \
+        PTNN_SW_STEP("s[60:61]", "s[62:63]", "s[60:67]", "s40", "s41", "s[44:45]", "s[46:47]", "v115", "v114", "0xc0", DPP4) \
+        "s_add_u32 s68, s68, 0x80\n" \
+        "s_addc_u32 s69, s69, 0\n" \
+        "s_cmp_lg_u32 s68, s70\n" \
+        "s_cbranch_scc1 L_ptnn_sweep_%=\n" \
+ \
+        "s_waitcnt lgkmcnt(0)\n" \
+        "v_pk_fma_f32 v[100:101], v[110:111], s[36:37], v[100:101] op_sel_hi:[0,1,1]\n" \
+        "v_pk_fma_f32 v[102:103], v[110:111], s[38:39], v[102:103] op_sel_hi:[0,1,1]\n" \
+        "v_add_f32_e32 v108, v108, v110\n" \
+        "s_nop 1\n" \
+        "v_mov_b32_e32 %[o0], v100\n" \
+        "v_mov_b32_e32 %[o1], v101\n" \
+        "v_mov_b32_e32 %[o2], v102\n" \
+        "v_mov_b32_e32 %[o3], v103\n" \
+        "v_mov_b32_e32 %[ocl], v104\n" \
+        "v_mov_b32_e32 %[ow2], v105\n" \
+        "v_mov_b32_e32 %[onb], v108\n" \
+        : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [onb] "=&v"(onb), [ow2] "=&v"(ow2), [ocl] "=&v"(ocl) \
+        : [gp] "s"(gp), [endlo] "s"(end_lo), [kb] "s"(kb), [k1] "s"(k1), [k2] "v"(k2), [w0] "v"(w1[0]), [w1] "v"(w1[1]), \
+          [w2] "v"(w1[2]), [w3] "v"(w1[3]), [cl] "v"(cl), [v2] "v"(w2 * sa), [cm0] "v"(clr * m0), [nb] "v"(nb1) \
+        : "memory", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
+          "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", \
+          "v126", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", \
+          "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", \
+          "s67", "s68", "s69", "s70", "s71", "s72");
+
+template <int NRED>
 __device__ __forceinline__ void sweep_rows_reg41(float (&w1)[4], float& nb1, float& w2, float& cl, float m0, float lr,
                                                  float clr, const float* gdata, int iters) {
     const unsigned long long gp = (unsigned long long)(uintptr_t)gdata;
@@ -224,66 +289,12 @@ __device__ __forceinline__ void sweep_rows_reg41(float (&w1)[4], float& nb1, flo
     auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
     const float kb = uni(-sa), k1 = uni(-lr_u * sa), k2 = -lr_u;
     float o0, o1, o2, o3, onb, ow2, ocl;
-    asm volatile(
-        "s_mov_b64 s[68:69], %[gp]\n"
-        "s_mov_b32 s70, %[endlo]\n"
-        "s_mov_b32 s71, %[kb]\n"
-        "s_mov_b32 s72, %[k1]\n"
-        "s_load_dwordx8 s[44:51], s[68:69], 0x0\n"                      // B = row 0
-        "s_load_dwordx8 s[52:59], s[68:69], 0x20\n"                     // C = row 1
-        "s_load_dwordx8 s[60:67], s[68:69], 0x40\n"                     // D = row 2
-        "s_mov_b64 s[36:37], 0\n"                                       // A: nothing to apply yet
-        "s_mov_b64 s[38:39], 0\n"
-        "v_mov_b32_e32 v100, %[w0]\n"
-        "v_mov_b32_e32 v101, %[w1]\n"
-        "v_mov_b32_e32 v102, %[w2]\n"
-        "v_mov_b32_e32 v103, %[w3]\n"
-        "v_mov_b32_e32 v104, %[cl]\n"
-        "v_mov_b32_e32 v105, %[v2]\n"
-        "v_mov_b32_e32 v106, %[cm0]\n"
-        "v_mov_b32_e32 v107, 0\n"
-        "v_mov_b32_e32 v108, %[nb]\n"
-        "v_mov_b32_e32 v109, 0\n"
-        "v_mov_b32_e32 v110, 0\n"
-        "v_mov_b32_e32 v111, 0\n"
-        "v_mov_b32_e32 v126, %[k2]\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_pk_fma_f32 v[112:113], s[44:45], v[100:101], v[108:109]\n"
-        "s_nop 1\n"
-        "v_pk_fma_f32 v[112:113], s[46:47], v[102:103], v[112:113]\n"
-        "s_nop 1\n"
-        "v_add_f32_e32 v114, v112, v113\n"
-        "L_ptnn_sweep_%=:\n"
-        //            prev (x01, x23, all)                  cur (y, d)    next (x01, x23)           zp      zn     request
-        PTNN_SW_STEP("s[36:37]", "s[38:39]", "s[36:43]", "s48", "s49", "s[52:53]", "s[54:55]", "v114", "v115", "0x60")
-        PTNN_SW_STEP("s[44:45]", "s[46:47]", "s[44:51]", "s56", "s57", "s[60:61]", "s[62:63]", "v115", "v114", "0x80")
-        PTNN_SW_STEP("s[52:53]", "s[54:55]", "s[52:59]", "s64", "s65", "s[36:37]", "s[38:39]", "v114", "v115", "0xa0")
-        PTNN_SW_STEP("s[60:61]", "s[62:63]", "s[60:67]", "s40", "s41", "s[44:45]", "s[46:47]", "v115", "v114", "0xc0")
-        "s_add_u32 s68, s68, 0x80\n"
-        "s_addc_u32 s69, s69, 0\n"
-        "s_cmp_lg_u32 s68, s70\n"
-        "s_cbranch_scc1 L_ptnn_sweep_%=\n"
-        // the update of the last row (its inputs are in A) is still pending
-        "s_waitcnt lgkmcnt(0)\n"
-        "v_pk_fma_f32 v[100:101], v[110:111], s[36:37], v[100:101] op_sel_hi:[0,1,1]\n"
-        "v_pk_fma_f32 v[102:103], v[110:111], s[38:39], v[102:103] op_sel_hi:[0,1,1]\n"
-        "v_add_f32_e32 v108, v108, v110\n"
-        "s_nop 1\n"
-        "v_mov_b32_e32 %[o0], v100\n"
-        "v_mov_b32_e32 %[o1], v101\n"
-        "v_mov_b32_e32 %[o2], v102\n"
-        "v_mov_b32_e32 %[o3], v103\n"
-        "v_mov_b32_e32 %[ocl], v104\n"
-        "v_mov_b32_e32 %[ow2], v105\n"
-        "v_mov_b32_e32 %[onb], v108\n"
-        : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [onb] "=&v"(onb), [ow2] "=&v"(ow2), [ocl] "=&v"(ocl)
-        : [gp] "s"(gp), [endlo] "s"(end_lo), [kb] "s"(kb), [k1] "s"(k1), [k2] "v"(k2), [w0] "v"(w1[0]), [w1] "v"(w1[1]),
-          [w2] "v"(w1[2]), [w3] "v"(w1[3]), [cl] "v"(cl), [v2] "v"(w2 * sa), [cm0] "v"(clr * m0), [nb] "v"(nb1)
-        : "memory", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",
-          "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125",
-          "v126", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50",
-          "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66",
-          "s67", "s68", "s69", "s70", "s71", "s72");
+    if constexpr (NRED == 3) {
+        PTNN_SW_ASM("")
+    } else {
+        PTNN_SW_ASM("s_nop 1\n"
+                    "v_add_f32_dpp v118, v118, v118 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n")
+    }
     w1[0] = o0; w1[1] = o1; w1[2] = o2; w1[3] = o3; nb1 = onb; w2 = ow2 * sb; cl = ocl;
 }
 
@@ -348,12 +359,12 @@ __device__ __forceinline__ void sgd_sweep(const float* __restrict__ w_in, float*
     };
     constexpr int IPY = sweep_row_stride(I);
     int n = 0;
-    if constexpr (TASK == TASK_REG && I == 4 && O == 1 && NRED == 3) {
+    if constexpr (TASK == TASK_REG && I == 4 && O == 1 && (NRED == 3 || NRED == 4)) {
         // the reference's time-series nets (4 lags -> <= 8 hidden units -> 1 output): rows 0 .. 4 floor(Ntr/4) - 1 in a
         // hand-scheduled loop (sweep_rows_reg41), whatever is left by the generic code below
         const int iters = Ntr / 4;
         if (iters > 0) {
-            sweep_rows_reg41(w1, nb1, w2[0], cl[0], m0, lr, clr, gdata, iters);
+            sweep_rows_reg41<NRED>(w1, nb1, w2[0], cl[0], m0, lr, clr, gdata, iters);
             n = 4 * iters;
         }
     }
