@@ -447,6 +447,26 @@ def test_config5_shape_against_oracle():
     s.close()
 
 
+@pytest.mark.parametrize("hidden", [1, 4, 5, 8, 10, 16, 20, 40])
+def test_sgd_epoch_row_counts_and_lane_groups(hidden):
+    """The SGD epoch (Network.langevin_gradient, REG:99-118) for every code path of the sweep: the hand-scheduled 4-row
+    loop (4-H-1 nets with H <= 16), its generic 0..3-row tail, data sets too short for it, and the compiler-scheduled
+    deferred-update loop of the larger lane groups -- against the float64 oracle."""
+    d = ds()
+    train, test = d["sunspot_train"], d["sunspot_test"]
+    topo = (4, hidden, 1)
+    rng = np.random.default_rng(hidden)
+    Pw = 4 * hidden + hidden + hidden + 1
+    for ntr in (1, 2, 3, 4, 5, 6, 7, 8, 9, 31, 297, 298):
+        s = parity.make_sampler(orc.TASK_REG, topo, train[:ntr], test, R_local=2, R_global=2, first=0, S=10, si=100,
+                                use_lg=True, lr=0.1, seed=3)
+        for scale in (0.3, 1.5):
+            w = (scale * rng.standard_normal(Pw)).astype(np.float32)
+            ref = orc.langevin_gradient(train[:ntr], w.astype(np.float64), topo, 0.1, 0)
+            np.testing.assert_allclose(s.langevin_gradient(w)[0], ref, rtol=1e-4, atol=2e-5, err_msg=f"H={hidden} Ntr={ntr}")
+        s.close()
+
+
 @pytest.mark.parametrize("schedule", [1, 2])
 def test_trace_ring_streaming_equals_full_traces(schedule):
     """trace_capacity < S keeps only a ring of rows in HBM; draining it in windows must give exactly the full traces, and
