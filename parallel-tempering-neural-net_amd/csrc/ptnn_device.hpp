@@ -182,40 +182,40 @@ __device__ __forceinline__ void lds_load(const float* __restrict__ p, float (&v)
 //   * scaling that removes two multiplies: with a = (lr log2 e)^-1/2 the loop keeps W = a W2' and computes
 //     HN = -hid / a = rcp(-a (1 + 2^z)) (the "+1" of the sigmoid becomes an fma), so that
 //         hid W2' = -HN W,    W += od HN  (is  W2' += (c lr) od hid),    lhd = (od W) HN fma(HN, -lr a, -lr).
-// Physical registers are fixed (v100-v126, s36-s72) and declared as clobbers; the state enters and leaves through
+// Physical registers are fixed (v40-v66, s36-s72) and declared as clobbers; the state enters and leaves through
 // operands.  Processes rows 0 .. 4 iters - 1 and applies the pending update of the last one.
 // Hazards honoured by construction (gfx950): transcendental result -> 1 slot before a non-transcendental use,
 // VALU result -> 2 slots before a DPP read, SMEM result -> s_waitcnt lgkmcnt(0) before use and before the block ends.
 // ------------------------------------------------------------------------------------------------
 #define PTNN_SW_STEP(P01, P23, PALL, XY, XD, N01, N23, ZP, ZN, OFF, DPP4)                                               \
-    "v_fmac_f32_e32 " ZP ", " XD ", v110\n"                             /*  z = zp + lhd d                       */ \
-    "v_exp_f32_e32 v117, " ZP "\n"                                                                                  \
-    "v_pk_fma_f32 v[100:101], v[110:111], " P01 ", v[100:101] op_sel_hi:[0,1,1]\n" /* W1[0:1] += lhd x[n-1]      */ \
-    "v_fma_f32 v117, v117, s71, s71\n"                                  /*  -a (1 + 2^z)                         */ \
-    "v_rcp_f32_e32 v107, v117\n"                                        /*  HN = -hid / a                        */ \
-    "v_pk_fma_f32 v[102:103], v[110:111], " P23 ", v[102:103] op_sel_hi:[0,1,1]\n"                                  \
-    "v_fma_f32 v118, -v107, v105, v104\n"                               /*  hid W2' + B2'(lane 0)                */ \
+    "v_fmac_f32_e32 " ZP ", " XD ", v50\n"                             /*  z = zp + lhd d                       */ \
+    "v_exp_f32_e32 v57, " ZP "\n"                                                                                  \
+    "v_pk_fma_f32 v[40:41], v[50:51], " P01 ", v[40:41] op_sel_hi:[0,1,1]\n" /* W1[0:1] += lhd x[n-1]      */ \
+    "v_fma_f32 v57, v57, s71, s71\n"                                  /*  -a (1 + 2^z)                         */ \
+    "v_rcp_f32_e32 v47, v57\n"                                        /*  HN = -hid / a                        */ \
+    "v_pk_fma_f32 v[42:43], v[50:51], " P23 ", v[42:43] op_sel_hi:[0,1,1]\n"                                  \
+    "v_fma_f32 v58, -v47, v45, v44\n"                               /*  hid W2' + B2'(lane 0)                */ \
     "s_waitcnt lgkmcnt(0)\n"                                            /*  row n+2 has arrived                  */ \
     "s_load_dwordx8 " PALL ", s[68:69], " OFF "\n"                      /*  row n+3 -> buffer of row n-1         */ \
-    "v_add_f32_dpp v118, v118, v118 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                  \
-    "v_add_f32_e32 v108, v108, v110\n"                                  /*  -B1' += lhd                          */ \
-    "v_fma_f32 v119, v107, s72, v126\n"                                 /*  -lr a HN - lr                        */ \
-    "v_add_f32_dpp v118, v118, v118 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                  \
-    "v_pk_fma_f32 v[112:113], " N01 ", v[100:101], v[108:109]\n"        /*  partial z of row n+1 ...             */ \
-    "v_mul_f32_e32 v120, v107, v119\n"                                  /*  lr hid (1 - hid) / a                 */ \
-    "v_add_f32_dpp v118, v118, v118 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                      \
+    "v_add_f32_dpp v58, v58, v58 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                  \
+    "v_add_f32_e32 v48, v48, v50\n"                                  /*  -B1' += lhd                          */ \
+    "v_fma_f32 v59, v47, s72, v66\n"                                 /*  -lr a HN - lr                        */ \
+    "v_add_f32_dpp v58, v58, v58 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                  \
+    "v_pk_fma_f32 v[52:53], " N01 ", v[40:41], v[48:49]\n"        /*  partial z of row n+1 ...             */ \
+    "v_mul_f32_e32 v60, v47, v59\n"                                  /*  lr hid (1 - hid) / a                 */ \
+    "v_add_f32_dpp v58, v58, v58 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                      \
     DPP4                                                                /*  16-lane groups: one more stage       */ \
-    "v_exp_f32_e32 v117, v118\n"                                                                                    \
-    "v_pk_fma_f32 v[112:113], " N23 ", v[102:103], v[112:113]\n"                                                    \
-    "v_add_f32_e32 v117, 1.0, v117\n"                                                                               \
-    "v_rcp_f32_e32 v121, v117\n"                                        /*  out                                  */ \
-    "v_add_f32_e32 " ZN ", v112, v113\n"                                                                            \
-    "v_sub_f32_e32 v122, " XY ", v121\n"                                /*  y - out                              */ \
-    "v_fma_f32 v123, -v121, v121, v121\n"                                                                           \
-    "v_mul_f32_e32 v124, v122, v123\n"                                  /*  od                                   */ \
-    "v_mul_f32_e32 v125, v124, v105\n"                                  /*  od W (pre-update)                    */ \
-    "v_mul_f32_e32 v110, v125, v120\n"                                  /*  lhd                                  */ \
-    "v_pk_fma_f32 v[104:105], v[124:125], v[106:107], v[104:105] op_sel_hi:[0,1,1]\n" /* {B2',W} += od {c lr m0, HN} */
+    "v_exp_f32_e32 v57, v58\n"                                                                                    \
+    "v_pk_fma_f32 v[52:53], " N23 ", v[42:43], v[52:53]\n"                                                    \
+    "v_add_f32_e32 v57, 1.0, v57\n"                                                                               \
+    "v_rcp_f32_e32 v61, v57\n"                                        /*  out                                  */ \
+    "v_add_f32_e32 " ZN ", v52, v53\n"                                                                            \
+    "v_sub_f32_e32 v62, " XY ", v61\n"                                /*  y - out                              */ \
+    "v_fma_f32 v63, -v61, v61, v61\n"                                                                           \
+    "v_mul_f32_e32 v64, v62, v63\n"                                  /*  od                                   */ \
+    "v_mul_f32_e32 v65, v64, v45\n"                                  /*  od W (pre-update)                    */ \
+    "v_mul_f32_e32 v50, v65, v60\n"                                  /*  lhd                                  */ \
+    "v_pk_fma_f32 v[44:45], v[64:65], v[46:47], v[44:45] op_sel_hi:[0,1,1]\n" /* {B2',W} += od {c lr m0, HN} */
 
 #define PTNN_SW_ASM(DPP4) \
     asm volatile( \
@@ -228,54 +228,54 @@ __device__ __forceinline__ void lds_load(const float* __restrict__ p, float (&v)
         "s_load_dwordx8 s[60:67], s[68:69], 0x40\n" \
         "s_mov_b64 s[36:37], 0\n" \
         "s_mov_b64 s[38:39], 0\n" \
-        "v_mov_b32_e32 v100, %[w0]\n" \
-        "v_mov_b32_e32 v101, %[w1]\n" \
-        "v_mov_b32_e32 v102, %[w2]\n" \
-        "v_mov_b32_e32 v103, %[w3]\n" \
-        "v_mov_b32_e32 v104, %[cl]\n" \
-        "v_mov_b32_e32 v105, %[v2]\n" \
-        "v_mov_b32_e32 v106, %[cm0]\n" \
-        "v_mov_b32_e32 v107, 0\n" \
-        "v_mov_b32_e32 v108, %[nb]\n" \
-        "v_mov_b32_e32 v109, 0\n" \
-        "v_mov_b32_e32 v110, 0\n" \
-        "v_mov_b32_e32 v111, 0\n" \
-        "v_mov_b32_e32 v126, %[k2]\n" \
+        "v_mov_b32_e32 v40, %[w0]\n" \
+        "v_mov_b32_e32 v41, %[w1]\n" \
+        "v_mov_b32_e32 v42, %[w2]\n" \
+        "v_mov_b32_e32 v43, %[w3]\n" \
+        "v_mov_b32_e32 v44, %[cl]\n" \
+        "v_mov_b32_e32 v45, %[v2]\n" \
+        "v_mov_b32_e32 v46, %[cm0]\n" \
+        "v_mov_b32_e32 v47, 0\n" \
+        "v_mov_b32_e32 v48, %[nb]\n" \
+        "v_mov_b32_e32 v49, 0\n" \
+        "v_mov_b32_e32 v50, 0\n" \
+        "v_mov_b32_e32 v51, 0\n" \
+        "v_mov_b32_e32 v66, %[k2]\n" \
         "s_waitcnt lgkmcnt(0)\n" \
-        "v_pk_fma_f32 v[112:113], s[44:45], v[100:101], v[108:109]\n" \
+        "v_pk_fma_f32 v[52:53], s[44:45], v[40:41], v[48:49]\n" \
         "s_nop 1\n" \
-        "v_pk_fma_f32 v[112:113], s[46:47], v[102:103], v[112:113]\n" \
+        "v_pk_fma_f32 v[52:53], s[46:47], v[42:43], v[52:53]\n" \
         "s_nop 1\n" \
-        "v_add_f32_e32 v114, v112, v113\n" \
+        "v_add_f32_e32 v54, v52, v53\n" \
         "L_ptnn_sweep_%=:\n" \
  \
-        PTNN_SW_STEP("s[36:37]", "s[38:39]", "s[36:43]", "s48", "s49", "s[52:53]", "s[54:55]", "v114", "v115", "0x60", DPP4) \
-        PTNN_SW_STEP("s[44:45]", "s[46:47]", "s[44:51]", "s56", "s57", "s[60:61]", "s[62:63]", "v115", "v114", "0x80", DPP4) \
-        PTNN_SW_STEP("s[52:53]", "s[54:55]", "s[52:59]", "s64", "s65", "s[36:37]", "s[38:39]", "v114", "v115", "0xa0", DPP4) \
-        PTNN_SW_STEP("s[60:61]", "s[62:63]", "s[60:67]", "s40", "s41", "s[44:45]", "s[46:47]", "v115", "v114", "0xc0", DPP4) \
+        PTNN_SW_STEP("s[36:37]", "s[38:39]", "s[36:43]", "s48", "s49", "s[52:53]", "s[54:55]", "v54", "v55", "0x60", DPP4) \
+        PTNN_SW_STEP("s[44:45]", "s[46:47]", "s[44:51]", "s56", "s57", "s[60:61]", "s[62:63]", "v55", "v54", "0x80", DPP4) \
+        PTNN_SW_STEP("s[52:53]", "s[54:55]", "s[52:59]", "s64", "s65", "s[36:37]", "s[38:39]", "v54", "v55", "0xa0", DPP4) \
+        PTNN_SW_STEP("s[60:61]", "s[62:63]", "s[60:67]", "s40", "s41", "s[44:45]", "s[46:47]", "v55", "v54", "0xc0", DPP4) \
         "s_add_u32 s68, s68, 0x80\n" \
         "s_addc_u32 s69, s69, 0\n" \
         "s_cmp_lg_u32 s68, s70\n" \
         "s_cbranch_scc1 L_ptnn_sweep_%=\n" \
  \
         "s_waitcnt lgkmcnt(0)\n" \
-        "v_pk_fma_f32 v[100:101], v[110:111], s[36:37], v[100:101] op_sel_hi:[0,1,1]\n" \
-        "v_pk_fma_f32 v[102:103], v[110:111], s[38:39], v[102:103] op_sel_hi:[0,1,1]\n" \
-        "v_add_f32_e32 v108, v108, v110\n" \
+        "v_pk_fma_f32 v[40:41], v[50:51], s[36:37], v[40:41] op_sel_hi:[0,1,1]\n" \
+        "v_pk_fma_f32 v[42:43], v[50:51], s[38:39], v[42:43] op_sel_hi:[0,1,1]\n" \
+        "v_add_f32_e32 v48, v48, v50\n" \
         "s_nop 1\n" \
-        "v_mov_b32_e32 %[o0], v100\n" \
-        "v_mov_b32_e32 %[o1], v101\n" \
-        "v_mov_b32_e32 %[o2], v102\n" \
-        "v_mov_b32_e32 %[o3], v103\n" \
-        "v_mov_b32_e32 %[ocl], v104\n" \
-        "v_mov_b32_e32 %[ow2], v105\n" \
-        "v_mov_b32_e32 %[onb], v108\n" \
+        "v_mov_b32_e32 %[o0], v40\n" \
+        "v_mov_b32_e32 %[o1], v41\n" \
+        "v_mov_b32_e32 %[o2], v42\n" \
+        "v_mov_b32_e32 %[o3], v43\n" \
+        "v_mov_b32_e32 %[ocl], v44\n" \
+        "v_mov_b32_e32 %[ow2], v45\n" \
+        "v_mov_b32_e32 %[onb], v48\n" \
         : [o0] "=&v"(o0), [o1] "=&v"(o1), [o2] "=&v"(o2), [o3] "=&v"(o3), [onb] "=&v"(onb), [ow2] "=&v"(ow2), [ocl] "=&v"(ocl) \
         : [gp] "s"(gp), [endlo] "s"(end_lo), [kb] "s"(kb), [k1] "s"(k1), [k2] "v"(k2), [w0] "v"(w1[0]), [w1] "v"(w1[1]), \
           [w2] "v"(w1[2]), [w3] "v"(w1[3]), [cl] "v"(cl), [v2] "v"(w2 * sa), [cm0] "v"(clr * m0), [nb] "v"(nb1) \
-        : "memory", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
-          "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", \
-          "v126", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", \
+        : "memory", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", \
+          "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", \
+          "v66", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", \
           "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", \
           "s67", "s68", "s69", "s70", "s71", "s72");
 
@@ -293,7 +293,7 @@ __device__ __forceinline__ void sweep_rows_reg41(float (&w1)[4], float& nb1, flo
         PTNN_SW_ASM("")
     } else {
         PTNN_SW_ASM("s_nop 1\n"
-                    "v_add_f32_dpp v118, v118, v118 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n")
+                    "v_add_f32_dpp v58, v58, v58 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n")
     }
     w1[0] = o0; w1[1] = o1; w1[2] = o2; w1[3] = o3; nb1 = onb; w2 = ow2 * sb; cl = ocl;
 }
