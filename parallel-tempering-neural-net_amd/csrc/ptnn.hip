@@ -101,6 +101,7 @@ struct ptnn_handle {
           *d_acc_te = nullptr;
     int* d_accept = nullptr;
     int *d_src = nullptr, *d_src_log = nullptr;
+    int* h_src = nullptr;                                   // pinned staging for the permutation of a round (sharded ladder)
     long long* d_counters = nullptr;
     // kernel timing (HIP events on our stream)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing;
@@ -302,6 +303,7 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
     HIP_TRY(hipMalloc(&h->d_acc_te, Rl * S * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_accept, Rl * S * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_src, R * sizeof(int)));
+    HIP_TRY(hipHostMalloc(&h->h_src, R * sizeof(int), hipHostMallocDefault));
     HIP_TRY(hipMalloc(&h->d_src_log, (size_t)h->max_rounds * R * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_counters, 2 * sizeof(long long)));
     HIP_TRY(hipMalloc(&h->d_error, sizeof(int)));
@@ -325,6 +327,7 @@ int ptnn_destroy(ptnn_handle* h) {
                     h->d_acc_te, h->d_accept, h->d_src, h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_stamps, h->d_wide_scratch, h->d_xt};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->h_src) (void)hipHostFree(h->h_src);
     for (auto& ev : h->timing) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -614,8 +617,10 @@ int ptnn_swap_set_L(ptnn_handle* h, int phantom, const float* L_host) {
 int ptnn_swap_cascade(ptnn_handle* h, int phantom, int32_t* src_host) {
     if (!h || !src_host) return fail(-1, "null argument");
     if (int rc = launch_swap(h, phantom != 0, 0, true)) return rc;
-    HIP_TRY(hipMemcpyAsync(src_host, h->d_src, h->cfg.n_replicas_global * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    const size_t bytes = h->cfg.n_replicas_global * sizeof(int);
+    HIP_TRY(hipMemcpyAsync(h->h_src, h->d_src, bytes, hipMemcpyDeviceToHost, h->stream));   // pinned: no staging copy
     HIP_TRY(hipStreamSynchronize(h->stream));
+    std::memcpy(src_host, h->h_src, bytes);
     return 0;
 }
 

@@ -36,6 +36,7 @@ class DeviceShard:
         import os
         self.stream_ordered = os.environ.get("PTNN_DIST_STREAM", "0") == "1"
         self.ext_stream = torch.cuda.ExternalStream(sampler.stream_ptr(), device=self.dev) if self.stream_ordered else None
+        self._views = {}
 
     def _view(self, ptr, n):
         class _Arr:            # __cuda_array_interface__ v2: zero-copy view of library-owned HBM
@@ -65,11 +66,20 @@ class DeviceShard:
         return self.s.steps_done()
 
     def L_tensor(self, phantom):
-        return self._view(self.s.swap_L_ptr(phantom), self.R_global)
+        ptr = self.s.swap_L_ptr(phantom)                   # views are cached per device address (two L buffers, 2 Rl rows)
+        t = self._views.get(ptr)
+        if t is None:
+            t = self._views[ptr] = self._view(ptr, self.R_global)
+        return t
 
     def row_tensors(self, local):
-        cur, nxt = self.s.swap_row_ptr(local)
-        return self._view(cur, self.PS), self._view(nxt, self.PS)
+        out = []
+        for ptr in self.s.swap_row_ptr(local):
+            t = self._views.get(ptr)
+            if t is None:
+                t = self._views[ptr] = self._view(ptr, self.PS)
+            out.append(t)
+        return tuple(out)
 
     def swap_cascade(self, phantom):
         return self.s.swap_cascade(phantom)
@@ -83,16 +93,12 @@ def route(src, rank, world, R_local):
     Returns (recvs, sends): recvs = [(local_dest, peer)], sends = [(local_source, peer)], both in ascending order of
     the GLOBAL destination slot so that the two ends of every pair enumerate their messages in the same order."""
     first = rank * R_local
-    recvs, sends = [], []
-    for kg in range(world * R_local):
-        sg = int(src[kg])
-        dst_owner, src_owner = kg // R_local, sg // R_local
-        if dst_owner == src_owner:
-            continue
-        if dst_owner == rank:
-            recvs.append((kg - first, src_owner))
-        elif src_owner == rank:
-            sends.append((sg - first, dst_owner))
+    src = np.asarray(src, dtype=np.int64)
+    dst_owner = np.arange(world * R_local, dtype=np.int64) // R_local
+    src_owner = src // R_local
+    cross = np.nonzero(dst_owner != src_owner)[0]          # ascending global destination slot; usually a handful of rows
+    recvs = [(int(kg) - first, int(src_owner[kg])) for kg in cross if dst_owner[kg] == rank]
+    sends = [(int(src[kg]) - first, int(dst_owner[kg])) for kg in cross if src_owner[kg] == rank]
     return recvs, sends
 
 
@@ -104,6 +110,10 @@ class ShardedLadder:
         self.shard, self.rank, self.world = shard, rank, world
         self.rounds = 0
         self.bytes_moved = 0
+        try:
+            self._gather_in_place = hasattr(dist, "get_backend") and str(dist.get_backend()) == "nccl"
+        except Exception:
+            self._gather_in_place = False
 
     def swap_round(self, phantom):
         import contextlib
@@ -113,8 +123,11 @@ class ShardedLadder:
         L = sh.L_tensor(phantom)
         Rl = sh.R_local
         with ctx:
-            mine = L[self.rank * Rl:(self.rank + 1) * Rl].clone()
-            dist.all_gather(list(L.split(Rl)), mine)        # 4 R bytes, latency-bound
+            if self._gather_in_place:                       # RCCL: in-place all-gather, the input is this rank's slice of L
+                dist.all_gather_into_tensor(L, L[self.rank * Rl:(self.rank + 1) * Rl])
+            else:
+                mine = L[self.rank * Rl:(self.rank + 1) * Rl].clone()
+                dist.all_gather(list(L.split(Rl)), mine)    # 4 R bytes, latency-bound
         if hasattr(sh, "fence_collectives"):
             sh.fence_collectives()
         src = sh.swap_cascade(phantom)                      # identical on every rank
