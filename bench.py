@@ -237,6 +237,34 @@ def bench_other_config(a):
     s.close()
 
 
+def dependent_chain(s, W, K, si, slots=16):
+    """What bounds the wall time of an interval (after the timed region, from the accept counters of the trace): an accepted
+    step forces a new speculative round, and the swap barrier waits for the replica with the most of them."""
+    acc = s.traces(0, s.steps_done() + 1, pos_w=False)["accept"].astype(np.int64)   # acc[r, i+1] = accepted before step i
+    flags = np.diff(acc, axis=1)[:, 1:]
+    a0 = W * si + 1
+    per_acc, per_rounds = [], []
+    for it in range(K):
+        f = flags[:, a0 + it * si: a0 + (it + 1) * si]
+        per_acc.append(f.sum(axis=1))
+        rr = []
+        for row in f:
+            pos, rounds = 0, 0
+            while pos < row.shape[0]:
+                hit = np.flatnonzero(row[pos:pos + slots])
+                pos += (hit[0] + 1) if hit.size else slots
+                rounds += 1
+            rr.append(rounds)
+        per_rounds.append(rr)
+    per_acc, per_rounds = np.array(per_acc), np.array(per_rounds)
+    return {"slots_per_round": slots, "accepted_steps_per_interval_mean": float(per_acc.mean()),
+            "accepted_steps_per_interval_max_over_replicas_mean": float(per_acc.max(axis=1).mean()),
+            "rounds_per_interval_mean": float(per_rounds.mean()),
+            "rounds_per_interval_max_over_replicas_mean": float(per_rounds.max(axis=1).mean()),
+            "note": "an interval ends when its slowest replica does (synchronous swap barrier, REG:730-752); every accepted "
+                    "Langevin step costs one more sequential SGD epoch whatever the number of speculative slots"}
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -289,7 +317,9 @@ def main():
         nsw1, tot1, _ = s.swap_stats()
         accepted = s.state()["num_accepted"]
         steps_done = s.steps_done()
+        chain = dependent_chain(s, W, K, si) if rank == 0 else None
     else:
+        chain = None
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -363,6 +393,8 @@ def main():
                          "note": "instruction-issue bound by construction (sequential SGD rows, AI 627 flop/B); the HBM "
                                  "fraction is reported because BASELINE.json asks for it"},
         }
+        if chain is not None:
+            out["dependent_chain"] = chain
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
