@@ -473,22 +473,32 @@ __device__ __forceinline__ void sgd_sweep_dispatch(const float* w_in, float* w_o
 }
 
 // ------------------------------------------------------------------------------------------------
-// packed forward layout: fw[h] = { W1[0..I-1][h], B1[h], W2[h][0..O-1], pad } (FWS floats, 16-B aligned rows),
-// then B2[0..O-1] at fw[H*FWS].  Built by all threads from a flat w.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// packed forward layout, hidden units in PAIRS so that the forward pass runs on v_pk_fma_f32: pair hp = units (2hp, 2hp+1)
+// occupies 2 FWS floats, element c of unit j at [2c + j] with c = 0..I-1: W1[c][h], c = I: B1[h], c = I+1+o: W2[h][o];
+// an absent odd unit is all zeros (its hid = 0.5 meets W2 = 0).  B2[0..O-1] follows at fw[fw_pairs(H) * 2 FWS].
+// Built by all threads from a flat w.
 // ------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int fw_pairs(int H) { return (H + 1) >> 1; }
+__host__ __device__ inline size_t fw_floats(int H, int FWS) { return ((size_t)2 * fw_pairs(H) + 1) * FWS; }
+
 template <int I, int O, bool WL = false>
 __device__ __forceinline__ void build_fw(const float* __restrict__ w, float* __restrict__ fw, int H, int FWS) {
     const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
     constexpr int K = I + 1 + O;
-    for (int e = gtid<WL>(); e < H * K; e += gsize<WL>()) {
+    const int HP2 = 2 * fw_pairs(H);
+    for (int e = gtid<WL>(); e < HP2 * K; e += gsize<WL>()) {
         const int h = e / K, c = e - h * K;
-        float v;
-        if (c < I) v = w[c * H + h];
-        else if (c == I) v = w[oB1 + h];
-        else v = w[oW2 + h * O + (c - I - 1)];
-        fw[h * FWS + c] = v;
+        float v = 0.0f;
+        if (h < H) {
+            if (c < I) v = w[c * H + h];
+            else if (c == I) v = w[oB1 + h];
+            else v = w[oW2 + h * O + (c - I - 1)];
+        }
+        fw[(h >> 1) * 2 * FWS + 2 * c + (h & 1)] = v;
     }
-    if (gtid<WL>() < O) fw[H * FWS + gtid<WL>()] = w[oB2 + gtid<WL>()];
+    if (gtid<WL>() < O) fw[HP2 * FWS + gtid<WL>()] = w[oB2 + gtid<WL>()];
 }
 
 // Ordering key of np.argmax over the reference's FLOAT64 sigmoid outputs, computed from the fp32 pre-activation z.
@@ -527,7 +537,7 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
     constexpr int RB = ((I + 1) * 8 <= 64) ? 8 : ((I + 1) * 4 <= 64) ? 4 : ((I + 1) * 2 <= 80) ? 2 : 1;
     float b2[O];
 #pragma unroll
-    for (int o = 0; o < O; ++o) b2[o] = fw[H * FWS + o];
+    for (int o = 0; o < O; ++o) b2[o] = fw[2 * fw_pairs(H) * FWS + o];
     const int stride = gsize<WL>();
     // one block = RBK rows of this lane (rows tid + (b0 + b) stride); the last rows of a lane take the smaller blockings,
     // so a small data set spread over many lanes costs one row per lane, not RB.  Every lane adds its rows in ascending
@@ -537,27 +547,50 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
         const int n0 = gtid<WL>() + b0 * stride;
         const int nc = n0 < Nall ? n0 : 0;
         float x[RBK][I + 1];
-        float acc[RBK][O];
+        f32x2 acc2[RBK][O];                                // {even units, odd units}: joined after the hidden loop
 #pragma unroll
         for (int b = 0; b < RBK; ++b) {
             const int n = n0 + b * stride;
             lds_load<I + 1>(xy + (n < Nall ? n : nc) * IPY, x[b]);
 #pragma unroll
-            for (int o = 0; o < O; ++o) acc[b][o] = -b2[o];
+            for (int o = 0; o < O; ++o) acc2[b][o] = f32x2{0.0f, 0.0f};
         }
-        for (int h = 0; h < H; ++h) {
-            float f[K];
-            lds_load<K>(fw + h * FWS, f);                  // wave-uniform address: broadcast reads
+        const int HP = fw_pairs(H);
+        constexpr int CH = 8, NF = I / CH, RQ = K - NF * CH;   // inputs in chunks of 8 pairs: bounded register footprint
+        for (int hp = 0; hp < HP; ++hp) {
+            const float* row = fw + hp * 2 * FWS;          // wave-uniform address: broadcast reads
+            f32x2 z[RBK];
+#pragma unroll
+            for (int b = 0; b < RBK; ++b) z[b] = f32x2{0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < NF; ++q) {
+                float f[2 * CH];
+                lds_load<2 * CH>(row + 2 * CH * q, f);
+#pragma unroll
+                for (int b = 0; b < RBK; ++b)
+#pragma unroll
+                    for (int i = 0; i < CH; ++i)
+                        z[b] = __builtin_elementwise_fma(f32x2{x[b][CH * q + i], x[b][CH * q + i]}, f32x2{f[2 * i], f[2 * i + 1]}, z[b]);
+            }
+            float f[2 * RQ];                                // the remaining inputs, B1, W2
+            lds_load<2 * RQ>(row + 2 * CH * NF, f);
 #pragma unroll
             for (int b = 0; b < RBK; ++b) {
-                float z = -f[I];
 #pragma unroll
-                for (int i = 0; i < I; ++i) z = fmaf(x[b][i], f[i], z);
-                const float hid = sigmoidf_fast(z);
+                for (int i = NF * CH; i < I; ++i)
+                    z[b] = __builtin_elementwise_fma(f32x2{x[b][i], x[b][i]}, f32x2{f[2 * (i - NF * CH)], f[2 * (i - NF * CH) + 1]}, z[b]);
+                const f32x2 zz = z[b] - f32x2{f[2 * (I - NF * CH)], f[2 * (I - NF * CH) + 1]};
+                const f32x2 hid = f32x2{sigmoidf_fast(zz.x), sigmoidf_fast(zz.y)};
 #pragma unroll
-                for (int o = 0; o < O; ++o) acc[b][o] = fmaf(hid, f[I + 1 + o], acc[b][o]);
+                for (int o = 0; o < O; ++o)
+                    acc2[b][o] = __builtin_elementwise_fma(hid, f32x2{f[2 * (I + 1 + o - NF * CH)], f[2 * (I + 1 + o - NF * CH) + 1]}, acc2[b][o]);
             }
         }
+        float acc[RBK][O];
+#pragma unroll
+        for (int b = 0; b < RBK; ++b)
+#pragma unroll
+            for (int o = 0; o < O; ++o) acc[b][o] = (acc2[b][o].x + acc2[b][o].y) - b2[o];
 #pragma unroll
         for (int b = 0; b < RBK; ++b) {
             const int n = n0 + b * stride;
@@ -642,15 +675,16 @@ __device__ __forceinline__ float reg_residual(const float* __restrict__ row, con
     constexpr int K = I + 1 + O;
     float x[I + 1];
     lds_load<I + 1>(row, x);
-    float acc = -fw[H * FWS];
-    for (int h = 0; h < H; ++h) {
-        float f[K];
-        lds_load<K>(fw + h * FWS, f);
-        float z = -f[I];
+    f32x2 acc2 = f32x2{0.0f, 0.0f};
+    for (int hp = 0; hp < fw_pairs(H); ++hp) {
+        float f[2 * K];
+        lds_load<2 * K>(fw + hp * 2 * FWS, f);
+        f32x2 z = f32x2{-f[2 * I], -f[2 * I + 1]};
 #pragma unroll
-        for (int i = 0; i < I; ++i) z = fmaf(x[i], f[i], z);
-        acc = fmaf(sigmoidf_fast(z), f[I + 1], acc);
+        for (int i = 0; i < I; ++i) z = __builtin_elementwise_fma(f32x2{x[i], x[i]}, f32x2{f[2 * i], f[2 * i + 1]}, z);
+        acc2 = __builtin_elementwise_fma(f32x2{sigmoidf_fast(z.x), sigmoidf_fast(z.y)}, f32x2{f[2 * (I + 1)], f[2 * (I + 1) + 1]}, acc2);
     }
+    const float acc = (acc2.x + acc2.y) - fw[2 * fw_pairs(H) * FWS];
     return sigmoidf_fast(acc) - x[I];
 }
 
@@ -714,13 +748,13 @@ __device__ __forceinline__ Lds carve(float* base, int Nall, int IPY, int PS, int
     l.w_pgd = q; q += PS;
     l.rec_w = q; q += PS;
     l.noise = q; q += PS;
-    l.fw = q; q += (H + 1) * FWS;
+    l.fw = q; q += fw_floats(H, FWS);
     l.red = q; q += MAX_WAVES * 8;
     l.scal = q; q += 8;
     return l;
 }
 __host__ __device__ inline size_t lds_floats(int Nall, int IPY, int PS, int H, int FWS) {
-    return (size_t)(Nall + 2) * IPY + 6 * (size_t)PS + (size_t)(H + 1) * FWS + MAX_WAVES * 8 + 8;
+    return (size_t)(Nall + 2) * IPY + 6 * (size_t)PS + fw_floats(H, FWS) + MAX_WAVES * 8 + 8;
 }
 
 // random tape of one step: noise[0..P) and scal[0..2] = {lx, u, n_eta}
@@ -788,6 +822,21 @@ __device__ __forceinline__ void chain_startup(const SegParams& p, const float* x
 // The segment kernel: MH steps [step_begin, step_begin + n_steps) of every local replica; block = replica.
 // step_begin == 0 also performs the chain start-up (REG:266-285).
 // ------------------------------------------------------------------------------------------------
+// Diagnostic build only (-DPTNN_STAMPS): wave 0 of the first work-group of replica 0 adds up shader-clock cycles per phase
+// of a round and writes the sums to p.stamps at the end.  In the product build no stamp executes.
+#ifdef PTNN_STAMPS
+#define STAMP(slot)                                                                          \
+    do {                                                                                     \
+        if (stamp_on) {                                                                      \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                      \
+            __builtin_amdgcn_s_waitcnt(0xC07F);                                              \
+            stamp_acc[slot] += t_ - stamp_last; stamp_last = t_;                             \
+        }                                                                                    \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 template <int TASK, int I, int O>
 __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -832,8 +881,16 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
         nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT];
     }
 
+#ifdef PTNN_STAMPS
+    const bool stamp_on = (blockIdx.x == 0 && tid < WAVE);
+    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const unsigned long long stamp_t0 = stamp_last;
+#endif
     const size_t trow = (size_t)r * p.trace_cap;        // traces are rings of trace_cap rows per replica (== S unless streaming)
     for (int i = step_begin; i < step_begin + n_steps; ++i) {
+        STAMP(0);
         // R10 temperature schedule (REG:317-324): tempered until the switch step, canonical afterwards
         float adapttemp = (p.switch_step >= 0 && i >= p.switch_step) ? 1.0f : T;
         if (i == p.switch_step) {
@@ -848,6 +905,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
         }
         tape_step(p, gid, i, l.noise, l.scal);
         __syncthreads();
+        STAMP(1);                                         // tape
         const float lx = l.scal[0], u = l.scal[1], n_eta = l.scal[2];
         float diff_prop = 0.0f;
         const bool lg = p.use_lg && (lx < p.l_prob);
@@ -875,13 +933,16 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
         }
         float eta_pro = eta;
         if (TASK == TASK_REG) { eta_pro = fmaf(p.step_eta, n_eta, eta); tau_eta_last = eta_pro; }
+        STAMP(2);                                         // proposal (+ SGD epochs)
 
         build_fw<I, O>(l.w_prop, l.fw, H, p.FWS);
         __syncthreads();
+        STAMP(3);                                         // packed forward image
         const EvalSums es = eval_rows<TASK, I, O>(l.fw, l.xy, p.IPY, p.FWS, H, p.Ntr, Nall, l.red);
         float ll, rm_tr, rm_te, ac_tr, ac_te;
         finish_eval<TASK>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
         const float lik_prop = ll / adapttemp;
+        STAMP(4);                                         // forward pass over all rows + likelihood
         const float ssq = block_sumsq(l.w_prop, P, l.red);
         const float prior_prop = prior_value<TASK>(p, ssq, eta_pro);
 
@@ -905,6 +966,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
             }
         }
         __syncthreads();
+        STAMP(5);                                         // prior, MH, state update
         // trace row i+1 (the only HBM traffic of a step)
         const size_t tpos = trow + (size_t)((i + 1) % p.trace_cap);
         float* prow = p.tr_pos_w + tpos * (size_t)P;
@@ -917,7 +979,15 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
             p.tr_acc_tr[tpos] = rec_acc_tr;
             p.tr_acc_te[tpos] = rec_acc_te;
         }
+        STAMP(6);                                         // trace row
     }
+#ifdef PTNN_STAMPS
+    if (stamp_on && (tid & 63) == 0 && p.stamps) {
+        for (int q_ = 0; q_ < 9; ++q_) atomicAdd(p.stamps + q_, stamp_acc[q_]);
+        atomicAdd(p.stamps + 9, (unsigned long long)n_steps);
+        atomicAdd(p.stamps + 10, __builtin_amdgcn_s_memtime() - stamp_t0);
+    }
+#endif
 
     // write the chain state back and post the swap scalars
     __syncthreads();
@@ -950,7 +1020,7 @@ enum { SL_ACCEPT = 0, SL_LIKPROP, SL_PRIORPROP, SL_ETAPRO, SL_RM_TR, SL_RM_TE, S
 constexpr int MAX_SLOTS = 64;          // speculative steps per round: work-groups per replica x waves per work-group
 constexpr unsigned SPIN_LIMIT = 1u << 22;   // x (s_sleep 2 + one L2 round trip) = a few seconds, then the launch gives up
 
-__host__ __device__ inline size_t spec_wave_floats(int PS, int H, int FWS) { return 3 * (size_t)PS + (size_t)(H + 1) * FWS + 8; }
+__host__ __device__ inline size_t spec_wave_floats(int PS, int H, int FWS) { return 3 * (size_t)PS + fw_floats(H, FWS) + 8; }
 __host__ __device__ inline size_t spec_lds_floats(int Nall, int IPY, int PS, int H, int FWS, int NW, int G) {
     return (size_t)(Nall + 2) * IPY + 3 * (size_t)PS + MAX_WAVES * 8 + (size_t)NW * G * SL_COUNT + (size_t)NW * spec_wave_floats(PS, H, FWS);
 }
@@ -972,20 +1042,6 @@ __device__ __forceinline__ bool granule_wait(const granule_t* g, unsigned epoch,
     return false;
 }
 
-// Diagnostic build only (-DPTNN_STAMPS): wave 0 of the first work-group of replica 0 adds up shader-clock cycles per phase
-// of a round and writes the sums to p.stamps at the end.  In the product build no stamp executes.
-#ifdef PTNN_STAMPS
-#define STAMP(slot)                                                                          \
-    do {                                                                                     \
-        if (stamp_on) {                                                                      \
-            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                      \
-            __builtin_amdgcn_s_waitcnt(0xC07F);                                              \
-            stamp_acc[slot] += t_ - stamp_last; stamp_last = t_;                             \
-        }                                                                                    \
-    } while (0)
-#else
-#define STAMP(slot) do { } while (0)
-#endif
 
 // p.G work-groups (one per CU) cooperate on one replica: work-group g, wave v owns speculative slot g*NW + v.
 // Every work-group keeps its own LDS copy of the chain state and applies the same commits, so the copies never
@@ -1022,7 +1078,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
     float* my_pgd = mine + PS;
     float* my_noise = mine + 2 * PS;
     float* my_fw = mine + 3 * PS;
-    float* my_scal = my_fw + (H + 1) * p.FWS;
+    float* my_scal = my_fw + fw_floats(H, p.FWS);
     // exchange areas of this replica (G > 1): [parity][slot][16] result granules, [parity][slot][2 PS] proposal granules
     granule_t* xs = p.xslots + (size_t)r * 2 * MAX_SLOTS * SL_COUNT;
     granule_t* xw = p.xw + (size_t)r * 2 * MAX_SLOTS * 2 * PS;
@@ -1306,7 +1362,7 @@ constexpr int PK_SLOTS = 16, PK_NRED = 3, PK_NG = 8, PK_WAVES = 4, PK_SWEEP_WAVE
 __host__ __device__ inline size_t pack_slot_floats(int PS) { return 3 * (size_t)PS + 8; }
 __host__ __device__ inline size_t pack_lds_floats(int Nall, int IPY, int PS, int H, int FWS) {
     return (size_t)(Nall + 2) * IPY + 3 * (size_t)PS + MAX_WAVES * 8 + (size_t)PK_SLOTS * SL_COUNT +
-           (size_t)PK_SLOTS * pack_slot_floats(PS) + (size_t)PK_WAVES * (H + 1) * FWS;
+           (size_t)PK_SLOTS * pack_slot_floats(PS) + (size_t)PK_WAVES * fw_floats(H, FWS);
 }
 
 template <int TASK, int I, int O>
@@ -1327,7 +1383,7 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
     float* slots = q; q += PK_SLOTS * SL_COUNT;
     const size_t SLF = pack_slot_floats(PS);                // per slot: proposal, its SGD epoch, noise, 8 scalars
     float* sl0 = q; q += PK_SLOTS * SLF;
-    float* my_fw = q + (size_t)wave * (H + 1) * p.FWS;
+    float* my_fw = q + (size_t)wave * fw_floats(H, p.FWS);
     auto s_prop = [&](int s_) { return sl0 + (size_t)s_ * SLF; };
     auto s_pgd = [&](int s_) { return sl0 + (size_t)s_ * SLF + PS; };
     auto s_noise = [&](int s_) { return sl0 + (size_t)s_ * SLF + 2 * PS; };
@@ -1604,11 +1660,11 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
 // and through L2 in the forward pass.  Cooperative schedule only.
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t wide_lds_floats(int H, int FWS, int O, int PS) {
-    const size_t img = ((size_t)(H + 1) * FWS > (size_t)PS) ? (size_t)(H + 1) * FWS : (size_t)PS;   // packed or flat image
+    const size_t img = (fw_floats(H, FWS) > (size_t)PS) ? fw_floats(H, FWS) : (size_t)PS;   // packed or flat image
     return img + MAX_WAVES * 8 + 2 * MAX_WAVES * (size_t)((O + 3) & ~3) + 16;
 }
 __host__ __device__ inline size_t wide_img_floats(int H, int FWS, int PS) {
-    return ((size_t)(H + 1) * FWS > (size_t)PS) ? (size_t)(H + 1) * FWS : (size_t)PS;
+    return (fw_floats(H, FWS) > (size_t)PS) ? fw_floats(H, FWS) : (size_t)PS;
 }
 
 // R5 for H > 64: thread h owns hidden unit h; the output pre-activation is a two-level sum (DPP inside the wave, then the
