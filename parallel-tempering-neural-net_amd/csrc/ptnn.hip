@@ -74,6 +74,7 @@ struct ptnn_handle {
     float* d_wide_scratch = nullptr;
     float* d_xt = nullptr;          // transposed data image for the MFMA forward pass
     int Npad = 0;
+    bool fw_mfma = false;           // cooperative schedule: forward pass on the matrix cores (24 <= H <= 64, I >= 6)
     int groups = 1;                 // work-groups (CUs) per replica in the speculative schedule
     unsigned epoch_base = 0;
     int num_cus = 0;
@@ -132,7 +133,7 @@ struct ptnn_handle {
         p.L_raw = (cfg.swap_rule == 1) ? d_L_raw : nullptr; p.prior_post = d_prior_post;
         p.tr_pos_w = d_pos_w; p.tr_likeh = d_likeh; p.tr_rmse_tr = d_rmse_tr; p.tr_rmse_te = d_rmse_te;
         p.tr_acc_tr = d_acc_tr; p.tr_acc_te = d_acc_te; p.tr_accept = d_accept;
-        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.xt = d_xt; p.Npad = Npad; p.forward_bf16 = cfg.forward_bf16;
+        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.xt = d_xt; p.Npad = Npad; p.fw_mfma = fw_mfma ? 1 : 0; p.forward_bf16 = cfg.forward_bf16;
         return p;
     }
 };
@@ -358,6 +359,17 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         }
     }
     const int H = h->cfg.n_hidden;
+    // transposed image Xt[k][Npad] for the MFMA forward passes (rows = data rows are the lanes of the B operand)
+    h->Npad = (Nall + 31) & ~31;
+    {
+        std::vector<float> xt((size_t)I * h->Npad, 0.0f);
+        for (int n = 0; n < Nall; ++n)
+            for (int k = 0; k < I; ++k) xt[(size_t)k * h->Npad + n] = packed[(size_t)n * IPY + k];
+        if (h->d_xt) { HIP_TRY(hipFree(h->d_xt)); h->d_xt = nullptr; }
+        HIP_TRY(hipMalloc(&h->d_xt, xt.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(h->d_xt, xt.data(), xt.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    h->fw_mfma = false;
     if (H > WAVE) {
         // wide net: one thread per hidden unit, vectors in HBM, only the packed forward image + scratch in LDS
         const size_t lds = wide_lds_floats(H, h->FWS, h->cfg.n_out, h->PS) * sizeof(float);
@@ -372,16 +384,6 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         HIP_TRY(hipMalloc(&h->d_data, packed.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(h->d_data, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
         if (!h->d_wide_scratch) HIP_TRY(hipMalloc(&h->d_wide_scratch, (size_t)h->cfg.n_replicas_local * 3 * h->PS * sizeof(float)));
-        // transposed image Xt[k][Npad] for the MFMA forward pass (rows = data rows are the lanes of the B operand)
-        h->Npad = (Nall + 31) & ~31;
-        {
-            std::vector<float> xt((size_t)I * h->Npad, 0.0f);
-            for (int n = 0; n < Nall; ++n)
-                for (int k = 0; k < I; ++k) xt[(size_t)k * h->Npad + n] = packed[(size_t)n * IPY + k];
-            if (h->d_xt) { HIP_TRY(hipFree(h->d_xt)); h->d_xt = nullptr; }
-            HIP_TRY(hipMalloc(&h->d_xt, xt.size() * sizeof(float)));
-            HIP_TRY(hipMemcpy(h->d_xt, xt.data(), xt.size() * sizeof(float), hipMemcpyHostToDevice));
-        }
         if (lds > 64 * 1024) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->shape->seg_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->shape->model_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -468,6 +470,9 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         h->speculative = false;
         h->nthreads = (nw ? nw : coop_nw) * 64;
         h->seg_lds = coop_lds;
+        // a hidden layer that fills most of a 32-unit tile and at least three k-steps: forward pass on the matrix cores
+        // (the VALU pass re-reads the weights from LDS with broadcast reads and is bound by the LDS pipe at this size)
+        h->fw_mfma = (H >= 24 && I >= 6);
     }
     h->Ntr = ntr; h->Nte = nte;
     if (h->d_data) { HIP_TRY(hipFree(h->d_data)); h->d_data = nullptr; }

@@ -34,6 +34,7 @@ enum { SI_NACC = 0, SI_UNUSED, SI_LG_COUNT, SI_LG_ACC, SI_COUNT = 4 };   // acce
 struct SegParams {
     int H, P, PS;            // hidden units, parameters, state row length (P + 1 rounded up to 4)
     int Ntr, Nte, IPY, FWS;  // rows, data row stride (floats), packed forward row stride (floats)
+    int fw_mfma;             // cooperative schedule: forward pass on the matrix cores (host decides: 24 <= H <= 64, I >= 6)
     int S, switch_step, use_lg;
     int trace_cap;           // rows per replica in the trace rings
     int first_global;
@@ -822,6 +823,136 @@ __device__ __forceinline__ void chain_startup(const SegParams& p, const float* x
 // The segment kernel: MH steps [step_begin, step_begin + n_steps) of every local replica; block = replica.
 // step_begin == 0 also performs the chain start-up (REG:266-285).
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Forward pass of a mid-sized net (24 <= H <= 64) on the matrix cores, cooperative schedule.  The lane-per-row VALU pass
+// re-reads every weight from LDS with all 64 lanes on one address (one 16-byte broadcast read per 4 weights and wave): at
+// 34 inputs x 50 hidden units the LDS pipe, not the VALU, bounds it.  Here the product is taken transposed,
+// Z^T[h][n] = sum_k W1[k][h] X[n][k] with v_mfma_f32_32x32x2_f32: A = W1 straight from the flat proposal in LDS (lane = hidden
+// unit: conflict-free 4-byte reads, all k-steps of a tile fetched in one batch), B = the transposed data image from L2
+// (lane = data row), two hidden tiles with independent accumulators in flight; in the 32x32 accumulator a lane is a data
+// row and the 16 registers are hidden units, so bias, sigmoid and the W2 product are applied in place (same epilogue as
+// eval_rows_mfma).  Exact fp32 (k-ordered fma chains).  A partial last tile is masked: absent units get W1 = W2 = 0.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int TASK, int I, int O>
+__device__ __forceinline__ EvalSums eval_rows_mfma_coop(const float* __restrict__ wl, const float* __restrict__ xt,
+                                                        const float* __restrict__ xy, int IPY, int H, int Ntr, int Nall,
+                                                        int Npad, float* __restrict__ red) {
+    constexpr int IK = (I + 1) & ~1, KS = IK / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
+    float a_tr = 0.f, b_tr = 0.f, c_tr = 0.f, a_te = 0.f, b_te = 0.f, c_te = 0.f;
+    float b2[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) b2[o] = wl[oB2 + o];
+    const int ntiles = (H + 31) >> 5;
+    // every load below is unconditional on a clamped index and masked by a select afterwards: no divergent control flow
+    for (int rb = wave; rb * 32 < Nall; rb += nw) {
+        const int n = rb * 32 + col;                                   // this lane's data row (Npad covers the last block)
+        float bf[KS];
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            const int k = 2 * s_ + half;
+            const float v = xt[(size_t)(k < I ? k : I - 1) * Npad + n];
+            bf[s_] = (IK == I || k < I) ? v : 0.0f;
+        }
+        float sum[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) sum[o] = 0.0f;
+        for (int t = 0; t < ntiles; ++t) {
+            const int hbase = t * 32;
+            const int h_a = hbase + col;
+            const bool h_in = h_a < H;
+            const int h_c = h_in ? h_a : H - 1;
+            float aa[KS];
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) {                          // all k-steps of the tile in one batch of LDS reads
+                const int k = 2 * s_ + half;
+                const float v = wl[(k < I ? k : I - 1) * H + h_c];
+                aa[s_] = (h_in && (IK == I || k < I)) ? v : 0.0f;
+            }
+            // bias and W2 rows of this lane's 16 hidden units, fetched while the matrix pipe works
+            float b1r[16], w2r[16][O];
+#pragma unroll
+            for (int r_ = 0; r_ < 16; ++r_) {
+                const int h = hbase + 8 * (r_ >> 2) + 4 * half + (r_ & 3);
+                const bool in = h < H;
+                const int hc = in ? h : H - 1;
+                b1r[r_] = wl[oB1 + hc];
+#pragma unroll
+                for (int o = 0; o < O; ++o) { const float v = wl[oW2 + hc * O + o]; w2r[r_][o] = in ? v : 0.0f; }
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r_ = 0; r_ < 16; ++r_) acc[r_] = 0.0f;
+#pragma unroll
+            for (int s_ = 0; s_ < KS; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[s_], bf[s_], acc, 0, 0, 0);
+#pragma unroll
+            for (int r_ = 0; r_ < 16; ++r_) {
+                const float hid = sigmoidf_fast(acc[r_] - b1r[r_]);
+#pragma unroll
+                for (int o = 0; o < O; ++o) sum[o] = fmaf(hid, w2r[r_][o], sum[o]);
+            }
+        }
+        float tot[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) {                                  // hidden units 4..7, 12..15, ... live in lanes 32..63
+            const unsigned u = __builtin_bit_cast(unsigned, sum[o]);
+            auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+            tot[o] = __builtin_bit_cast(float, (unsigned)r2[0]) + __builtin_bit_cast(float, (unsigned)r2[1]) - b2[o];
+        }
+        if (half == 0 && n < Nall) {
+            const float y = xy[(size_t)n * IPY + I];
+            float a, bb = 0.f, c = 0.f;
+            if (TASK == TASK_REG) {
+                const float d = y - sigmoidf_fast(tot[0]);
+                a = d * d;
+            } else {
+                ArgKey best = argmax_key(tot[0]);
+                float se = 0.0f, oy = 0.0f;
+                int arg = 0;
+                const int yi = (int)y;
+#pragma unroll
+                for (int o = 0; o < O; ++o) {
+                    const float out = sigmoidf_fast(tot[o]);
+                    const ArgKey key = argmax_key(tot[o]);
+                    if (argkey_greater(key, best)) { best = key; arg = o; }
+                    se += expf_fast(out);
+                    oy = (o == yi) ? out : oy;
+                }
+                a = oy - logf_fast(se);
+                const float dd = (float)arg - y;
+                bb = dd * dd;
+                c = ((float)arg == y) ? 1.0f : 0.0f;
+            }
+            if (n < Ntr) { a_tr += a; b_tr += bb; c_tr += c; }
+            else { a_te += a; b_te += bb; c_te += c; }
+        }
+    }
+    a_tr = wave_allsum(a_tr);
+    a_te = wave_allsum(a_te);
+    if (TASK == TASK_CLS) {
+        b_tr = wave_allsum(b_tr); c_tr = wave_allsum(c_tr);
+        b_te = wave_allsum(b_te); c_te = wave_allsum(c_te);
+    }
+    EvalSums s;
+    __syncthreads();
+    if (lane == 0) {
+        float* r = red + wave * 8;
+        r[0] = a_tr; r[1] = b_tr; r[2] = c_tr; r[3] = a_te; r[4] = b_te; r[5] = c_te;
+    }
+    __syncthreads();
+    s.a_tr = s.b_tr = s.c_tr = s.a_te = s.b_te = s.c_te = 0.f;
+    for (int k = 0; k < nw; ++k) {
+        const float* r = red + k * 8;
+        s.a_tr += r[0]; s.b_tr += r[1]; s.c_tr += r[2]; s.a_te += r[3]; s.b_te += r[4]; s.c_te += r[5];
+    }
+    return s;
+}
+
+
 // Diagnostic build only (-DPTNN_STAMPS): wave 0 of the first work-group of replica 0 adds up shader-clock cycles per phase
 // of a round and writes the sums to p.stamps at the end.  In the product build no stamp executes.
 #ifdef PTNN_STAMPS
@@ -895,9 +1026,14 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
         float adapttemp = (p.switch_step >= 0 && i >= p.switch_step) ? 1.0f : T;
         if (i == p.switch_step) {
             // re-evaluate the current w with the LAST PROPOSED tau (Q9, REG:322)
-            build_fw<I, O>(l.w_cur, l.fw, H, p.FWS);
-            __syncthreads();
-            const EvalSums sc = eval_rows<TASK, I, O>(l.fw, l.xy, p.IPY, p.FWS, H, p.Ntr, Nall, l.red);
+            EvalSums sc;
+            if (p.fw_mfma) {
+                sc = eval_rows_mfma_coop<TASK, I, O>(l.w_cur, p.xt, l.xy, p.IPY, H, p.Ntr, Nall, p.Npad, l.red);
+            } else {
+                build_fw<I, O>(l.w_cur, l.fw, H, p.FWS);
+                __syncthreads();
+                sc = eval_rows<TASK, I, O>(l.fw, l.xy, p.IPY, p.FWS, H, p.Ntr, Nall, l.red);
+            }
             float ll, r1, r2, a1, a2;
             finish_eval<TASK>(sc, p.Ntr, p.Nte, tau_eta_last, ll, r1, r2, a1, a2);
             lik = ll;                                       // adapttemp == 1
@@ -935,10 +1071,16 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
         if (TASK == TASK_REG) { eta_pro = fmaf(p.step_eta, n_eta, eta); tau_eta_last = eta_pro; }
         STAMP(2);                                         // proposal (+ SGD epochs)
 
-        build_fw<I, O>(l.w_prop, l.fw, H, p.FWS);
-        __syncthreads();
-        STAMP(3);                                         // packed forward image
-        const EvalSums es = eval_rows<TASK, I, O>(l.fw, l.xy, p.IPY, p.FWS, H, p.Ntr, Nall, l.red);
+        EvalSums es;
+        if (p.fw_mfma) {
+            STAMP(3);
+            es = eval_rows_mfma_coop<TASK, I, O>(l.w_prop, p.xt, l.xy, p.IPY, H, p.Ntr, Nall, p.Npad, l.red);
+        } else {
+            build_fw<I, O>(l.w_prop, l.fw, H, p.FWS);
+            __syncthreads();
+            STAMP(3);                                     // packed forward image
+            es = eval_rows<TASK, I, O>(l.fw, l.xy, p.IPY, p.FWS, H, p.Ntr, Nall, l.red);
+        }
         float ll, rm_tr, rm_te, ac_tr, ac_te;
         finish_eval<TASK>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
         const float lik_prop = ll / adapttemp;
@@ -1775,7 +1917,6 @@ __device__ __forceinline__ void sgd_sweep_wide(const float* __restrict__ w_in, f
 // (exact fp32, k-ordered fma chain) or 16 per v_mfma_f32_32x32x16_bf16 (BF16 = true: operands rounded to bf16,
 // fp32 accumulation; the tolerance study of BASELINE config 5).  Needs H % 32 == 0; I is zero-padded to IK.
 // ------------------------------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ short f32_to_bf16(float f) {            // round to nearest even; inputs are finite
