@@ -835,101 +835,115 @@ __device__ __forceinline__ void chain_startup(const SegParams& p, const float* x
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// LDS floats the MFMA forward pass of the cooperative schedule adds: the transposed data image and the per-tile partial
+// output sums of every row
+__host__ __device__ inline size_t mfma_coop_lds_floats(int I, int O, int H, int Npad) {
+    return (size_t)I * Npad + (size_t)((H + 31) >> 5) * Npad * O;
+}
+
 template <int TASK, int I, int O>
 __device__ __forceinline__ EvalSums eval_rows_mfma_coop(const float* __restrict__ wl, const float* __restrict__ xt,
-                                                        const float* __restrict__ xy, int IPY, int H, int Ntr, int Nall,
-                                                        int Npad, float* __restrict__ red) {
+                                                        float* __restrict__ part, const float* __restrict__ xy, int IPY,
+                                                        int H, int Ntr, int Nall, int Npad, float* __restrict__ red) {
     constexpr int IK = (I + 1) & ~1, KS = IK / 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: the unit loops branch on the SALU
     const int col = lane & 31, half = lane >> 5;
     const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
+    const int ntiles = (H + 31) >> 5;
+    // phase 1: one unit = 32 data rows x 32 hidden units; units are dealt round-robin to the waves (11 row blocks x 2 tiles
+    // over 8 waves: 3 or 2 each).  Straight-line address arithmetic, no divergent control flow: absent units of a partial
+    // tile read the last real unit again / whatever follows in LDS (finite weights) and meet W2 = 0.
+    const int nunits = (Npad >> 5) * ntiles;
+    for (int u = wave; u < nunits; u += nw) {
+        const int rb = (ntiles == 1) ? u : (u >> 1), t = (ntiles == 1) ? 0 : (u & 1);   // H <= 64: one or two tiles
+        const int n = rb * 32 + col;                                   // this lane's data row (Npad covers the last block)
+        const int hbase = t * 32;
+        const float* pa = wl + half * H + min(hbase + col, H - 1);
+        const float* pb = xt + half * Npad + n;
+        float bf[KS], aa[KS];
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {                              // all k-steps in one batch of conflict-free LDS reads
+            const bool pad = (IK != I) && (s_ == KS - 1) && half;      // odd I: k = I of the upper lane half is padding
+            const float vb = pb[(size_t)s_ * 2 * Npad - (pad ? Npad : 0)];
+            const float va = pa[s_ * 2 * H - (pad ? H : 0)];
+            bf[s_] = pad ? 0.0f : vb;
+            aa[s_] = pad ? 0.0f : va;
+        }
+        // bias and W2 rows of this lane's 16 hidden units, fetched while the matrix pipe works
+        const int hq = hbase + 4 * half;
+        const float* pb1 = wl + oB1 + hq;
+        const float* pw2 = wl + oW2 + hq * O;
+        float b1r[16], w2r[16][O];
+#pragma unroll
+        for (int r_ = 0; r_ < 16; ++r_) {
+            const int dh = 8 * (r_ >> 2) + (r_ & 3);
+            b1r[r_] = pb1[dh];
+            const bool in = hq + dh < H;
+#pragma unroll
+            for (int o = 0; o < O; ++o) { const float v = pw2[dh * O + o]; w2r[r_][o] = in ? v : 0.0f; }
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r_ = 0; r_ < 16; ++r_) acc[r_] = 0.0f;
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[s_], bf[s_], acc, 0, 0, 0);
+        float sum[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) sum[o] = 0.0f;
+#pragma unroll
+        for (int r_ = 0; r_ < 16; ++r_) {
+            const float hid = sigmoidf_fast(acc[r_] - b1r[r_]);
+#pragma unroll
+            for (int o = 0; o < O; ++o) sum[o] = fmaf(hid, w2r[r_][o], sum[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < O; ++o) {                                  // hidden units 4..7, 12..15, ... live in lanes 32..63
+            const unsigned uu = __builtin_bit_cast(unsigned, sum[o]);
+            auto r2 = __builtin_amdgcn_permlane32_swap(uu, uu, false, false);
+            const float tot = __builtin_bit_cast(float, (unsigned)r2[0]) + __builtin_bit_cast(float, (unsigned)r2[1]);
+            if (half == 0) part[((size_t)t * Npad + n) * O + o] = tot;
+        }
+    }
+    __syncthreads();
+    // phase 2: one lane per data row joins the tiles (ascending) and scores the row
     float a_tr = 0.f, b_tr = 0.f, c_tr = 0.f, a_te = 0.f, b_te = 0.f, c_te = 0.f;
     float b2[O];
 #pragma unroll
     for (int o = 0; o < O; ++o) b2[o] = wl[oB2 + o];
-    const int ntiles = (H + 31) >> 5;
-    // every load below is unconditional on a clamped index and masked by a select afterwards: no divergent control flow
-    for (int rb = wave; rb * 32 < Nall; rb += nw) {
-        const int n = rb * 32 + col;                                   // this lane's data row (Npad covers the last block)
-        float bf[KS];
-#pragma unroll
-        for (int s_ = 0; s_ < KS; ++s_) {
-            const int k = 2 * s_ + half;
-            const float v = xt[(size_t)(k < I ? k : I - 1) * Npad + n];
-            bf[s_] = (IK == I || k < I) ? v : 0.0f;
-        }
-        float sum[O];
-#pragma unroll
-        for (int o = 0; o < O; ++o) sum[o] = 0.0f;
-        for (int t = 0; t < ntiles; ++t) {
-            const int hbase = t * 32;
-            const int h_a = hbase + col;
-            const bool h_in = h_a < H;
-            const int h_c = h_in ? h_a : H - 1;
-            float aa[KS];
-#pragma unroll
-            for (int s_ = 0; s_ < KS; ++s_) {                          // all k-steps of the tile in one batch of LDS reads
-                const int k = 2 * s_ + half;
-                const float v = wl[(k < I ? k : I - 1) * H + h_c];
-                aa[s_] = (h_in && (IK == I || k < I)) ? v : 0.0f;
-            }
-            // bias and W2 rows of this lane's 16 hidden units, fetched while the matrix pipe works
-            float b1r[16], w2r[16][O];
-#pragma unroll
-            for (int r_ = 0; r_ < 16; ++r_) {
-                const int h = hbase + 8 * (r_ >> 2) + 4 * half + (r_ & 3);
-                const bool in = h < H;
-                const int hc = in ? h : H - 1;
-                b1r[r_] = wl[oB1 + hc];
-#pragma unroll
-                for (int o = 0; o < O; ++o) { const float v = wl[oW2 + hc * O + o]; w2r[r_][o] = in ? v : 0.0f; }
-            }
-            f32x16 acc;
-#pragma unroll
-            for (int r_ = 0; r_ < 16; ++r_) acc[r_] = 0.0f;
-#pragma unroll
-            for (int s_ = 0; s_ < KS; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[s_], bf[s_], acc, 0, 0, 0);
-#pragma unroll
-            for (int r_ = 0; r_ < 16; ++r_) {
-                const float hid = sigmoidf_fast(acc[r_] - b1r[r_]);
-#pragma unroll
-                for (int o = 0; o < O; ++o) sum[o] = fmaf(hid, w2r[r_][o], sum[o]);
-            }
-        }
+    for (int n = threadIdx.x; n < Nall; n += blockDim.x) {
         float tot[O];
 #pragma unroll
-        for (int o = 0; o < O; ++o) {                                  // hidden units 4..7, 12..15, ... live in lanes 32..63
-            const unsigned u = __builtin_bit_cast(unsigned, sum[o]);
-            auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-            tot[o] = __builtin_bit_cast(float, (unsigned)r2[0]) + __builtin_bit_cast(float, (unsigned)r2[1]) - b2[o];
+        for (int o = 0; o < O; ++o) {
+            float v = part[(size_t)n * O + o];
+            if (ntiles > 1) v += part[((size_t)Npad + n) * O + o];
+            tot[o] = v - b2[o];
         }
-        if (half == 0 && n < Nall) {
-            const float y = xy[(size_t)n * IPY + I];
-            float a, bb = 0.f, c = 0.f;
-            if (TASK == TASK_REG) {
-                const float d = y - sigmoidf_fast(tot[0]);
-                a = d * d;
-            } else {
-                ArgKey best = argmax_key(tot[0]);
-                float se = 0.0f, oy = 0.0f;
-                int arg = 0;
-                const int yi = (int)y;
+        const float y = xy[(size_t)n * IPY + I];
+        float a, bb = 0.f, c = 0.f;
+        if (TASK == TASK_REG) {
+            const float d = y - sigmoidf_fast(tot[0]);
+            a = d * d;
+        } else {
+            ArgKey best = argmax_key(tot[0]);
+            float se = 0.0f, oy = 0.0f;
+            int arg = 0;
+            const int yi = (int)y;
 #pragma unroll
-                for (int o = 0; o < O; ++o) {
-                    const float out = sigmoidf_fast(tot[o]);
-                    const ArgKey key = argmax_key(tot[o]);
-                    if (argkey_greater(key, best)) { best = key; arg = o; }
-                    se += expf_fast(out);
-                    oy = (o == yi) ? out : oy;
-                }
-                a = oy - logf_fast(se);
-                const float dd = (float)arg - y;
-                bb = dd * dd;
-                c = ((float)arg == y) ? 1.0f : 0.0f;
+            for (int o = 0; o < O; ++o) {
+                const float out = sigmoidf_fast(tot[o]);
+                const ArgKey key = argmax_key(tot[o]);
+                if (argkey_greater(key, best)) { best = key; arg = o; }
+                se += expf_fast(out);
+                oy = (o == yi) ? out : oy;
             }
-            if (n < Ntr) { a_tr += a; b_tr += bb; c_tr += c; }
-            else { a_te += a; b_te += bb; c_te += c; }
+            a = oy - logf_fast(se);
+            const float dd = (float)arg - y;
+            bb = dd * dd;
+            c = ((float)arg == y) ? 1.0f : 0.0f;
         }
+        if (n < Ntr) { a_tr += a; b_tr += bb; c_tr += c; }
+        else { a_te += a; b_te += bb; c_te += c; }
     }
     a_tr = wave_allsum(a_tr);
     a_te = wave_allsum(a_te);
@@ -990,6 +1004,11 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
         l.rec_w[j] = p.rec_w[(size_t)r * PS + j];
         l.w_gd[j] = p.gd_w[(size_t)r * PS + j];
     }
+    // MFMA forward pass (host decides): transposed data image and per-tile partial sums behind the common LDS block
+    float* xt_l = smem + lds_floats(Nall, p.IPY, p.PS, p.H, p.FWS);
+    float* part_l = xt_l + (size_t)I * p.Npad;
+    if (p.fw_mfma)
+        for (int e = tid; e < I * p.Npad; e += nthr) xt_l[e] = p.xt[e];
     __syncthreads();
 
     const float T = p.temps[r];
@@ -1028,7 +1047,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
             // re-evaluate the current w with the LAST PROPOSED tau (Q9, REG:322)
             EvalSums sc;
             if (p.fw_mfma) {
-                sc = eval_rows_mfma_coop<TASK, I, O>(l.w_cur, p.xt, l.xy, p.IPY, H, p.Ntr, Nall, p.Npad, l.red);
+                sc = eval_rows_mfma_coop<TASK, I, O>(l.w_cur, xt_l, part_l, l.xy, p.IPY, H, p.Ntr, Nall, p.Npad, l.red);
             } else {
                 build_fw<I, O>(l.w_cur, l.fw, H, p.FWS);
                 __syncthreads();
@@ -1074,7 +1093,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
         EvalSums es;
         if (p.fw_mfma) {
             STAMP(3);
-            es = eval_rows_mfma_coop<TASK, I, O>(l.w_prop, p.xt, l.xy, p.IPY, H, p.Ntr, Nall, p.Npad, l.red);
+            es = eval_rows_mfma_coop<TASK, I, O>(l.w_prop, xt_l, part_l, l.xy, p.IPY, H, p.Ntr, Nall, p.Npad, l.red);
         } else {
             build_fw<I, O>(l.w_prop, l.fw, H, p.FWS);
             __syncthreads();

@@ -1,7 +1,7 @@
 """Per-phase cycles of one MH step of the cooperative kernel (diagnostic build: build_stamps.sh 1 34 2 / 1 4 3)."""
 import os, sys, numpy as np
 R=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["PTNN_LIBRARY"] = os.path.join(R, "profiles/tools/libptnn_stamps.so")
+os.environ.setdefault("PTNN_LIBRARY", os.path.join(R, "profiles/tools/libptnn_stamps.so"))
 sys.path.insert(0, R)
 import bench, time
 from ptnn_amd import _lib, ladder, philox
