@@ -484,22 +484,43 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 __host__ __device__ constexpr int fw_pairs(int H) { return (H + 1) >> 1; }
 __host__ __device__ inline size_t fw_floats(int H, int FWS) { return ((size_t)2 * fw_pairs(H) + 1) * FWS; }
 
+// Nets with few inputs (I < 8) and an odd or tiny hidden layer keep one unit per row of FWS floats (fw[h] = { W1[0..I-1][h], B1[h], W2[h][0..O-1] }, B2 at
+// fw[H*FWS]): their forward pass is sigmoid-bound and padding an odd H to a pair costs more than the packed FMAs save.
+// An even hidden layer of at least 8 units takes the pairs too (Iris 4-12-3).  The rule is a function of (I, H) only, so
+// build_fw and its readers agree without passing a flag around.
+template <int I>
+struct FwLayout {
+    static __host__ __device__ constexpr bool pairs(int H) { return I >= 8 || (H >= 8 && (H & 1) == 0); }
+};
+
 template <int I, int O, bool WL = false>
 __device__ __forceinline__ void build_fw(const float* __restrict__ w, float* __restrict__ fw, int H, int FWS) {
     const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
     constexpr int K = I + 1 + O;
-    const int HP2 = 2 * fw_pairs(H);
-    for (int e = gtid<WL>(); e < HP2 * K; e += gsize<WL>()) {
-        const int h = e / K, c = e - h * K;
-        float v = 0.0f;
-        if (h < H) {
+    if (FwLayout<I>::pairs(H)) {
+        const int HP2 = 2 * fw_pairs(H);
+        for (int e = gtid<WL>(); e < HP2 * K; e += gsize<WL>()) {
+            const int h = e / K, c = e - h * K;
+            float v = 0.0f;
+            if (h < H) {
+                if (c < I) v = w[c * H + h];
+                else if (c == I) v = w[oB1 + h];
+                else v = w[oW2 + h * O + (c - I - 1)];
+            }
+            fw[(h >> 1) * 2 * FWS + 2 * c + (h & 1)] = v;
+        }
+        if (gtid<WL>() < O) fw[HP2 * FWS + gtid<WL>()] = w[oB2 + gtid<WL>()];
+    } else {
+        for (int e = gtid<WL>(); e < H * K; e += gsize<WL>()) {
+            const int h = e / K, c = e - h * K;
+            float v;
             if (c < I) v = w[c * H + h];
             else if (c == I) v = w[oB1 + h];
             else v = w[oW2 + h * O + (c - I - 1)];
+            fw[h * FWS + c] = v;
         }
-        fw[(h >> 1) * 2 * FWS + 2 * c + (h & 1)] = v;
+        if (gtid<WL>() < O) fw[H * FWS + gtid<WL>()] = w[oB2 + gtid<WL>()];
     }
-    if (gtid<WL>() < O) fw[HP2 * FWS + gtid<WL>()] = w[oB2 + gtid<WL>()];
 }
 
 // Ordering key of np.argmax over the reference's FLOAT64 sigmoid outputs, computed from the fp32 pre-activation z.
@@ -538,7 +559,7 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
     constexpr int RB = ((I + 1) * 8 <= 64) ? 8 : ((I + 1) * 4 <= 64) ? 4 : ((I + 1) * 2 <= 80) ? 2 : 1;
     float b2[O];
 #pragma unroll
-    for (int o = 0; o < O; ++o) b2[o] = fw[2 * fw_pairs(H) * FWS + o];
+    for (int o = 0; o < O; ++o) b2[o] = fw[(FwLayout<I>::pairs(H) ? 2 * fw_pairs(H) : H) * FWS + o];
     const int stride = gsize<WL>();
     // one block = RBK rows of this lane (rows tid + (b0 + b) stride); the last rows of a lane take the smaller blockings,
     // so a small data set spread over many lanes costs one row per lane, not RB.  Every lane adds its rows in ascending
@@ -548,50 +569,72 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
         const int n0 = gtid<WL>() + b0 * stride;
         const int nc = n0 < Nall ? n0 : 0;
         float x[RBK][I + 1];
-        f32x2 acc2[RBK][O];                                // {even units, odd units}: joined after the hidden loop
+        float acc[RBK][O];
 #pragma unroll
         for (int b = 0; b < RBK; ++b) {
             const int n = n0 + b * stride;
             lds_load<I + 1>(xy + (n < Nall ? n : nc) * IPY, x[b]);
-#pragma unroll
-            for (int o = 0; o < O; ++o) acc2[b][o] = f32x2{0.0f, 0.0f};
         }
-        const int HP = fw_pairs(H);
-        constexpr int CH = 8, NF = I / CH, RQ = K - NF * CH;   // inputs in chunks of 8 pairs: bounded register footprint
-        for (int hp = 0; hp < HP; ++hp) {
-            const float* row = fw + hp * 2 * FWS;          // wave-uniform address: broadcast reads
-            f32x2 z[RBK];
+        if (FwLayout<I>::pairs(H)) {
+            f32x2 acc2[RBK][O];                            // {even units, odd units}: joined after the hidden loop
 #pragma unroll
-            for (int b = 0; b < RBK; ++b) z[b] = f32x2{0.0f, 0.0f};
+            for (int b = 0; b < RBK; ++b)
 #pragma unroll
-            for (int q = 0; q < NF; ++q) {
-                float f[2 * CH];
-                lds_load<2 * CH>(row + 2 * CH * q, f);
+                for (int o = 0; o < O; ++o) acc2[b][o] = f32x2{0.0f, 0.0f};
+            const int HP = fw_pairs(H);
+            constexpr int CH = 8, NF = I / CH, RQ = K - NF * CH;   // inputs in chunks of 8 pairs: bounded register footprint
+            for (int hp = 0; hp < HP; ++hp) {
+                const float* row = fw + hp * 2 * FWS;      // wave-uniform address: broadcast reads
+                f32x2 z[RBK];
 #pragma unroll
-                for (int b = 0; b < RBK; ++b)
+                for (int b = 0; b < RBK; ++b) z[b] = f32x2{0.0f, 0.0f};
 #pragma unroll
-                    for (int i = 0; i < CH; ++i)
-                        z[b] = __builtin_elementwise_fma(f32x2{x[b][CH * q + i], x[b][CH * q + i]}, f32x2{f[2 * i], f[2 * i + 1]}, z[b]);
+                for (int q = 0; q < NF; ++q) {
+                    float f[2 * CH];
+                    lds_load<2 * CH>(row + 2 * CH * q, f);
+#pragma unroll
+                    for (int b = 0; b < RBK; ++b)
+#pragma unroll
+                        for (int i = 0; i < CH; ++i)
+                            z[b] = __builtin_elementwise_fma(f32x2{x[b][CH * q + i], x[b][CH * q + i]}, f32x2{f[2 * i], f[2 * i + 1]}, z[b]);
+                }
+                float f[2 * RQ];                            // the remaining inputs, B1, W2
+                lds_load<2 * RQ>(row + 2 * CH * NF, f);
+#pragma unroll
+                for (int b = 0; b < RBK; ++b) {
+#pragma unroll
+                    for (int i = NF * CH; i < I; ++i)
+                        z[b] = __builtin_elementwise_fma(f32x2{x[b][i], x[b][i]}, f32x2{f[2 * (i - NF * CH)], f[2 * (i - NF * CH) + 1]}, z[b]);
+                    const f32x2 zz = z[b] - f32x2{f[2 * (I - NF * CH)], f[2 * (I - NF * CH) + 1]};
+                    const f32x2 hid = f32x2{sigmoidf_fast(zz.x), sigmoidf_fast(zz.y)};
+#pragma unroll
+                    for (int o = 0; o < O; ++o)
+                        acc2[b][o] = __builtin_elementwise_fma(hid, f32x2{f[2 * (I + 1 + o - NF * CH)], f[2 * (I + 1 + o - NF * CH) + 1]}, acc2[b][o]);
+                }
             }
-            float f[2 * RQ];                                // the remaining inputs, B1, W2
-            lds_load<2 * RQ>(row + 2 * CH * NF, f);
 #pragma unroll
-            for (int b = 0; b < RBK; ++b) {
+            for (int b = 0; b < RBK; ++b)
 #pragma unroll
-                for (int i = NF * CH; i < I; ++i)
-                    z[b] = __builtin_elementwise_fma(f32x2{x[b][i], x[b][i]}, f32x2{f[2 * (i - NF * CH)], f[2 * (i - NF * CH) + 1]}, z[b]);
-                const f32x2 zz = z[b] - f32x2{f[2 * (I - NF * CH)], f[2 * (I - NF * CH) + 1]};
-                const f32x2 hid = f32x2{sigmoidf_fast(zz.x), sigmoidf_fast(zz.y)};
+                for (int o = 0; o < O; ++o) acc[b][o] = (acc2[b][o].x + acc2[b][o].y) - b2[o];
+        } else {
 #pragma unroll
-                for (int o = 0; o < O; ++o)
-                    acc2[b][o] = __builtin_elementwise_fma(hid, f32x2{f[2 * (I + 1 + o - NF * CH)], f[2 * (I + 1 + o - NF * CH) + 1]}, acc2[b][o]);
+            for (int b = 0; b < RBK; ++b)
+#pragma unroll
+                for (int o = 0; o < O; ++o) acc[b][o] = -b2[o];
+            for (int h = 0; h < H; ++h) {
+                float f[K];
+                lds_load<K>(fw + h * FWS, f);              // wave-uniform address: broadcast reads
+#pragma unroll
+                for (int b = 0; b < RBK; ++b) {
+                    float z = -f[I];
+#pragma unroll
+                    for (int i = 0; i < I; ++i) z = fmaf(x[b][i], f[i], z);
+                    const float hid = sigmoidf_fast(z);
+#pragma unroll
+                    for (int o = 0; o < O; ++o) acc[b][o] = fmaf(hid, f[I + 1 + o], acc[b][o]);
+                }
             }
         }
-        float acc[RBK][O];
-#pragma unroll
-        for (int b = 0; b < RBK; ++b)
-#pragma unroll
-            for (int o = 0; o < O; ++o) acc[b][o] = (acc2[b][o].x + acc2[b][o].y) - b2[o];
 #pragma unroll
         for (int b = 0; b < RBK; ++b) {
             const int n = n0 + b * stride;
@@ -676,16 +719,29 @@ __device__ __forceinline__ float reg_residual(const float* __restrict__ row, con
     constexpr int K = I + 1 + O;
     float x[I + 1];
     lds_load<I + 1>(row, x);
-    f32x2 acc2 = f32x2{0.0f, 0.0f};
-    for (int hp = 0; hp < fw_pairs(H); ++hp) {
-        float f[2 * K];
-        lds_load<2 * K>(fw + hp * 2 * FWS, f);
-        f32x2 z = f32x2{-f[2 * I], -f[2 * I + 1]};
+    float acc;
+    if (FwLayout<I>::pairs(H)) {
+        f32x2 acc2 = f32x2{0.0f, 0.0f};
+        for (int hp = 0; hp < fw_pairs(H); ++hp) {
+            float f[2 * K];
+            lds_load<2 * K>(fw + hp * 2 * FWS, f);
+            f32x2 z = f32x2{-f[2 * I], -f[2 * I + 1]};
 #pragma unroll
-        for (int i = 0; i < I; ++i) z = __builtin_elementwise_fma(f32x2{x[i], x[i]}, f32x2{f[2 * i], f[2 * i + 1]}, z);
-        acc2 = __builtin_elementwise_fma(f32x2{sigmoidf_fast(z.x), sigmoidf_fast(z.y)}, f32x2{f[2 * (I + 1)], f[2 * (I + 1) + 1]}, acc2);
+            for (int i = 0; i < I; ++i) z = __builtin_elementwise_fma(f32x2{x[i], x[i]}, f32x2{f[2 * i], f[2 * i + 1]}, z);
+            acc2 = __builtin_elementwise_fma(f32x2{sigmoidf_fast(z.x), sigmoidf_fast(z.y)}, f32x2{f[2 * (I + 1)], f[2 * (I + 1) + 1]}, acc2);
+        }
+        acc = (acc2.x + acc2.y) - fw[2 * fw_pairs(H) * FWS];
+    } else {
+        acc = -fw[H * FWS];
+        for (int h = 0; h < H; ++h) {
+            float f[K];
+            lds_load<K>(fw + h * FWS, f);
+            float z = -f[I];
+#pragma unroll
+            for (int i = 0; i < I; ++i) z = fmaf(x[i], f[i], z);
+            acc = fmaf(sigmoidf_fast(z), f[I + 1], acc);
+        }
     }
-    const float acc = (acc2.x + acc2.y) - fw[2 * fw_pairs(H) * FWS];
     return sigmoidf_fast(acc) - x[I];
 }
 
