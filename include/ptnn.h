@@ -119,6 +119,16 @@ int ptnn_state_row_floats(ptnn_handle *h);
  * received into next_row before this call. */
 int ptnn_swap_apply(ptnn_handle *h, const int32_t *src_host, int phantom);
 
+/* Gathered exchange (the default of the sharded-ladder driver; replaces the Queue traffic of REG:427-437 <-> 730-752 with ONE
+ * collective per swap round): ptnn_swap_pack writes, for every local replica, the exchange row
+ *   { (w, eta) row | cached langevin_gradient row | its valid flag | posted L | pad }   (row_floats floats)
+ * into this rank's block of the buffer ptnn_xchg_ptr returns ([n_replicas_global][row_floats], same layout on every rank);
+ * the caller all-gathers the buffer in place; ptnn_swap_apply_gathered then runs the cascade on the gathered L values and
+ * copies every local slot's source row out of the buffer, wherever that replica ran, flips the buffers and counts the round. */
+int ptnn_xchg_ptr(ptnn_handle *h, void **base, int *row_floats);
+int ptnn_swap_pack(ptnn_handle *h, int phantom);
+int ptnn_swap_apply_gathered(ptnn_handle *h, int phantom);
+
 /* the HIP stream (hipStream_t) all of this handle's work is queued on: lets the caller order its collectives after the
  * segment / before the swap kernels on the device instead of synchronising the host */
 int ptnn_stream(ptnn_handle *h, void **hip_stream);

@@ -57,6 +57,9 @@ SYMBOLS = {
     "ptnn_state_row_floats": (C.c_int, [C.c_void_p]),
     "ptnn_stream": (C.c_int, [C.c_void_p, _vpp]),
     "ptnn_swap_apply": (C.c_int, [C.c_void_p, _ip, C.c_int]),
+    "ptnn_xchg_ptr": (C.c_int, [C.c_void_p, _vpp, _ip]),
+    "ptnn_swap_pack": (C.c_int, [C.c_void_p, C.c_int]),
+    "ptnn_swap_apply_gathered": (C.c_int, [C.c_void_p, C.c_int]),
     "ptnn_get_traces": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _ip]),
     "ptnn_get_swap_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _ip]),
     "ptnn_get_swap_log": (C.c_int, [C.c_void_p, _ip, C.c_int]),
@@ -196,6 +199,17 @@ class Sampler:
     def swap_apply(self, src, phantom):
         src = np.ascontiguousarray(src, dtype=np.int32)
         self._check(self.lib.ptnn_swap_apply(self.h, _ptr(src, _ip), int(phantom)))
+
+    def xchg_ptr(self):
+        base, n = C.c_void_p(), C.c_int32()
+        self._check(self.lib.ptnn_xchg_ptr(self.h, C.byref(base), C.byref(n)))
+        return base.value, n.value
+
+    def swap_pack(self, phantom):
+        self._check(self.lib.ptnn_swap_pack(self.h, int(phantom)))
+
+    def swap_apply_gathered(self, phantom):
+        self._check(self.lib.ptnn_swap_apply_gathered(self.h, int(phantom)))
 
     def traces(self, step0=0, nsteps=None, pos_w=True):
         n = self.S - step0 if nsteps is None else nsteps

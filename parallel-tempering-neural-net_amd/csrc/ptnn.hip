@@ -102,7 +102,8 @@ struct ptnn_handle {
           *d_acc_te = nullptr;
     int* d_accept = nullptr;
     int *d_src = nullptr, *d_src_log = nullptr;
-    int* h_src = nullptr;                                   // pinned staging for the permutation of a round (sharded ladder)
+    int* h_src = nullptr;
+    float* d_xchg = nullptr;                                // [R_global][XS] exchange rows of the gathered sharding mode                                   // pinned staging for the permutation of a round (sharded ladder)
     long long* d_counters = nullptr;
     // kernel timing (HIP events on our stream)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing;
@@ -194,7 +195,8 @@ int launch_segment(ptnn_handle* h, int begin, int n) {
     return 0;
 }
 
-// mode bit 0 = apply local moves (and flip), bit 1 = count + log, src_out optional
+// mode bit 0 = apply moves (and flip), bit 1 = count + log, bit 2 = L and the source rows come from the gathered exchange
+// buffer; src_out optional.  mode -1 = pack the exchange rows of the local replicas.
 int launch_swap(ptnn_handle* h, bool phantom, int mode, bool want_src) {
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     SwapParams sp{};
@@ -210,6 +212,13 @@ int launch_swap(ptnn_handle* h, bool phantom, int mode, bool want_src) {
     sp.rule = h->cfg.swap_rule; sp.L_raw = h->d_L_raw; sp.prior_post = h->d_prior_post; sp.temps_global = h->d_temps_global;
     sp.st_f = h->d_st_f;
     sp.canonical = (h->cfg.pt_switch_step >= 0 && h->cur - 1 >= h->cfg.pt_switch_step) ? 1 : 0;
+    sp.xchg = h->d_xchg; sp.XS = xchg_row_floats(h->PS); sp.L_stride = 1;
+    if (mode == -1) {
+        hipLaunchKernelGGL(xchg_pack_kernel, dim3(sp.Rl), dim3(64), 0, h->stream, sp);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    if (mode & 4) { sp.L = h->d_xchg + 2 * h->PS + 1; sp.L_stride = sp.XS; }
     const size_t lds = (size_t)(3 * sp.R + 1) * sizeof(float);
     hipLaunchKernelGGL(swap_kernel, dim3(sp.Rl), dim3(64), lds, h->stream, sp, h->rounds_done, mode);
     HIP_TRY(hipGetLastError());
@@ -305,6 +314,8 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
     HIP_TRY(hipMalloc(&h->d_accept, Rl * S * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_src, R * sizeof(int)));
     HIP_TRY(hipHostMalloc(&h->h_src, R * sizeof(int), hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&h->d_xchg, (size_t)R * xchg_row_floats(h->PS) * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(h->d_xchg, 0, (size_t)R * xchg_row_floats(h->PS) * sizeof(float), h->stream));
     HIP_TRY(hipMalloc(&h->d_src_log, (size_t)h->max_rounds * R * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_counters, 2 * sizeof(long long)));
     HIP_TRY(hipMalloc(&h->d_error, sizeof(int)));
@@ -329,6 +340,7 @@ int ptnn_destroy(ptnn_handle* h) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_src) (void)hipHostFree(h->h_src);
+    if (h->d_xchg) (void)hipFree(h->d_xchg);
     for (auto& ev : h->timing) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -651,6 +663,27 @@ int ptnn_swap_apply(ptnn_handle* h, const int32_t* src_host, int phantom) {
     if (int rc = check_ready(h)) return rc;
     (void)src_host;   // the device recomputes the identical cascade; the host copy only routed the remote rows
     if (int rc = launch_swap(h, phantom != 0, phantom ? 2 : 3, false)) return rc;
+    if (!phantom) h->flip ^= 1;
+    h->rounds_done += 1;
+    return 0;
+}
+
+int ptnn_xchg_ptr(ptnn_handle* h, void** base, int* row_floats) {
+    if (!h || !base || !row_floats) return fail(-1, "null argument");
+    *base = h->d_xchg;
+    *row_floats = xchg_row_floats(h->PS);
+    return 0;
+}
+
+int ptnn_swap_pack(ptnn_handle* h, int phantom) {
+    if (int rc = check_ready(h)) return rc;
+    if (h->cfg.swap_rule != 0) return fail(-3, "the sharded ladder implements the reference's cascade (swap_rule 0) only");
+    return launch_swap(h, phantom != 0, -1, false);
+}
+
+int ptnn_swap_apply_gathered(ptnn_handle* h, int phantom) {
+    if (int rc = check_ready(h)) return rc;
+    if (int rc = launch_swap(h, phantom != 0, phantom ? (2 | 4) : (3 | 4), false)) return rc;
     if (!phantom) h->flip ^= 1;
     h->rounds_done += 1;
     return 0;

@@ -2331,13 +2331,19 @@ struct SwapParams {
     const float* prior_post;   // [R]
     const float* temps_global; // [R]
     float* st_f;               // [Rl][SF_COUNT]
+    // gathered exchange (ladder sharded over GPUs): every rank holds, after one all-gather, the exchange rows of ALL replicas
+    // xchg[R][XS] = { state row (PS) | cached-gradient row (PS) | gradient valid | posted L | pad }
+    float* xchg;               // null: single-GPU / point-to-point modes
+    int XS;
+    int L_stride;              // 1, or XS when L is read from the exchange rows
 };
+__host__ __device__ inline int xchg_row_floats(int PS) { return (2 * PS + 2 + 3) & ~3; }
 
 // sSrc has R + 1 ints: the last one carries the number of accepted swaps
 __device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, float* sL, float* sU, int* sSrc) {
     const int R = sp.R;
     for (int k = threadIdx.x; k < R; k += blockDim.x) {
-        sL[k] = sp.L[k];
+        sL[k] = sp.L[(size_t)k * sp.L_stride];
         if (k < R - 1) {
             uint32_t x[4];
             philox4x32_10((uint32_t)k, (uint32_t)round, 0u, STREAM_SWAP, sp.seed_lo, sp.seed_hi, x);
@@ -2376,6 +2382,19 @@ __device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, floa
 
 #ifndef PTNN_SHAPE_TU      // non-template kernel: defined in the main translation unit only
 // mode bit 0: apply the local moves; bit 1: count the round and log it
+// exchange row of every local replica: state, cached gradient, its valid flag and the posted scalar, ready for the all-gather
+__global__ void xchg_pack_kernel(const SwapParams sp) {
+    const int b = blockIdx.x;
+    float* row = sp.xchg + (size_t)(sp.first_global + b) * sp.XS;
+    const float* from = sp.cur + (size_t)b * sp.PS;
+    const float* gfrom = sp.gd_cur + (size_t)b * sp.PS;
+    for (int j = threadIdx.x; j < sp.PS; j += blockDim.x) { row[j] = from[j]; row[sp.PS + j] = gfrom[j]; }
+    if (threadIdx.x == 0) {
+        row[2 * sp.PS] = sp.gd_valid_cur[b] ? 1.0f : 0.0f;
+        row[2 * sp.PS + 1] = sp.L[sp.first_global + b];
+    }
+}
+
 __global__ void swap_kernel(const SwapParams sp, const int round, const int mode) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sL = smem;
@@ -2390,7 +2409,13 @@ __global__ void swap_kernel(const SwapParams sp, const int round, const int mode
         // gd_valid of the destination = gd_valid of the source when the source is local; a row that arrives from
         // another GPU comes without its cached gradient
         int valid = 0;
-        if (sl >= 0 && sl < sp.Rl) {
+        if (mode & 4) {                                     // the source row is in the gathered exchange buffer, wherever it ran
+            const float* from = sp.xchg + (size_t)s * sp.XS;
+            float* to = sp.next + (size_t)b * sp.PS;
+            float* gto = sp.gd_next + (size_t)b * sp.PS;
+            for (int j = threadIdx.x; j < sp.PS; j += blockDim.x) { to[j] = from[j]; gto[j] = from[sp.PS + j]; }
+            valid = (from[2 * sp.PS] != 0.0f) ? 1 : 0;
+        } else if (sl >= 0 && sl < sp.Rl) {
             const float* from = sp.cur + (size_t)sl * sp.PS;
             float* to = sp.next + (size_t)b * sp.PS;
             const float* gfrom = sp.gd_cur + (size_t)sl * sp.PS;

@@ -2,13 +2,18 @@
 
 Replaces the reference's star topology (every replica ships its whole parameter vector to the parent through a
 multiprocessing.Queue each swap round, REG:427-437 <-> 719-752).  Replicas are independent for a swap interval, so
-the data path needs exactly one exchange step per interval:
+the data path needs exactly one exchange step per interval.  Two modes:
 
-  1. all-gather of the R posted scalars L (4 R bytes);
-  2. every rank runs the identical cascade kernel (uniforms are Philox(seed; round, pair)) -> the same src[R];
-  3. only rows whose source lives on another rank travel: point-to-point, straight into the destination row of the
-     receiver's next-state buffer (at most one row arrives from below and one from the rank directly above);
-  4. the local rows are copied by the swap kernel, buffers flip.
+  "gather" (default): ONE collective per round.  Every rank packs, per local replica, an exchange row {state, cached
+     gradient, posted L}; the rows are all-gathered in place (R x (8 P + 16) bytes: 18 KB per rank for the Sunspot net --
+     nothing next to an interval of MH steps, and a single large collective is what xGMI rings like); every rank then runs
+     the identical cascade kernel on the gathered L (uniforms are Philox(seed; round, pair)) and copies each local slot's
+     source row out of the buffer, wherever that replica ran.  The host never looks at the permutation, so the whole round
+     is queued without a host synchronisation: the segment kernel, the pack kernel, the collective (on torch's stream,
+     chained to libptnn's stream by two events) and the swap kernel.
+  "p2p": 1. all-gather of the R posted scalars L (4 R bytes); 2. cascade kernel, permutation to the host; 3. only rows whose
+     source lives on another rank travel point-to-point into the destination row of the receiver's next-state buffer;
+     4. local rows are copied by the swap kernel.  Least bytes (for nets whose rows are megabytes), three host waits.
 
 `torch.distributed` is the plumbing (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests); the
 tensors it moves are views of libptnn's own device buffers.  The driver is written against a small shard protocol so
@@ -35,8 +40,14 @@ class DeviceShard:
         # waits once per round for the 4 R-byte permutation.  Opt-in (PTNN_DIST_STREAM=1) until measured on several GPUs.
         import os
         self.stream_ordered = os.environ.get("PTNN_DIST_STREAM", "0") == "1"
-        self.ext_stream = torch.cuda.ExternalStream(sampler.stream_ptr(), device=self.dev) if self.stream_ordered else None
         self._views = {}
+        # "gather" mode: event-chained by default; PTNN_DIST_SYNC=host falls back to host synchronisation around the collective
+        self.host_sync = os.environ.get("PTNN_DIST_SYNC", "event") == "host"
+        self.ext_stream = torch.cuda.ExternalStream(sampler.stream_ptr(), device=self.dev)
+        self._ev_seg, self._ev_coll = torch.cuda.Event(), torch.cuda.Event()
+        base, xs = sampler.xchg_ptr()
+        self.XS = xs
+        self._xchg = self._view(base, self.R_global * xs)
 
     def _view(self, ptr, n):
         class _Arr:            # __cuda_array_interface__ v2: zero-copy view of library-owned HBM
@@ -84,6 +95,32 @@ class DeviceShard:
     def swap_cascade(self, phantom):
         return self.s.swap_cascade(phantom)
 
+    # ---- gather mode ----
+    def xchg_tensor(self):
+        return self._xchg
+
+    def pack(self, phantom):
+        self.s.swap_pack(phantom)
+
+    def before_collective(self):
+        """Order torch's current stream (where the collective runs) after everything queued on libptnn's stream."""
+        if self.host_sync:
+            self.s.sync()
+        else:
+            self._ev_seg.record(self.ext_stream)
+            self.torch.cuda.current_stream(self.dev).wait_event(self._ev_seg)
+
+    def after_collective(self):
+        """Order libptnn's stream (where the swap kernel runs) after the collective."""
+        if self.host_sync:
+            self.torch.cuda.synchronize(self.dev)
+        else:
+            self._ev_coll.record(self.torch.cuda.current_stream(self.dev))
+            self.ext_stream.wait_event(self._ev_coll)
+
+    def apply_gathered(self, phantom):
+        self.s.swap_apply_gathered(phantom)
+
     def swap_apply(self, src, phantom):
         self.s.swap_apply(src, phantom)
 
@@ -103,11 +140,15 @@ def route(src, rank, world, R_local):
 
 
 class ShardedLadder:
-    def __init__(self, shard, rank, world, dist=None):
+    def __init__(self, shard, rank, world, dist=None, mode=None):
         if dist is None:
             import torch.distributed as dist
+        import os
         self.dist = dist
         self.shard, self.rank, self.world = shard, rank, world
+        self.mode = mode or os.environ.get("PTNN_DIST_MODE", "gather")
+        if self.mode not in ("gather", "p2p"):
+            raise ValueError("mode must be 'gather' or 'p2p'")
         self.rounds = 0
         self.bytes_moved = 0
         try:
@@ -116,6 +157,28 @@ class ShardedLadder:
             self._gather_in_place = False
 
     def swap_round(self, phantom):
+        if self.mode == "gather":
+            return self._swap_round_gather(phantom)
+        return self._swap_round_p2p(phantom)
+
+    def _swap_round_gather(self, phantom):
+        sh, dist = self.shard, self.dist
+        sh.pack(phantom)                                    # exchange rows of the local replicas (queued behind the segment)
+        X = sh.xchg_tensor()
+        n = sh.R_local * sh.XS
+        sh.before_collective()
+        if self._gather_in_place:                           # RCCL: in place, the input is this rank's block of the buffer
+            dist.all_gather_into_tensor(X, X[self.rank * n:(self.rank + 1) * n])
+        else:
+            mine = X[self.rank * n:(self.rank + 1) * n].clone()
+            dist.all_gather(list(X.split(n)), mine)
+        sh.after_collective()
+        sh.apply_gathered(phantom)                          # identical cascade on every rank + copy of the source rows
+        self.bytes_moved += 4 * n * (self.world - 1)
+        self.rounds += 1
+        return None
+
+    def _swap_round_p2p(self, phantom):
         import contextlib
         sh, dist = self.shard, self.dist
         ctx = sh.collective_context() if hasattr(sh, "collective_context") else contextlib.nullcontext()

@@ -69,6 +69,8 @@ class OracleShard:
         self.L = [torch.zeros(self.R_global, dtype=torch.float64), torch.zeros(self.R_global, dtype=torch.float64)]
         self.rows_cur = torch.zeros(self.R_local, self.PS, dtype=torch.float64)
         self.rows_next = torch.zeros(self.R_local, self.PS, dtype=torch.float64)
+        self.XS = self.PS + 3                       # gather mode: {w, eta | L handoff | L final | pad}
+        self.xchg = torch.zeros(self.R_global * self.XS, dtype=torch.float64)
 
     def run_segment(self):
         last = self.S - 1
@@ -105,6 +107,36 @@ class OracleShard:
     def row_tensors(self, local):
         return self.rows_cur[local], self.rows_next[local]
 
+    # ---- gather mode of the shard protocol ----
+    def xchg_tensor(self):
+        return self.xchg
+
+    def pack(self, phantom):
+        X = self.xchg.view(self.R_global, self.XS)
+        for k in range(self.R_local):
+            X[self.first + k, :self.PS] = self.rows_cur[k]
+            X[self.first + k, self.PS] = self.L[0][self.first + k]
+            X[self.first + k, self.PS + 1] = self.L[1][self.first + k]
+
+    def before_collective(self):
+        pass
+
+    def after_collective(self):
+        pass
+
+    def apply_gathered(self, phantom):
+        X = self.xchg.view(self.R_global, self.XS)
+        L = X[:, self.PS + (1 if phantom else 0)].tolist()
+        u = self.tape.swap_uniforms(self.rounds_done, self.R_global - 1)
+        src, nsw = orc.swap_cascade(L, u)
+        if not phantom:
+            for k, rep in enumerate(self.reps):
+                row = X[int(src[self.first + k])]
+                rep.w = row[:self.P].numpy().copy()
+                rep.eta = float(row[self.P])
+        self.num_swap += nsw
+        self.rounds_done += 1
+
     def swap_cascade(self, phantom):
         L = self.L[1 if phantom else 0].tolist()
         u = self.tape.swap_uniforms(self.rounds_done, self.R_global - 1)
@@ -125,7 +157,7 @@ class OracleShard:
         self.rounds_done += 1
 
 
-def _worker(rank, world, port, pt_args, outdir):
+def _worker(rank, world, port, pt_args, outdir, mode="gather"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -134,7 +166,7 @@ def _worker(rank, world, port, pt_args, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dm = _load_distributed()
     shard = OracleShard(pt_args, rank, world)
-    lad = dm.ShardedLadder(shard, rank, world, dist)
+    lad = dm.ShardedLadder(shard, rank, world, dist, mode=mode)
     lad.run_intervals(None)
     np.savez(os.path.join(outdir, f"rank{rank}.npz"),
              pos_w=np.stack([r.pos_w for r in shard.reps]), accept=np.stack([r.accept_list for r in shard.reps]),
@@ -152,8 +184,9 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,task", [(2, orc.TASK_REG), (4, orc.TASK_CLS)])
-def test_sharded_ladder_matches_single_process(tmp_path, datasets, world, task):
+@pytest.mark.parametrize("world,task,mode", [(2, orc.TASK_REG, "gather"), (4, orc.TASK_CLS, "gather"),
+                                             (2, orc.TASK_REG, "p2p"), (4, orc.TASK_CLS, "p2p")])
+def test_sharded_ladder_matches_single_process(tmp_path, datasets, world, task, mode):
     import torch.multiprocessing as mp
     if task == orc.TASK_REG:
         args = (task, (4, 5, 1), datasets["sunspot_train"], datasets["sunspot_test"], 8, 2, 8 * 43, 5)
@@ -163,7 +196,7 @@ def test_sharded_ladder_matches_single_process(tmp_path, datasets, world, task):
         kw = dict(use_lg=False, l_prob=0.5, lr=0.01, seed=32)      # S = 40: S % si == 0 -> phantom round
     pt_args = dict(args=args, kw=kw)
     ref = orc.PTOracle(*args, **kw).run()
-    mp.spawn(_worker, args=(world, _free_port(), pt_args, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), pt_args, str(tmp_path), mode), nprocs=world, join=True)
     Rl = 8 // world
     moved = 0
     for rank in range(world):
@@ -179,4 +212,5 @@ def test_sharded_ladder_matches_single_process(tmp_path, datasets, world, task):
     assert ref.num_swap > 0
     # something actually crossed a shard boundary, and never more than two rows in + two rows out per rank per round
     assert moved > 0
-    assert moved <= ref.rounds_done * world * 4 * 4 * (ref.P + 1)
+    if mode == "p2p":
+        assert moved <= ref.rounds_done * world * 4 * 4 * (ref.P + 1)
