@@ -598,49 +598,15 @@ def test_even_odd_swap_rule_option(task):
             assert abs(o.logalpha[r, i] - o.logu[r, i]) < parity.LOGALPHA_SLACK
 
 
+
 @pytest.mark.gpu
 def test_sharded_ladder_driver_on_device_matches_plain_run():
     """The multi-GPU driver (distributed.py) on the real device buffers, rehearsed at world size 1 over RCCL: both exchange
-    modes must reproduce the chain of the single-GPU path bit for bit (traces, swap log, counters)."""
-    import socket
-    import torch
-    import torch.distributed as dist
-    from ptnn_amd import distributed as dm
-    d = ds()
-    train, test = d["sunspot_train"], d["sunspot_test"]
-    topo, R, S, si = (4, 5, 1), 16, 8 * 12 + 3, 12
-
-    from ptnn_amd import ladder, philox
-    Pw = topo[0] * topo[1] + topo[1] * topo[2] + topo[1] + topo[2]
-
-    def make():
-        s_ = parity.make_sampler(orc.TASK_REG, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=True,
-                                 lr=0.1, seed=77)
-        s_.set_state(np.stack([philox.initial_weights(77, r, Pw) for r in range(R)]), ladder.temperatures(R, 2))
-        return s_
-    ref = make()
-    ref.run(-1)
-    ref.sync()
-    want, want_log, want_stats = ref.traces(), ref.swap_log(), ref.swap_stats()
-    ref.close()
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1)
-    try:
-        for mode in ("gather", "p2p"):
-            s = make()
-            lad = dm.ShardedLadder(dm.DeviceShard(s, 0), 0, 1, dist, mode=mode)
-            lad.run_intervals(None)
-            s.sync()
-            got = s.traces()
-            for k in want:
-                assert np.array_equal(got[k], want[k]), (mode, k)
-            assert np.array_equal(s.swap_log(), want_log), mode
-            assert s.swap_stats() == want_stats, mode
-            s.close()
-    finally:
-        dist.destroy_process_group()
+    modes must reproduce the chain of the single-GPU path bit for bit (traces, swap log, counters).  Runs in a child process
+    (tests/dist_device_check.py) so that torch initialises the GPU before libptnn does, as in bench.py."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "dist_device_check.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "OK gather" in r.stdout and "OK p2p" in r.stdout
