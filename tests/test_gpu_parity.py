@@ -610,3 +610,41 @@ def test_sharded_ladder_driver_on_device_matches_plain_run():
     r = subprocess.run([sys.executable, os.path.join(here, "dist_device_check.py")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "OK gather" in r.stdout and "OK p2p" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("topo", [(11, 50, 10), (20, 50, 2), (16, 30, 10), (6, 25, 18), (9, 12, 2), (34, 50, 2), (34, 64, 2)])
+def test_classification_shapes_of_the_problem_table(topo):
+    """Every (inputs, hidden, classes) of the reference's classification table (CLS:909-995) on synthetic data of that shape,
+    cooperative schedule, random walk: chains against the oracle on the same tape.  Covers the forward-pass variants the
+    host picks by shape -- packed FMAs on unit pairs, and the matrix-core pass with odd input counts, one partial tile
+    (25, 30 units), two tiles (50 of 64 units, 64 of 64) and 2..18 classes."""
+    I, H, O = topo
+    rng = np.random.default_rng(I * 1000 + H)
+    n_tr, n_te = 150, 53
+    X = rng.standard_normal((n_tr + n_te, I))
+    proj = rng.standard_normal((I, O))
+    y = np.argmax(X @ proj + 0.5 * rng.standard_normal((n_tr + n_te, O)), axis=1).astype(np.float64)
+    data = np.hstack([X, y[:, None]])
+    train, test = data[:n_tr], data[n_tr:]
+    R, S, si, seed = 4, 26, 6, 90 + H
+    pt = orc.PTOracle(orc.TASK_CLS, topo, train, test, R, 10, R * S, si, use_lg=False, l_prob=0.5, lr=0.01, seed=seed)
+    w0 = (0.5 * np.stack([rep.w for rep in pt.replicas])).astype(np.float32)
+    for rep, w in zip(pt.replicas, w0):
+        rep.__init__(orc.TASK_CLS, topo, pt.train, pt.test, w.astype(np.float64), rep.T, S, False, 0.5, 0.01, pt.tape, rep.gid)
+    o = parity.OracleRun(pt).run()
+    for waves in (0, 1):                                    # several waves share the (row block, tile) units, or one takes all
+        s = parity.make_sampler(orc.TASK_CLS, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=False,
+                                lr=0.01, seed=seed, schedule=1, waves=waves)
+        s.set_state(w0, np.array(pt.temperatures, dtype=np.float32))
+        s.run(-1)
+        s.sync()
+        tr = s.traces()
+        nsw, tot, rounds = s.swap_stats()
+        assert rounds == pt.rounds_done and tot == pt.total_swap_proposals
+        for r in range(R):
+            first = parity.compare_replica_trace(tr, r, pt.replicas[r], f"{topo} waves={waves} r{r} ")
+            if first is not None:
+                i = first - 2
+                assert abs(o.logalpha[r, i] - o.logu[r, i]) < 0.05, (topo, waves, r, i, o.logalpha[r, i], o.logu[r, i])
+        s.close()
