@@ -60,6 +60,10 @@ typedef struct ptnn_config {
     int32_t swap_rule;            /* 0 = the reference's cascade (REG:659-690, default); 1 = even/odd Metropolis exchange
                                    * min(1, exp((1/T_k - 1/T_k+1)(L_k+1 - L_k))) on untempered log-likelihoods, the moved state
                                    * brings its likelihood and prior along, no phantom round (not in the reference) */
+    int32_t shared_noise;         /* 0 = every (replica, step) has its own Philox counter (default); 1 = all replicas read the
+                                   * step tape of replica 0 (proposal noise, Langevin coin, MH uniform, eta noise): what the
+                                   * reference's forked chains do, which all inherit one numpy / random state (REG:709-712,
+                                   * SURVEY Q14).  Initial weights and swap uniforms are not shared (the parent draws them). */
     float l_prob;                 /* langevin_prob (REG:174); CLS fixes 0.5 (CLS:192) */
     float learn_rate;             /* SGD step of langevin_gradient (REG:33) */
     float step_w;                 /* 0.025 (REG:258) */

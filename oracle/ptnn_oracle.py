@@ -271,6 +271,7 @@ class Replica:
         self.S = int(samples)
         self.use_lg, self.l_prob, self.lr = bool(use_lg), float(l_prob), float(lr)
         self.tape, self.gid, self.faithful = tape, int(gid), faithful
+        self.noise_gid = int(gid)                          # Q14 option: PTOracle(shared_noise=True) points every chain at tape 0
         self.step_w, self.step_eta = step_w, step_eta
         self.sigma_squared, self.nu_1, self.nu_2 = sigma_squared, nu_1, nu_2
         P = num_param(topo)
@@ -316,8 +317,8 @@ class Replica:
             self.adapttemp = 1
             self.likelihood = self._lik(self.train, self.w, self.tau_pro)[0]
             self.init_count = 1
-        lx, u, n_eta = self.tape.step_scalars(self.gid, i)
-        noise = self.tape.w_noise(self.gid, i, self.P)
+        lx, u, n_eta = self.tape.step_scalars(self.noise_gid, i)
+        noise = self.tape.w_noise(self.noise_gid, i, self.P)
         if self.use_lg and lx < self.l_prob:
             w_gd = langevin_gradient(self.train, self.w, self.topo, self.lr, self.task)
             w_proposal = w_gd + self.step_w * noise
@@ -386,7 +387,7 @@ class PTOracle:
     """
 
     def __init__(self, task, topo, train, test, num_chains, maxtemp, NumSample, swap_interval,
-                 use_lg=False, l_prob=0.5, lr=0.1, seed=1, w0=None, faithful=False, swap_rule=0):
+                 use_lg=False, l_prob=0.5, lr=0.1, seed=1, w0=None, faithful=False, swap_rule=0, shared_noise=False):
         self.swap_rule = swap_rule          # 0 = the reference's cascade; 1 = even/odd Metropolis (NOT in the reference)
         self.task, self.topo = task, tuple(topo)
         self.train = np.asarray(train, dtype=np.float64)
@@ -402,6 +403,9 @@ class PTOracle:
             w0 = np.stack([self.tape.w_init(r, P) for r in range(self.R)])
         self.replicas = [Replica(task, topo, self.train, self.test, w0[r], self.temperatures[r], self.S,
                                  use_lg, l_prob, lr, self.tape, r, faithful) for r in range(self.R)]
+        if shared_noise:                                   # Q14: forked chains inherit ONE RNG state (REG:709-712)
+            for rep in self.replicas:
+                rep.noise_gid = 0
         self.num_swap = 0
         self.total_swap_proposals = 0
         self.rounds_done = 0

@@ -134,7 +134,7 @@ struct ptnn_handle {
         p.L_raw = (cfg.swap_rule == 1) ? d_L_raw : nullptr; p.prior_post = d_prior_post;
         p.tr_pos_w = d_pos_w; p.tr_likeh = d_likeh; p.tr_rmse_tr = d_rmse_tr; p.tr_rmse_te = d_rmse_te;
         p.tr_acc_tr = d_acc_tr; p.tr_acc_te = d_acc_te; p.tr_accept = d_accept;
-        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.xt = d_xt; p.Npad = Npad; p.fw_mfma = fw_mfma ? 1 : 0; p.forward_bf16 = cfg.forward_bf16;
+        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.noise_shared = cfg.shared_noise ? 1 : 0; p.xt = d_xt; p.Npad = Npad; p.fw_mfma = fw_mfma ? 1 : 0; p.forward_bf16 = cfg.forward_bf16;
         return p;
     }
 };

@@ -34,6 +34,7 @@ enum { SI_NACC = 0, SI_UNUSED, SI_LG_COUNT, SI_LG_ACC, SI_COUNT = 4 };   // acce
 struct SegParams {
     int H, P, PS;            // hidden units, parameters, state row length (P + 1 rounded up to 4)
     int Ntr, Nte, IPY, FWS;  // rows, data row stride (floats), packed forward row stride (floats)
+    int noise_shared;        // Q14: every replica reads the step tape of replica 0
     int fw_mfma;             // cooperative schedule: forward pass on the matrix cores (host decides: 24 <= H <= 64, I >= 6)
     int S, switch_step, use_lg;
     int trace_cap;           // rows per replica in the trace rings
@@ -822,7 +823,7 @@ __device__ __forceinline__ void tape_step(const SegParams& p, int gid, int step,
     for (int q = gtid<WL>(); q <= nq; q += gsize<WL>()) {
         const bool sc = (q == nq);
         uint32_t x[4];
-        philox4x32_10(sc ? 0u : (uint32_t)q, (uint32_t)step, (uint32_t)gid, sc ? STREAM_STEP : STREAM_WNOISE, p.seed_lo,
+        philox4x32_10(sc ? 0u : (uint32_t)q, (uint32_t)step, p.noise_shared ? 0u : (uint32_t)gid, sc ? STREAM_STEP : STREAM_WNOISE, p.seed_lo,
                       p.seed_hi, x);
         float n0, n1, n2, n3;
         box_muller(x[0], x[1], n0, n1);
@@ -1696,7 +1697,7 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
                     if (ls < per_pass && s_ < k) {
                         const bool sc = (q_ == nq1 - 1);
                         uint32_t x[4];
-                        philox4x32_10(sc ? 0u : (uint32_t)q_, (uint32_t)(i + s_), (uint32_t)gid, sc ? STREAM_STEP : STREAM_WNOISE,
+                        philox4x32_10(sc ? 0u : (uint32_t)q_, (uint32_t)(i + s_), p.noise_shared ? 0u : (uint32_t)gid, sc ? STREAM_STEP : STREAM_WNOISE,
                                       p.seed_lo, p.seed_hi, x);
                         float n0, n1, n2, n3;
                         box_muller(x[0], x[1], n0, n1);

@@ -33,7 +33,8 @@ class ParallelTemperingBase:
 
     def __init__(self, use_langevin_gradients, learn_rate, traindata, testdata, topology, num_chains, maxtemp,
                  NumSample, swap_interval, langevin_prob, path, *, seed=None, device=None, waves_per_replica=0,
-                 schedule=0, groups_per_replica=0, trace_capacity=0, swap_rule=0, write_files=True, io_threads=None):
+                 schedule=0, groups_per_replica=0, trace_capacity=0, swap_rule=0, shared_noise=False, write_files=True,
+                 io_threads=None):
         # FNN chain variables (REG:491-494)
         self.traindata = traindata
         self.testdata = testdata
@@ -63,6 +64,7 @@ class ParallelTemperingBase:
         self.schedule = int(schedule)            # 0 auto, 1 cooperative, 2 speculative (include/ptnn.h)
         self.groups_per_replica = int(groups_per_replica)
         self.swap_rule = int(swap_rule)          # 0 = the reference's cascade; 1 = even/odd Metropolis exchange (not in the reference)
+        self.shared_noise = bool(shared_noise)   # True: all chains read one noise tape, as the reference's forked chains do (Q14)
         self.trace_capacity = int(trace_capacity)   # rows per replica kept in HBM (0 = all); smaller = streamed to the host
         self.write_files = bool(write_files)
         self.io_threads = io_threads or min(16, os.cpu_count() or 1)
@@ -130,7 +132,7 @@ class ParallelTemperingBase:
             n_replicas_local=self.num_chains, n_replicas_global=self.num_chains, first_global_replica=0,
             n_samples=S, swap_interval=int(self.swap_interval), pt_switch_step=self._pt_switch_step(),
             use_langevin=1 if self.use_langevin_gradients is True else 0, waves_per_replica=self.waves_per_replica,
-            schedule=self.schedule, groups_per_replica=self.groups_per_replica, trace_capacity=self.trace_capacity, swap_rule=self.swap_rule,
+            schedule=self.schedule, groups_per_replica=self.groups_per_replica, trace_capacity=self.trace_capacity, swap_rule=self.swap_rule, shared_noise=int(self.shared_noise),
             l_prob=float(self.langevin_prob), learn_rate=float(self.learn_rate), step_w=0.025, step_eta=0.2,
             sigma_squared=25.0, nu_1=0.0, nu_2=0.0, seed=self.seed)
         self._sampler.set_data(train, test)

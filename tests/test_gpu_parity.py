@@ -648,3 +648,36 @@ def test_classification_shapes_of_the_problem_table(topo):
                 i = first - 2
                 assert abs(o.logalpha[r, i] - o.logu[r, i]) < 0.05, (topo, waves, r, i, o.logalpha[r, i], o.logu[r, i])
         s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("schedule", [0, 1])
+def test_shared_noise_option_matches_oracle(schedule):
+    """Q14: the reference's forked chains all inherit one RNG state (REG:709-712), so every chain sees the same proposal
+    noise, Langevin coin and MH uniform.  `shared_noise=1` reproduces that (default off); checked against the oracle's
+    restatement of it, swaps included."""
+    d = ds()
+    train, test = d["sunspot_train"], d["sunspot_test"]
+    topo, R, S, si, seed = (4, 5, 1), 6, 45, 7, 61
+    pt = orc.PTOracle(orc.TASK_REG, topo, train, test, R, 2, R * S, si, use_lg=True, l_prob=0.5, lr=0.1, seed=seed, shared_noise=True)
+    w0 = np.stack([rep.w for rep in pt.replicas]).astype(np.float32)
+    for rep, w in zip(pt.replicas, w0):
+        rep.__init__(orc.TASK_REG, topo, pt.train, pt.test, w.astype(np.float64), rep.T, S, True, 0.5, 0.1, pt.tape, rep.gid)
+        rep.noise_gid = 0
+    o = parity.OracleRun(pt).run()
+    s = parity.make_sampler(orc.TASK_REG, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=True, lr=0.1,
+                            seed=seed, schedule=schedule, shared_noise=1)
+    s.set_state(w0, np.array(pt.temperatures, dtype=np.float32))
+    noise0, scal0 = s.tape(0, 3)
+    noise3, scal3 = s.tape(3, 3)
+    assert np.array_equal(noise0, noise3) and np.array_equal(scal0, scal3)
+    s.run(-1)
+    s.sync()
+    tr = s.traces()
+    assert s.swap_stats()[2] == pt.rounds_done and s.swap_stats()[1] == pt.total_swap_proposals
+    for r in range(R):
+        first = parity.compare_replica_trace(tr, r, pt.replicas[r], f"shared noise r{r} ")
+        if first is not None:
+            i = first - 2
+            assert abs(o.logalpha[r, i] - o.logu[r, i]) < 0.05, (r, i, o.logalpha[r, i], o.logu[r, i])
+    s.close()
