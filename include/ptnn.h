@@ -154,6 +154,16 @@ int ptnn_get_swap_log(ptnn_handle *h, int32_t *src, int max_rounds);
 int ptnn_get_state(ptnn_handle *h, float *w, float *eta, float *likelihood, float *prior, int32_t *num_accepted,
                    int32_t *langevin_count, int32_t *langevin_accepted);
 
+/* ---- checkpoint / resume (the reference has none) ----
+ * The RNG is counter based, so the state of the chains is small: (w, eta), cached gradient, recorded row, likelihood / prior /
+ * counters per replica, posted scalars, swap counters and log, step and round indices.  ptnn_checkpoint_save writes it into a
+ * caller buffer of ptnn_checkpoint_size bytes; ptnn_checkpoint_load on a handle created with the same chain configuration
+ * (after ptnn_set_data, instead of ptnn_set_state) continues the chains bit for bit.  Trace rows are not part of it: rows up
+ * to the checkpoint step stay with whoever fetched them, and ptnn_get_traces of the restored handle refuses them. */
+int ptnn_checkpoint_size(ptnn_handle *h, int64_t *bytes);
+int ptnn_checkpoint_save(ptnn_handle *h, void *buf, int64_t bytes);
+int ptnn_checkpoint_load(ptnn_handle *h, const void *buf, int64_t bytes);
+
 /* ---- the model functions on their own (same device code as the sampler) ---- */
 /* Network.evaluate_proposal + likelihood_func + prior_likelihood for n weight vectors w [n,P] (REG:120-134, 200-221;
  * CLS:134-153, 209-230); tau_sq [n] (ignored for CLS, may be NULL).  out [n,8] =

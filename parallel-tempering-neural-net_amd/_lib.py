@@ -64,6 +64,9 @@ SYMBOLS = {
     "ptnn_get_swap_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _ip]),
     "ptnn_get_swap_log": (C.c_int, [C.c_void_p, _ip, C.c_int]),
     "ptnn_get_state": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _ip, _ip, _ip]),
+    "ptnn_checkpoint_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "ptnn_checkpoint_save": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "ptnn_checkpoint_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "ptnn_evaluate": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, _fp]),
     "ptnn_langevin_gradient": (C.c_int, [C.c_void_p, _fp, C.c_int, _fp]),
     "ptnn_tape": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp]),
@@ -244,6 +247,19 @@ class Sampler:
         self._check(self.lib.ptnn_get_state(self.h, _ptr(w), _ptr(eta), _ptr(lik), _ptr(pri), _ptr(nacc, _ip), _ptr(lg, _ip),
                                             _ptr(lga, _ip)))
         return dict(w=w, eta=eta, likelihood=lik, prior=pri, num_accepted=nacc, langevin_count=lg, langevin_accepted=lga)
+
+    def checkpoint(self):
+        """State of the chains as bytes (ptnn_checkpoint_save); traces are not included."""
+        n = C.c_int64()
+        self._check(self.lib.ptnn_checkpoint_size(self.h, C.byref(n)))
+        buf = np.empty(n.value, np.uint8)
+        self._check(self.lib.ptnn_checkpoint_save(self.h, buf.ctypes.data_as(C.c_void_p), n.value))
+        return buf.tobytes()
+
+    def restore(self, blob):
+        """Continue chains saved by checkpoint() (call after set_data, instead of set_state)."""
+        buf = np.frombuffer(blob, np.uint8)
+        self._check(self.lib.ptnn_checkpoint_load(self.h, buf.ctypes.data_as(C.c_void_p), buf.size))
 
     def evaluate(self, w, tau_sq=None):
         w = _f32(np.atleast_2d(w))

@@ -84,6 +84,7 @@ struct ptnn_handle {
     bool have_data = false, have_state = false, finalized = false;
     int cap = 0;            // trace ring rows per replica
     int drained = 0;        // rows [0, drained] have been fetched by the caller (streaming mode)
+    int first_row = 0;      // trace rows below this one are not on this device (chains restored from a checkpoint)
     int cur = 0;            // next MH step index
     int rounds_done = 0;    // swap rounds counted (including the phantom one)
     int max_rounds = 0;
@@ -531,7 +532,7 @@ int ptnn_set_state(ptnn_handle* h, const float* w0, const float* temperatures) {
         HIP_TRY(hipMemcpy(h->d_pos_w + (size_t)r * S * P, onesP.data(), P * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->d_likeh + (size_t)r * S, &m100, sizeof(float), hipMemcpyHostToDevice));
     }
-    h->flip = 0; h->cur = 0; h->rounds_done = 0; h->finalized = false; h->drained = 0;
+    h->flip = 0; h->cur = 0; h->rounds_done = 0; h->finalized = false; h->drained = 0; h->first_row = 0;
     HIP_TRY(hipMemset(h->d_counters, 0, 2 * sizeof(long long)));
     h->have_state = true;
     return 0;
@@ -696,6 +697,7 @@ int ptnn_get_traces(ptnn_handle* h, int step0, int nsteps, float* pos_w, float* 
     if (step0 < 0 || nsteps < 0 || step0 + nsteps > S) return fail(-1, "trace range [%d, %d) outside [0, %d)", step0, step0 + nsteps, S);
     if (nsteps == 0) return 0;
     if (step0 + nsteps > h->cur + 1) return fail(-1, "rows up to %d requested but only %d MH steps have been queued", step0 + nsteps - 1, h->cur);
+    if (step0 < h->first_row) return fail(-1, "rows below %d were produced before the checkpoint these chains were restored from", h->first_row);
     if (step0 < h->cur + 1 - cap) return fail(-1, "row %d has already been overwritten in the trace ring (capacity %d, %d steps done)", step0, cap, h->cur);
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -770,6 +772,119 @@ int ptnn_get_state(ptnn_handle* h, float* w, float* eta, float* likelihood, floa
         if (langevin_count) langevin_count[r] = si[(size_t)r * SI_COUNT + SI_LG_COUNT];
         if (langevin_accepted) langevin_accepted[r] = si[(size_t)r * SI_COUNT + SI_LG_ACC];
     }
+    return 0;
+}
+
+// ---- checkpoint / resume: the RNG is counter based, so the chain state is small and a restored handle
+// continues the chains bit for bit.  Traces are not part of it: the caller keeps the rows it has fetched. ----
+namespace {
+struct CkHeader {
+    uint32_t magic, version;
+    ptnn_config cfg;
+    int32_t P, PS, cur, rounds_done, finalized, have_ladder, log_rounds, reserved;
+    long long counters[2];
+};
+constexpr uint32_t CK_MAGIC = 0x4b435450u;      // "PTCK"
+
+size_t ck_bytes(const ptnn_handle* h) {
+    const size_t Rl = h->cfg.n_replicas_local, R = h->cfg.n_replicas_global, PS = h->PS;
+    const size_t logr = (size_t)std::min(h->rounds_done, h->max_rounds);
+    return sizeof(CkHeader) + sizeof(float) * (3 * Rl * PS + Rl * SF_COUNT + Rl + 5 * R) + sizeof(int) * (Rl + Rl * SI_COUNT + logr * R);
+}
+
+bool same_chain(const ptnn_config& a, const ptnn_config& b) {
+    return a.task == b.task && a.n_in == b.n_in && a.n_hidden == b.n_hidden && a.n_out == b.n_out &&
+           a.n_replicas_local == b.n_replicas_local && a.n_replicas_global == b.n_replicas_global &&
+           a.first_global_replica == b.first_global_replica && a.n_samples == b.n_samples && a.swap_interval == b.swap_interval &&
+           a.pt_switch_step == b.pt_switch_step && a.use_langevin == b.use_langevin && a.swap_rule == b.swap_rule &&
+           a.shared_noise == b.shared_noise && a.forward_bf16 == b.forward_bf16 && a.l_prob == b.l_prob &&
+           a.learn_rate == b.learn_rate && a.step_w == b.step_w && a.step_eta == b.step_eta && a.sigma_squared == b.sigma_squared &&
+           a.nu_1 == b.nu_1 && a.nu_2 == b.nu_2 && a.seed == b.seed;
+}
+}  // namespace
+
+int ptnn_checkpoint_size(ptnn_handle* h, int64_t* bytes) {
+    if (int rc = check_ready(h)) return rc;
+    if (!bytes) return fail(-1, "null argument");
+    *bytes = (int64_t)ck_bytes(h);
+    return 0;
+}
+
+int ptnn_checkpoint_save(ptnn_handle* h, void* buf, int64_t bytes) {
+    if (int rc = check_ready(h)) return rc;
+    if (!buf || bytes < (int64_t)ck_bytes(h)) return fail(-1, "checkpoint buffer too small: %lld < %zu", (long long)bytes, ck_bytes(h));
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t Rl = h->cfg.n_replicas_local, R = h->cfg.n_replicas_global, PS = h->PS;
+    CkHeader hd{};
+    hd.magic = CK_MAGIC; hd.version = 1; hd.cfg = h->cfg; hd.P = h->P; hd.PS = h->PS; hd.cur = h->cur;
+    hd.rounds_done = h->rounds_done; hd.finalized = h->finalized ? 1 : 0; hd.have_ladder = h->have_ladder ? 1 : 0;
+    hd.log_rounds = std::min(h->rounds_done, h->max_rounds);
+    HIP_TRY(hipMemcpy(hd.counters, h->d_counters, sizeof(hd.counters), hipMemcpyDeviceToHost));
+    char* q = static_cast<char*>(buf);
+    std::memcpy(q, &hd, sizeof(hd)); q += sizeof(hd);
+    auto get = [&](const void* dev, size_t n) -> int {
+        if (n) HIP_TRY(hipMemcpy(q, dev, n, hipMemcpyDeviceToHost));
+        q += n;
+        return 0;
+    };
+    if (int rc = get(h->d_state[h->flip], sizeof(float) * Rl * PS)) return rc;
+    if (int rc = get(h->d_gd_w[h->flip], sizeof(float) * Rl * PS)) return rc;
+    if (int rc = get(h->d_rec_w, sizeof(float) * Rl * PS)) return rc;
+    if (int rc = get(h->d_st_f, sizeof(float) * Rl * SF_COUNT)) return rc;
+    if (int rc = get(h->d_temps, sizeof(float) * Rl)) return rc;
+    if (int rc = get(h->d_L_handoff, sizeof(float) * R)) return rc;
+    if (int rc = get(h->d_L_final, sizeof(float) * R)) return rc;
+    if (int rc = get(h->d_L_raw, sizeof(float) * R)) return rc;
+    if (int rc = get(h->d_prior_post, sizeof(float) * R)) return rc;
+    if (int rc = get(h->d_temps_global, sizeof(float) * R)) return rc;
+    if (int rc = get(h->d_gd_valid[h->flip], sizeof(int) * Rl)) return rc;
+    if (int rc = get(h->d_st_i, sizeof(int) * Rl * SI_COUNT)) return rc;
+    if (int rc = get(h->d_src_log, sizeof(int) * (size_t)hd.log_rounds * R)) return rc;
+    return 0;
+}
+
+int ptnn_checkpoint_load(ptnn_handle* h, const void* buf, int64_t bytes) {
+    if (!h || !buf) return fail(-1, "null argument");
+    if (!h->have_data) return fail(-1, "call ptnn_set_data before ptnn_checkpoint_load");
+    if (bytes < (int64_t)sizeof(CkHeader)) return fail(-1, "not a checkpoint (too short)");
+    CkHeader hd;
+    std::memcpy(&hd, buf, sizeof(hd));
+    if (hd.magic != CK_MAGIC || hd.version != 1) return fail(-1, "not a libptnn checkpoint (magic %08x version %u)", hd.magic, hd.version);
+    if (!same_chain(hd.cfg, h->cfg) || hd.P != h->P || hd.PS != h->PS)
+        return fail(-1, "the checkpoint was written by chains with a different configuration (topology, replicas, samples, seed ...)");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t Rl = h->cfg.n_replicas_local, R = h->cfg.n_replicas_global, PS = h->PS;
+    const size_t need = sizeof(CkHeader) + sizeof(float) * (3 * Rl * PS + Rl * SF_COUNT + Rl + 5 * R) +
+                        sizeof(int) * (Rl + Rl * SI_COUNT + (size_t)hd.log_rounds * R);
+    if ((size_t)bytes < need) return fail(-1, "truncated checkpoint: %lld < %zu bytes", (long long)bytes, need);
+    if (hd.log_rounds > h->max_rounds) return fail(-1, "checkpoint holds more swap rounds than this handle can log");
+    const char* q = static_cast<const char*>(buf) + sizeof(CkHeader);
+    auto put = [&](void* dev, size_t n) -> int {
+        if (n) HIP_TRY(hipMemcpy(dev, q, n, hipMemcpyHostToDevice));
+        q += n;
+        return 0;
+    };
+    h->flip = 0;
+    if (int rc = put(h->d_state[0], sizeof(float) * Rl * PS)) return rc;
+    if (int rc = put(h->d_gd_w[0], sizeof(float) * Rl * PS)) return rc;
+    if (int rc = put(h->d_rec_w, sizeof(float) * Rl * PS)) return rc;
+    if (int rc = put(h->d_st_f, sizeof(float) * Rl * SF_COUNT)) return rc;
+    if (int rc = put(h->d_temps, sizeof(float) * Rl)) return rc;
+    if (int rc = put(h->d_L_handoff, sizeof(float) * R)) return rc;
+    if (int rc = put(h->d_L_final, sizeof(float) * R)) return rc;
+    if (int rc = put(h->d_L_raw, sizeof(float) * R)) return rc;
+    if (int rc = put(h->d_prior_post, sizeof(float) * R)) return rc;
+    if (int rc = put(h->d_temps_global, sizeof(float) * R)) return rc;
+    if (int rc = put(h->d_gd_valid[0], sizeof(int) * Rl)) return rc;
+    if (int rc = put(h->d_st_i, sizeof(int) * Rl * SI_COUNT)) return rc;
+    if (int rc = put(h->d_src_log, sizeof(int) * (size_t)hd.log_rounds * R)) return rc;
+    HIP_TRY(hipMemcpy(h->d_state[1], h->d_state[0], sizeof(float) * Rl * PS, hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(h->d_counters, hd.counters, sizeof(hd.counters), hipMemcpyHostToDevice));
+    h->cur = hd.cur; h->rounds_done = hd.rounds_done; h->finalized = hd.finalized != 0; h->have_ladder = hd.have_ladder != 0;
+    h->drained = hd.cur; h->first_row = hd.cur + 1;
+    h->have_state = true;
     return 0;
 }
 

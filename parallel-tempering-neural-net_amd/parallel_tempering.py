@@ -141,24 +141,54 @@ class ParallelTemperingBase:
             self._sampler.set_ladder(self.temperatures)
 
     # ------------------------------------------------------------------ run_chains (REG:694-771)
-    def run_chains(self):
+    def run_chains(self, *, checkpoint_path=None, checkpoint_every=None, resume_from=None, max_steps=None):
+        """The reference's run_chains().  Keyword-only extras (the reference has none): `checkpoint_path` +
+        `checkpoint_every` (MH steps) write a resumable .npz (device state of the chains + the trace rows fetched so far)
+        as the run proceeds; `resume_from` continues such a file bit for bit; `max_steps` stops after that many MH steps of
+        this call (writing a checkpoint when a path is given) and returns None instead of the result tuple."""
         if self._sampler is None:
             raise RuntimeError("call initialize_chains(burn_in) before run_chains()")
         S = self.NumSamples
         open(self.path + '/num_exchange.txt', 'a').close()                      # REG:704: opened, never written
         t0 = time.perf_counter()
         cap = self.trace_capacity
-        if cap and cap < S:
-            # streaming: the device keeps a ring of `cap` trace rows per replica; drain it every cap - 1 steps
+        chunked = bool(cap and cap < S) or checkpoint_every or resume_from or max_steps
+        if chunked:
+            # the device keeps a ring of `cap` trace rows per replica (all S rows when cap == 0): drain it in windows
             parts, row, t_fetch = [], 0, 0.0
-            while self._sampler.steps_done() < S - 1:
-                self._sampler.run(min(cap - 1, S - 1 - self._sampler.steps_done()))
+            if resume_from is not None:
+                with np.load(resume_from) as z:
+                    self._sampler.restore(z["blob"].tobytes())
+                    parts.append({k[3:]: z[k] for k in z.files if k.startswith("tr_")})
+                row = self._sampler.steps_done() + 1
+                if parts[0]["accept"].shape[1] != row:
+                    raise ValueError("checkpoint file is inconsistent: trace rows do not end at the saved step")
+            window = (cap - 1) if (cap and cap < S) else S
+            if checkpoint_every:
+                window = min(window, int(checkpoint_every))
+            budget = None if max_steps is None else int(max_steps)
+
+            def save():
+                tf = {k: np.concatenate([p[k] for p in parts], axis=1) for k in parts[0]}
+                tmp = checkpoint_path + ".tmp.npz"
+                np.savez(tmp, blob=np.frombuffer(self._sampler.checkpoint(), np.uint8), **{"tr_" + k: v for k, v in tf.items()})
+                os.replace(tmp, checkpoint_path)
+            while self._sampler.steps_done() < S - 1 and (budget is None or budget > 0):
+                n = min(window, S - 1 - self._sampler.steps_done())
+                if budget is not None:
+                    n = min(n, budget)
+                    budget -= n
+                self._sampler.run(n)
                 self._sampler.sync()
                 tf = time.perf_counter()
                 hi = self._sampler.steps_done() + 1
                 parts.append(self._sampler.traces(row, hi - row))
                 row = hi
+                if checkpoint_path is not None and (checkpoint_every or budget == 0):
+                    save()
                 t_fetch += time.perf_counter() - tf
+            if self._sampler.steps_done() < S - 1:
+                return None                                                     # max_steps reached: resume later
             self._sampler.run(-1)                                               # phantom round, if due
             self._sampler.sync()
             tr = {k: np.concatenate([p[k] for p in parts], axis=1) for k in parts[0]}

@@ -32,8 +32,11 @@ def _run(key, tmp_path, **kw):
     for sdir in SUBDIRS:
         pt.make_directory(os.path.join(path, sdir))
     pt.initialize_chains(0.5)
-    res = pt.run_chains()
+    res = pt.run_chains(**_RUN_KW)
     return g, pt, res
+
+
+_RUN_KW = {}
 
 
 @pytest.mark.parametrize("key", ["reg", "reg_nophantom", "cls", "cls_nophantom"])
@@ -137,3 +140,29 @@ def test_streaming_run_chains_equals_resident(tmp_path):
     b = _run("reg", tmp_path / "b", trace_capacity=17)[2] if os.makedirs(tmp_path / "b") is None else None
     for x, y in zip(a, b):
         assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
+@pytest.mark.parametrize("key", ["reg", "cls"])
+def test_run_chains_checkpoint_and_resume(key, tmp_path):
+    """a run that is cut off after max_steps and resumed from its checkpoint file (in a new object: new
+    handle, same data) returns the same 11-tuple and writes the same files as the uninterrupted run."""
+    global _RUN_KW
+    os.makedirs(tmp_path / "a")
+    os.makedirs(tmp_path / "b")
+    a = _run(key, tmp_path / "a")[2]
+    ck = str(tmp_path / "ck.npz")
+    try:
+        _RUN_KW = dict(checkpoint_path=ck, checkpoint_every=7, max_steps=23)
+        g, pt, res = _run(key, tmp_path / "b")
+        assert res is None and os.path.exists(ck)
+        _RUN_KW = dict(checkpoint_path=ck, checkpoint_every=9, resume_from=ck)
+        b = _run(key, tmp_path / "b")[2]
+    finally:
+        _RUN_KW = {}
+    for x, y in zip(a, b):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    for root, _, files in os.walk(tmp_path / "a"):
+        for f in files:
+            pa = os.path.join(root, f)
+            pb = pa.replace(str(tmp_path / "a"), str(tmp_path / "b"))
+            assert open(pa, "rb").read() == open(pb, "rb").read(), f

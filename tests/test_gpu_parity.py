@@ -681,3 +681,50 @@ def test_shared_noise_option_matches_oracle(schedule):
             i = first - 2
             assert abs(o.logalpha[r, i] - o.logu[r, i]) < 0.05, (r, i, o.logalpha[r, i], o.logu[r, i])
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["reg_packed", "reg_spec", "cls_coop"])
+def test_checkpoint_resume_continues_bit_for_bit(case):
+    """chains saved mid-run (between swap intervals and in the middle of one) and restored into a fresh handle
+    produce the same trace rows, swap log and counters as the uninterrupted run."""
+    d = ds()
+    from ptnn_amd import ladder, philox
+    if case.startswith("reg"):
+        task, topo, train, test, lg, lr, mt = orc.TASK_REG, (4, 5, 1), d["sunspot_train"], d["sunspot_test"], True, 0.1, 2
+        sched = 0 if case == "reg_packed" else 2
+    else:
+        task, topo, train, test, lg, lr, mt, sched = orc.TASK_CLS, (4, 12, 3), d["iris_train"], d["iris_test"], False, 0.01, 10, 1
+    R, S, si, seed = 8, 10 * 11 + 3, 11, 123
+    Pw = topo[0] * topo[1] + topo[1] * topo[2] + topo[1] + topo[2]
+
+    def make():
+        return parity.make_sampler(task, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=lg, lr=lr, seed=seed,
+                                   schedule=sched)
+    full = make()
+    full.set_state(np.stack([philox.initial_weights(seed, r, Pw) for r in range(R)]), ladder.temperatures(R, mt))
+    full.run(-1)
+    full.sync()
+    want, want_log, want_stats = full.traces(), full.swap_log(), full.swap_stats()
+    full.close()
+    for stop in (4 * si + 1, 6 * si + 5):
+        a = make()
+        a.set_state(np.stack([philox.initial_weights(seed, r, Pw) for r in range(R)]), ladder.temperatures(R, mt))
+        a.run(stop)
+        a.sync()
+        head = a.traces(0, stop + 1)
+        blob = a.checkpoint()
+        a.close()
+        b = make()
+        b.restore(blob)
+        assert b.steps_done() == stop
+        with pytest.raises(Exception):
+            b.traces(0, 2)                                  # rows from before the checkpoint live with the caller
+        b.run(-1)
+        b.sync()
+        tail = b.traces(stop + 1, S - stop - 1)
+        for k in want:
+            got = np.concatenate([head[k], tail[k]], axis=1)
+            assert np.array_equal(got, want[k]), (case, stop, k)
+        assert np.array_equal(b.swap_log(), want_log) and b.swap_stats() == want_stats
+        b.close()
