@@ -180,3 +180,59 @@ def takens_embedding(series, window=5, stride=2):
     rows = np.stack([series[stride * k:stride * k + window] for k in range(nrows)])
     n_train, n_test = int(0.6 * nrows), int(0.4 * nrows) - 1
     return rows[:n_train], rows[nrows - n_test:]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Data ingestion: the per-problem loading rules of the reference's main() functions as tables.
+# REG:881-917: `Data_OneStepAhead/<name>/{train,test}.txt`, whitespace separated, 4 lag columns + target.
+# CLS:909-1012: one rule per problem -- file(s), delimiter, header row, label column and its offset, whether train/test ship
+# separately (a trailing column is dropped there) or are split 70/30 after z-scoring (`separate_flag`), and PenDigit's
+# z-scoring of train and test with their OWN moments.
+# ---------------------------------------------------------------------------------------------------------------------
+REG_FILES = {name: ("Data_OneStepAhead/%s/train.txt" % name, "Data_OneStepAhead/%s/test.txt" % name) for name in REG_PROBLEMS}
+
+# name: (mode, files, delimiter, header rows, label column, label offset)
+#   mode "split":  one file, features = columns [0, ip), z-score + random 70/30 split (split_and_normalise)
+#   mode "pair":   train and test files, last column dropped
+#   mode "pair_z": train and test files kept whole, the first ip columns z-scored per file
+CLS_FILES = {
+    "winequality-red": ("split", ("DATA/winequality-red.csv",), ";", 1, 11, 0.0),
+    "winequality-white": ("split", ("DATA/winequality-white.csv",), ";", 1, 11, 0.0),
+    "iris": ("split", ("DATA/iris.csv",), ";", 0, 4, -1.0),
+    "Ionosphere": ("pair", ("DATA/Ions/Ions/ftrain.csv", "DATA/Ions/Ions/ftest.csv"), ",", 0, None, 0.0),
+    "Cancer": ("pair", ("DATA/Cancer/ftrain.txt", "DATA/Cancer/ftest.txt"), " ", 0, None, 0.0),
+    "bank-additional": ("split", ("DATA/Bank/bank-processed.csv",), ";", 0, 20, 0.0),
+    "PenDigit": ("pair_z", ("DATA/PenDigit/train.csv", "DATA/PenDigit/test.csv"), ",", 0, None, 0.0),
+    "chess": ("split", ("DATA/chess.csv",), ";", 0, 6, 0.0),
+}
+
+
+def load_regression_problem(name, data_root):
+    """(traindata, testdata) of a time-series problem of REG main(), read from `data_root` (the directory that holds
+    `Data_OneStepAhead/`)."""
+    if name not in REG_FILES:
+        raise KeyError(f"unknown regression problem {name!r}; known: {sorted(REG_FILES)}")
+    tr, te = (os.path.join(data_root, f) for f in REG_FILES[name])
+    return np.loadtxt(tr), np.loadtxt(te)
+
+
+def load_classification_problem(name, data_root, rng=None, train_ratio=0.7):
+    """(traindata, testdata, (ip, hidden, output)) of a classification problem of CLS main(), read from `data_root` (the
+    directory that holds `DATA/`).  Problems the reference splits at random take `rng` (a numpy Generator) for a
+    reproducible split; the reference itself uses the unseeded global generator (CLS:1010)."""
+    if name not in CLS_FILES:
+        raise KeyError(f"unknown classification problem {name!r}; known: {sorted(CLS_FILES)}")
+    mode, files, delim, header, label_col, label_off = CLS_FILES[name]
+    _, ip, hidden, output = CLS_PROBLEMS[name]
+    arrs = [np.genfromtxt(os.path.join(data_root, f), delimiter=delim)[header:] for f in files]
+    if mode == "split":
+        data = arrs[0]
+        classes = data[:, label_col].reshape(-1, 1) + label_off
+        train, test = split_and_normalise(data[:, :ip], classes, ip, train_ratio=train_ratio, rng=rng)
+    elif mode == "pair":
+        train, test = arrs[0][:, :-1], arrs[1][:, :-1]
+    else:
+        train, test = (np.array(a, dtype=np.float64, copy=True) for a in arrs)
+        for a in (train, test):
+            a[:, :ip] = (a[:, :ip] - a[:, :ip].mean(axis=0)) / a[:, :ip].std(axis=0)
+    return train, test, (ip, hidden, output)

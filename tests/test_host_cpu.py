@@ -184,3 +184,39 @@ def test_create_validates_before_touching_the_gpu(pt):
     assert lib.ptnn_create(None, None) < 0
     assert lib.ptnn_destroy(None) == 0
     assert lib.ptnn_sync(None) < 0 and lib.ptnn_steps_done(None) == -1
+
+
+REF_REG = "/root/reference/multicore-pt-regression"
+REF_CLS = "/root/reference/multicore-pt-classification"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CLS), reason="the reference's data directories are only present in the build container")
+def test_problem_loaders_follow_the_reference_rules():
+    """drivers.load_*_problem: the loading rules of REG:881-917 / CLS:909-1012 as tables.  Checked against the
+    fixtures the reference-importing script wrote (same files, same rules) and against properties of the rules."""
+    import ptnn_amd
+    from ptnn_amd import drivers
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "datasets.npz"))
+    for name, key in (("Sunspot", "sunspot"), ("Mackey", "mackey"), ("Lazer", "lazer")):
+        tr, te = drivers.load_regression_problem(name, REF_REG)
+        assert np.array_equal(tr, d[key + "_train"]) and np.array_equal(te, d[key + "_test"])
+    tr, te, topo = drivers.load_classification_problem("Ionosphere", REF_CLS)
+    assert topo == (34, 50, 2) and np.array_equal(tr, d["ions_train"]) and np.array_equal(te, d["ions_test"])
+    tr, te, topo = drivers.load_classification_problem("Cancer", REF_CLS)
+    assert topo == (9, 12, 2) and np.array_equal(tr, d["cancer_train"]) and np.array_equal(te, d["cancer_test"])
+    tr, te, topo = drivers.load_classification_problem("iris", REF_CLS, rng=np.random.default_rng(2024))
+    assert topo == (4, 12, 3) and np.array_equal(tr, d["iris_train"]) and np.array_equal(te, d["iris_test"])
+    # wine: header row dropped, 11 z-scored features, quality label untouched, 70/30 split
+    tr, te, topo = drivers.load_classification_problem("winequality-red", REF_CLS, rng=np.random.default_rng(1))
+    assert topo == (11, 50, 10) and tr.shape[1] == 12 and tr.shape[0] == int(0.7 * (tr.shape[0] + te.shape[0]))
+    both = np.vstack([tr, te])
+    assert np.allclose(both[:, :11].mean(axis=0), 0, atol=1e-9) and np.allclose(both[:, :11].std(axis=0), 1)
+    assert set(np.unique(both[:, 11])) <= set(range(10))
+    # PenDigit: train and test z-scored with their own moments (CLS:975-981), labels in the last column
+    tr, te, topo = drivers.load_classification_problem("PenDigit", REF_CLS)
+    assert topo == (16, 30, 10) and tr.shape[1] == 17
+    for a in (tr, te):
+        assert np.allclose(a[:, :16].mean(axis=0), 0, atol=1e-9) and np.allclose(a[:, :16].std(axis=0), 1)
+        assert set(np.unique(a[:, 16])) <= set(range(10))
+    with pytest.raises(KeyError):
+        drivers.load_classification_problem("mnist", REF_CLS)
