@@ -125,7 +125,7 @@ int ptnn_swap_apply(ptnn_handle *h, const int32_t *src_host, int phantom);
 
 /* Gathered exchange (the default of the sharded-ladder driver; replaces the Queue traffic of REG:427-437 <-> 730-752 with ONE
  * collective per swap round): ptnn_swap_pack writes, for every local replica, the exchange row
- *   { (w, eta) row | cached langevin_gradient row | its valid flag | posted L | pad }   (row_floats floats)
+ *   { (w, eta) row | cached langevin_gradient row | its valid flag | posted L | swap_rule 1: untempered L, prior | pad }
  * into this rank's block of the buffer ptnn_xchg_ptr returns ([n_replicas_global][row_floats], same layout on every rank);
  * the caller all-gathers the buffer in place; ptnn_swap_apply_gathered then runs the cascade on the gathered L values and
  * copies every local slot's source row out of the buffer, wherever that replica ran, flips the buffers and counts the round. */

@@ -219,7 +219,10 @@ int launch_swap(ptnn_handle* h, bool phantom, int mode, bool want_src) {
         HIP_TRY(hipGetLastError());
         return 0;
     }
-    if (mode & 4) { sp.L = h->d_xchg + 2 * h->PS + 1; sp.L_stride = sp.XS; }
+    if (mode & 4) {
+        sp.L = h->d_xchg + 2 * h->PS + 1; sp.L_stride = sp.XS;
+        sp.L_raw = h->d_xchg + 2 * h->PS + 2; sp.prior_post = h->d_xchg + 2 * h->PS + 3;
+    }
     const size_t lds = (size_t)(3 * sp.R + 1) * sizeof(float);
     hipLaunchKernelGGL(swap_kernel, dim3(sp.Rl), dim3(64), lds, h->stream, sp, h->rounds_done, mode);
     HIP_TRY(hipGetLastError());
@@ -264,8 +267,6 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
     if (cfg->n_samples < 2) return fail(-1, "n_samples must be >= 2");
     if (cfg->swap_interval < 1) return fail(-1, "swap_interval must be >= 1 (the reference divides by it, REG:427)");
     if (cfg->swap_rule != 0 && cfg->swap_rule != 1) return fail(-1, "swap_rule must be 0 (reference cascade) or 1 (even/odd Metropolis)");
-    if (cfg->swap_rule == 1 && cfg->n_replicas_local != cfg->n_replicas_global)
-        return fail(-3, "swap_rule 1 is single-GPU for now: the moved state's likelihood and prior are not yet part of the row exchange");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(-2, "device %d not present (%d devices)", cfg->device_id, ndev);
@@ -615,7 +616,7 @@ int ptnn_run_segment(ptnn_handle* h, int* handoff) {
     }
     if (h->cur == last && !h->finalized) {
         h->finalized = true;
-        if (S / h->cfg.swap_interval > h->rounds_done) *handoff = 2;
+        if (h->cfg.swap_rule == 0 && S / h->cfg.swap_interval > h->rounds_done) *handoff = 2;   // no phantom round in rule 1
     }
     return 0;
 }
@@ -636,6 +637,8 @@ int ptnn_swap_set_L(ptnn_handle* h, int phantom, const float* L_host) {
 
 int ptnn_swap_cascade(ptnn_handle* h, int phantom, int32_t* src_host) {
     if (!h || !src_host) return fail(-1, "null argument");
+    if (h->cfg.swap_rule != 0)
+        return fail(-3, "the point-to-point exchange implements the reference's cascade (swap_rule 0) only: use the gathered mode");
     if (int rc = launch_swap(h, phantom != 0, 0, true)) return rc;
     const size_t bytes = h->cfg.n_replicas_global * sizeof(int);
     HIP_TRY(hipMemcpyAsync(h->h_src, h->d_src, bytes, hipMemcpyDeviceToHost, h->stream));   // pinned: no staging copy
@@ -678,7 +681,7 @@ int ptnn_xchg_ptr(ptnn_handle* h, void** base, int* row_floats) {
 
 int ptnn_swap_pack(ptnn_handle* h, int phantom) {
     if (int rc = check_ready(h)) return rc;
-    if (h->cfg.swap_rule != 0) return fail(-3, "the sharded ladder implements the reference's cascade (swap_rule 0) only");
+    if (h->cfg.swap_rule == 1 && !h->have_ladder) return fail(-1, "swap_rule 1 needs ptnn_set_ladder (all temperatures)");
     return launch_swap(h, phantom != 0, -1, false);
 }
 

@@ -2336,9 +2336,9 @@ struct SwapParams {
     // xchg[R][XS] = { state row (PS) | cached-gradient row (PS) | gradient valid | posted L | pad }
     float* xchg;               // null: single-GPU / point-to-point modes
     int XS;
-    int L_stride;              // 1, or XS when L is read from the exchange rows
+    int L_stride;              // 1, or XS when L (and, swap_rule 1, L_raw / prior_post) are read from the exchange rows
 };
-__host__ __device__ inline int xchg_row_floats(int PS) { return (2 * PS + 2 + 3) & ~3; }
+__host__ __device__ inline int xchg_row_floats(int PS) { return (2 * PS + 4 + 3) & ~3; }
 
 // sSrc has R + 1 ints: the last one carries the number of accepted swaps
 __device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, float* sL, float* sU, int* sSrc) {
@@ -2358,7 +2358,8 @@ __device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, floa
         if (threadIdx.x == 0) sSrc[R] = 0;
         __syncthreads();
         for (int k = (round & 1) + 2 * threadIdx.x; k < R - 1; k += 2 * blockDim.x) {
-            const float d = (1.0f / sp.temps_global[k] - 1.0f / sp.temps_global[k + 1]) * (sp.L_raw[k + 1] - sp.L_raw[k]);
+            const float d = (1.0f / sp.temps_global[k] - 1.0f / sp.temps_global[k + 1]) *
+                            (sp.L_raw[(size_t)(k + 1) * sp.L_stride] - sp.L_raw[(size_t)k * sp.L_stride]);
             const float pr = (d != d) ? 1.0f : fminf(1.0f, expf_fast(fminf(d, 80.0f)));
             if (sU[k] < pr) { sSrc[k] = k + 1; sSrc[k + 1] = k; atomicAdd(&sSrc[R], 1); }
         }
@@ -2393,6 +2394,10 @@ __global__ void xchg_pack_kernel(const SwapParams sp) {
     if (threadIdx.x == 0) {
         row[2 * sp.PS] = sp.gd_valid_cur[b] ? 1.0f : 0.0f;
         row[2 * sp.PS + 1] = sp.L[sp.first_global + b];
+        if (sp.rule == 1) {
+            row[2 * sp.PS + 2] = sp.L_raw[sp.first_global + b];
+            row[2 * sp.PS + 3] = sp.prior_post[sp.first_global + b];
+        }
     }
 }
 
@@ -2427,8 +2432,9 @@ __global__ void swap_kernel(const SwapParams sp, const int round, const int mode
         if (threadIdx.x == 0) sp.gd_valid_next[b] = valid;
         if (sp.rule == 1 && s != k && threadIdx.x == 0) {
             // the arriving state brings its own likelihood (re-tempered for this slot) and prior
-            sp.st_f[(size_t)b * SF_COUNT + SF_LIK] = sp.canonical ? sp.L_raw[s] : sp.L_raw[s] / sp.temps_global[k];
-            sp.st_f[(size_t)b * SF_COUNT + SF_PRIOR] = sp.prior_post[s];
+            const float lraw = sp.L_raw[(size_t)s * sp.L_stride];
+            sp.st_f[(size_t)b * SF_COUNT + SF_LIK] = sp.canonical ? lraw : lraw / sp.temps_global[k];
+            sp.st_f[(size_t)b * SF_COUNT + SF_PRIOR] = sp.prior_post[(size_t)s * sp.L_stride];
         }
     }
     if (b == 0) {

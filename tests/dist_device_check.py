@@ -28,20 +28,22 @@ def main():
     topo, R, S, si = (4, 5, 1), 16, 8 * 12 + 3, 12
     Pw = topo[0] * topo[1] + topo[1] * topo[2] + topo[1] + topo[2]
 
-    def make():
+    def make(rule=0):
         s_ = parity.make_sampler(orc.TASK_REG, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=True,
-                                 lr=0.1, seed=77)
+                                 lr=0.1, seed=77, swap_rule=rule)
         s_.set_state(np.stack([philox.initial_weights(77, r, Pw) for r in range(R)]), ladder.temperatures(R, 2))
+        if rule:
+            s_.set_ladder(ladder.temperatures(R, 2))
         return s_
-    ref = make()
-    ref.run(-1)
-    ref.sync()
-    want, want_log, want_stats = ref.traces(), ref.swap_log(), ref.swap_stats()
-    ref.close()
-    assert want_stats[0] > 0
     try:
-        for mode in ("gather", "p2p"):
-            s = make()
+        for mode, rule in (("gather", 0), ("p2p", 0), ("gather", 1)):
+            ref = make(rule)
+            ref.run(-1)
+            ref.sync()
+            want, want_log, want_stats = ref.traces(), ref.swap_log(), ref.swap_stats()
+            ref.close()
+            assert want_stats[0] > 0
+            s = make(rule)
             lad = dm.ShardedLadder(dm.DeviceShard(s, 0), 0, 1, dist, mode=mode)
             lad.run_intervals(None)
             s.sync()
@@ -51,7 +53,7 @@ def main():
             assert np.array_equal(s.swap_log(), want_log), mode
             assert s.swap_stats() == want_stats, mode
             s.close()
-            print("OK", mode, flush=True)
+            print("OK", mode, "rule", rule, flush=True)
     finally:
         dist.destroy_process_group()
 

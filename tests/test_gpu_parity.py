@@ -609,7 +609,7 @@ def test_sharded_ladder_driver_on_device_matches_plain_run():
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "dist_device_check.py")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "OK gather" in r.stdout and "OK p2p" in r.stdout
+    assert "OK gather rule 0" in r.stdout and "OK p2p rule 0" in r.stdout and "OK gather rule 1" in r.stdout
 
 
 @pytest.mark.gpu

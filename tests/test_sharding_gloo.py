@@ -69,7 +69,9 @@ class OracleShard:
         self.L = [torch.zeros(self.R_global, dtype=torch.float64), torch.zeros(self.R_global, dtype=torch.float64)]
         self.rows_cur = torch.zeros(self.R_local, self.PS, dtype=torch.float64)
         self.rows_next = torch.zeros(self.R_local, self.PS, dtype=torch.float64)
-        self.XS = self.PS + 3                       # gather mode: {w, eta | L handoff | L final | pad}
+        self.swap_rule = int(pt_args["kw"].get("swap_rule", 0))
+        self.temps = list(full.temperatures)
+        self.XS = self.PS + 4                       # gather mode: {w, eta | L handoff | L final | untempered L | prior}
         self.xchg = torch.zeros(self.R_global * self.XS, dtype=torch.float64)
 
     def run_segment(self):
@@ -86,7 +88,7 @@ class OracleShard:
                     break
         if ho == 0 and self.cur == last and not self.finalized:
             self.finalized = True
-            if int(self.S / self.si) > self.rounds_done:
+            if self.swap_rule == 0 and int(self.S / self.si) > self.rounds_done:
                 ho = 2
         for k, rep in enumerate(self.reps):
             self.L[0][self.first + k] = rep.posted_L()
@@ -117,6 +119,8 @@ class OracleShard:
             X[self.first + k, :self.PS] = self.rows_cur[k]
             X[self.first + k, self.PS] = self.L[0][self.first + k]
             X[self.first + k, self.PS + 1] = self.L[1][self.first + k]
+            X[self.first + k, self.PS + 2] = self.reps[k].likelihood * self.reps[k].adapttemp
+            X[self.first + k, self.PS + 3] = self.reps[k].prior_current
 
     def before_collective(self):
         pass
@@ -126,6 +130,28 @@ class OracleShard:
 
     def apply_gathered(self, phantom):
         X = self.xchg.view(self.R_global, self.XS)
+        if self.swap_rule == 1:                     # even/odd Metropolis exchange on the gathered untempered likelihoods
+            import math
+            R = self.R_global
+            u = self.tape.swap_uniforms(self.rounds_done, R - 1)
+            raw = X[:, self.PS + 2].tolist()
+            src = list(range(R))
+            for k in range(self.rounds_done & 1, R - 1, 2):
+                dd = (1.0 / self.temps[k] - 1.0 / self.temps[k + 1]) * (raw[k + 1] - raw[k])
+                pr = 1.0 if dd != dd else min(1.0, math.exp(min(dd, 80.0)))
+                if u[k] < pr:
+                    src[k], src[k + 1] = k + 1, k
+                    self.num_swap += 1
+            for k, rep in enumerate(self.reps):
+                sg = src[self.first + k]
+                if sg != self.first + k:
+                    row = X[sg]
+                    rep.w = row[:self.P].numpy().copy()
+                    rep.eta = float(row[self.P])
+                    rep.prior_current = float(row[self.PS + 3])
+                    rep.likelihood = float(row[self.PS + 2]) / rep.adapttemp
+            self.rounds_done += 1
+            return
         L = X[:, self.PS + (1 if phantom else 0)].tolist()
         u = self.tape.swap_uniforms(self.rounds_done, self.R_global - 1)
         src, nsw = orc.swap_cascade(L, u)
@@ -185,7 +211,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,task,mode", [(2, orc.TASK_REG, "gather"), (4, orc.TASK_CLS, "gather"),
-                                             (2, orc.TASK_REG, "p2p"), (4, orc.TASK_CLS, "p2p")])
+                                             (2, orc.TASK_REG, "p2p"), (4, orc.TASK_CLS, "p2p"), (4, orc.TASK_REG, "gather-rule1")])
 def test_sharded_ladder_matches_single_process(tmp_path, datasets, world, task, mode):
     import torch.multiprocessing as mp
     if task == orc.TASK_REG:
@@ -194,6 +220,9 @@ def test_sharded_ladder_matches_single_process(tmp_path, datasets, world, task, 
     else:
         args = (task, (4, 12, 3), datasets["iris_train"], datasets["iris_test"], 8, 10, 8 * 40, 5)
         kw = dict(use_lg=False, l_prob=0.5, lr=0.01, seed=32)      # S = 40: S % si == 0 -> phantom round
+    if mode == "gather-rule1":
+        kw["swap_rule"] = 1
+        mode = "gather"
     pt_args = dict(args=args, kw=kw)
     ref = orc.PTOracle(*args, **kw).run()
     mp.spawn(_worker, args=(world, _free_port(), pt_args, str(tmp_path), mode), nprocs=world, join=True)
