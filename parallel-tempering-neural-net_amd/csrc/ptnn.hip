@@ -70,7 +70,8 @@ struct ptnn_handle {
     int model_threads = 64;
     bool speculative = false;
     bool wide = false;              // 64 < H: vectors in HBM, one thread per hidden unit
-    bool packed = false;            // H <= 8: packed speculative schedule on one CU
+    bool packed = false;            // H <= 16: packed speculative schedule on one CU
+    int pk_nred = 3;                // its lane-group width: 2^3 (H <= 8) or 2^4 hidden units
     float* d_wide_scratch = nullptr;
     float* d_xt = nullptr;          // transposed data image for the MFMA forward pass
     int Npad = 0;
@@ -135,7 +136,7 @@ struct ptnn_handle {
         p.L_raw = (cfg.swap_rule == 1) ? d_L_raw : nullptr; p.prior_post = d_prior_post;
         p.tr_pos_w = d_pos_w; p.tr_likeh = d_likeh; p.tr_rmse_tr = d_rmse_tr; p.tr_rmse_te = d_rmse_te;
         p.tr_acc_tr = d_acc_tr; p.tr_acc_te = d_acc_te; p.tr_accept = d_accept;
-        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.noise_shared = cfg.shared_noise ? 1 : 0; p.xt = d_xt; p.Npad = Npad; p.fw_mfma = fw_mfma ? 1 : 0; p.forward_bf16 = cfg.forward_bf16;
+        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.noise_shared = cfg.shared_noise ? 1 : 0; p.pk_nred = pk_nred; p.xt = d_xt; p.Npad = Npad; p.fw_mfma = fw_mfma ? 1 : 0; p.forward_bf16 = cfg.forward_bf16;
         return p;
     }
 };
@@ -421,16 +422,21 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         return fail(-1, "unknown schedule %d", sched);
     h->packed = false;
     {
-        // packed speculative: 16 slots on one CU, the SGD epochs of all slots in the lane groups of two waves.  Taken
-        // automatically for Langevin runs of nets with <= 8 hidden units (same speed as 4 CUs per replica on a quarter of
-        // the GPU, twice the throughput once there are more replicas than CUs); random-walk-only runs have no epochs to pack
-        // and keep the multi-CU speculative schedule.
-        const size_t pk = pack_lds_floats(Nall, IPY, h->PS, H, h->FWS) * sizeof(float);
-        const bool fits = H <= (1 << PK_NRED) && pk <= LDS_MAX;
+        // packed speculative: all slots of a round on one CU, the SGD epochs of the slots in the lane groups of two waves:
+        // 16 slots in groups of 8 lanes for n_hidden <= 8, 8 slots in groups of 16 lanes for n_hidden <= 16.  Taken
+        // automatically for Langevin runs of such nets (faster than 4 CUs per replica on a quarter of the GPU, and more than
+        // twice the throughput once there are more replicas than CUs); random-walk-only runs have no epochs to pack and keep
+        // the multi-CU speculative schedule.
+        h->pk_nred = (H <= 8) ? 3 : 4;
+        const size_t pk = pack_lds_floats(Nall, IPY, h->PS, H, h->FWS, pack_slots(h->pk_nred)) * sizeof(float);
+        const bool fits = H <= 16 && pk <= LDS_MAX;
         if (sched == PTNN_SCHED_PACKED && !fits)
-            return fail(-3, "the packed schedule needs n_hidden <= %d and %zu B of LDS <= 160 KiB", 1 << PK_NRED, pk);
+            return fail(-3, "the packed schedule needs n_hidden <= 16 and %zu B of LDS <= 160 KiB", pk);
+        // 16-lane groups give 8 slots per round: with CUs to spare, 4 CUs x 4 waves per replica (16 slots) are still quicker
+        // (Mackey-Glass 4-10-1, 64 replicas: 13.7 M vs 12.9 M samples/s), so the wider groups are taken when replicas are many
+        const bool pays = (H <= 8) || h->cfg.n_replicas_local * 4 > h->num_cus;
         if (sched == PTNN_SCHED_PACKED ||
-            (h->cfg.schedule == PTNN_SCHED_AUTO && sched == PTNN_SCHED_SPECULATIVE && fits && h->cfg.use_langevin &&
+            (h->cfg.schedule == PTNN_SCHED_AUTO && sched == PTNN_SCHED_SPECULATIVE && fits && pays && h->cfg.use_langevin &&
              h->cfg.waves_per_replica == 0 && h->cfg.groups_per_replica == 0)) {
             h->packed = true; h->speculative = true; h->groups = 1;
             h->nthreads = PK_WAVES * WAVE;

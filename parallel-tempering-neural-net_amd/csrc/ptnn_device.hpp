@@ -34,6 +34,7 @@ enum { SI_NACC = 0, SI_UNUSED, SI_LG_COUNT, SI_LG_ACC, SI_COUNT = 4 };   // acce
 struct SegParams {
     int H, P, PS;            // hidden units, parameters, state row length (P + 1 rounded up to 4)
     int Ntr, Nte, IPY, FWS;  // rows, data row stride (floats), packed forward row stride (floats)
+    int pk_nred;             // packed schedule: log2 of the lane-group width (3: n_hidden <= 8, 4: n_hidden <= 16)
     int noise_shared;        // Q14: every replica reads the step tape of replica 0
     int fw_mfma;             // cooperative schedule: forward pass on the matrix cores (host decides: 24 <= H <= 64, I >= 6)
     int S, switch_step, use_lg;
@@ -786,8 +787,9 @@ __device__ __forceinline__ void finish_eval(const EvalSums& s, int Ntr, int Nte,
 // R7 prior_likelihood (REG:215-221 / CLS:224-230); prior_c = part1, log tau^2 = eta
 template <int TASK>
 __device__ __forceinline__ float prior_value(const SegParams& p, float sumsq, float eta) {
-    float v = p.prior_c - p.inv_2sig2 * sumsq;
-    if (TASK == TASK_REG) v = v - (1.0f + p.nu1) * eta - p.nu2 * expf_fast(-eta);
+    // explicit fused operations: the value must not depend on how the compiler contracts the expression in each kernel
+    float v = fmaf(-p.inv_2sig2, sumsq, p.prior_c);
+    if (TASK == TASK_REG) v = fmaf(-p.nu2, expf_fast(-eta), fmaf(-(1.0f + p.nu1), eta, v));
     return v;
 }
 
@@ -927,7 +929,8 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_coop(const float* __restrict_
             bf[s_] = pad ? 0.0f : vb;
             aa[s_] = pad ? 0.0f : va;
         }
-        // bias and W2 rows of this lane's 16 hidden units, fetched while the matrix pipe works
+        // bias and W2 rows of this lane's 16 hidden units, fetched while the matrix pipe works (absent units: both zero,
+        // so their sigmoid is a finite 0.5 that meets W2 = 0)
         const int hq = hbase + 4 * half;
         const float* pb1 = wl + oB1 + hq;
         const float* pw2 = wl + oW2 + hq * O;
@@ -935,8 +938,9 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_coop(const float* __restrict_
 #pragma unroll
         for (int r_ = 0; r_ < 16; ++r_) {
             const int dh = 8 * (r_ >> 2) + (r_ & 3);
-            b1r[r_] = pb1[dh];
             const bool in = hq + dh < H;
+            const float bv = pb1[dh];
+            b1r[r_] = in ? bv : 0.0f;                                  // past H the read lands in padding: never let a NaN in
 #pragma unroll
             for (int o = 0; o < O; ++o) { const float v = pw2[dh * O + o]; w2r[r_][o] = in ? v : 0.0f; }
         }
@@ -1575,16 +1579,19 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
 // no cross-CU exchange on the critical path.  Per-slot arithmetic is the same code as in segment_spec_kernel, so the
 // committed chain is bit-identical to it (tested).
 // ------------------------------------------------------------------------------------------------
-constexpr int PK_SLOTS = 16, PK_NRED = 3, PK_NG = 8, PK_WAVES = 4, PK_SWEEP_WAVES = 2;
+constexpr int PK_WAVES = 4, PK_SWEEP_WAVES = 2;
+// lane groups of 2^nred hidden units: 8 (n_hidden <= 8: 16 slots per round) or 16 (n_hidden <= 16: 8 slots per round)
+__host__ __device__ constexpr int pack_slots(int nred) { return PK_SWEEP_WAVES * (WAVE >> nred); }
 
 __host__ __device__ inline size_t pack_slot_floats(int PS) { return 3 * (size_t)PS + 8; }
-__host__ __device__ inline size_t pack_lds_floats(int Nall, int IPY, int PS, int H, int FWS) {
-    return (size_t)(Nall + 2) * IPY + 3 * (size_t)PS + MAX_WAVES * 8 + (size_t)PK_SLOTS * SL_COUNT +
-           (size_t)PK_SLOTS * pack_slot_floats(PS) + (size_t)PK_WAVES * fw_floats(H, FWS);
+__host__ __device__ inline size_t pack_lds_floats(int Nall, int IPY, int PS, int H, int FWS, int nslots) {
+    return (size_t)(Nall + 2) * IPY + 3 * (size_t)PS + MAX_WAVES * 8 + (size_t)nslots * SL_COUNT +
+           (size_t)nslots * pack_slot_floats(PS) + (size_t)PK_WAVES * fw_floats(H, FWS);
 }
 
-template <int TASK, int I, int O>
-__global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const SegParams p, const int step_begin, const int n_steps) {
+template <int TASK, int I, int O, int PK_NRED>
+__device__ __forceinline__ void segment_pack_body(const SegParams& p, const int step_begin, const int n_steps) {
+    constexpr int PK_NG = WAVE >> PK_NRED, PK_SLOTS = pack_slots(PK_NRED);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int r = blockIdx.x;
     const int gid = p.first_global + r;
@@ -1868,6 +1875,14 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
         p.L_final[gid] = lik;
         post_raw(p, gid, lik, prior_cur, T, step_begin + n_steps - 1);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+
+template <int TASK, int I, int O>
+__global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const SegParams p, const int step_begin, const int n_steps) {
+    if (p.pk_nred == 4) segment_pack_body<TASK, I, O, 4>(p, step_begin, n_steps);
+    else segment_pack_body<TASK, I, O, 3>(p, step_begin, n_steps);
 }
 
 // ------------------------------------------------------------------------------------------------

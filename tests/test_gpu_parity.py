@@ -308,7 +308,7 @@ def test_invariants_at_full_size():
     s.close(); s2.close(); s3.close()
 
 
-@pytest.mark.parametrize("case", ["sunspot_lg", "sunspot_rw", "iris_lg", "ions_rw"])
+@pytest.mark.parametrize("case", ["sunspot_lg", "sunspot_rw", "mackey_lg", "iris_lg", "ions_rw"])
 def test_speculative_schedule_is_wave_count_invariant(case):
     """Slot s = (work-group g, wave v) pre-computes step i+s; only the prefix up to the first accept is committed.  The
     committed chain must not depend on how many steps were speculated nor on how the slots are spread over CUs: every
@@ -318,6 +318,8 @@ def test_speculative_schedule_is_wave_count_invariant(case):
         task, topo, name, lg, lr, R, S, si, mt = 0, (4, 5, 1), "sunspot", True, 0.1, 8, 400, 20, 2
     elif case == "sunspot_rw":
         task, topo, name, lg, lr, R, S, si, mt = 0, (4, 5, 1), "sunspot", False, 0.1, 8, 400, 20, 2
+    elif case == "mackey_lg":
+        task, topo, name, lg, lr, R, S, si, mt = 0, (4, 10, 1), "mackey", True, 0.1, 8, 300, 20, 2
     elif case == "iris_lg":
         task, topo, name, lg, lr, R, S, si, mt = 1, (4, 12, 3), "iris", True, 0.01, 6, 300, 10, 10
     else:
@@ -348,8 +350,8 @@ def test_speculative_schedule_is_wave_count_invariant(case):
             assert (got[0][k] == ref[0][k]).all(), (waves, groups, k)
         for k in got[3]:
             assert (got[3][k] == ref[3][k]).all(), (waves, groups, k)
-    if topo[1] <= 8:
-        # the packed schedule (16 slots on one CU, SGD epochs of all slots in lane groups) commits the same chain too
+    if topo[1] <= 16:
+        # the packed schedule (all slots on one CU, SGD epochs of the slots in lane groups of 8 or 16) commits the same chain too
         s = parity.make_sampler(task, topo, d[name + "_train"], d[name + "_test"], R_local=R, R_global=R, first=0, S=S, si=si,
                                 use_lg=lg, lr=lr, seed=77, schedule=3)
         s.set_state(w0, T)
