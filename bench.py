@@ -180,6 +180,17 @@ OTHER_CONFIGS = {
 }
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch of the dominant kernel of a workload, from the PMC passes committed under profiles/ (rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE, separate runs of the same command, gfx950 FETCH_SIZE x2 correction applied), or None."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", f"current_pmc_{workload}.json")))
+        best = max((e for k, e in pmc["kernels"].items() if "segment" in k), key=lambda e: e.get("hbm_bytes_per_launch", 0.0))
+        return best.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def bench_other_config(a):
     """Single-GPU measurement of the other BASELINE configs (parity-test cases; same JSON shape as the headline)."""
     import ptnn_amd
@@ -232,7 +243,7 @@ def bench_other_config(a):
         "swap_accept_pct": 100.0 * (nsw1 - nsw0) / max(tot1 - tot0, 1),
         "mh_accept_pct": float(100.0 * np.mean(s.state()["num_accepted"]) / max(s.steps_done(), 1)),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
+                     "traffic": pmc_traffic(a.workload), "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
                      "algorithmic_bytes_per_launch": bytes_per_launch}}), flush=True)
     s.close()
 

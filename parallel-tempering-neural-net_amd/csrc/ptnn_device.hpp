@@ -371,86 +371,134 @@ __device__ __forceinline__ void sgd_sweep(const float* __restrict__ w_in, float*
             n = 4 * iters;
         }
     }
-    auto row_step = [&](const float (&xprev)[RW], const float (&x)[RW], const float (&xnext)[RW]) {
-        const float z = fmaf(lhd_p, x[I + 1], zp);
-        const float e = __builtin_amdgcn_exp2f(z);
-#pragma unroll
-        for (int i = 0; i < I; ++i) w1[i] = fmaf(lhd_p, xprev[i], w1[i]);     // row n-1's update
-        nb1 += lhd_p;
-        zp = zpart(xnext);
-        const float hid = __builtin_amdgcn_rcpf(1.0f + e);
-        const float dh = fmaf(-hid, hid, hid);                 // hid (1 - hid)
-        const float ldh = lr * dh;
-        float g = 0.0f;
-        float lod[O];
-#pragma unroll
-        for (int o = 0; o < O; ++o) {
-            const float zo = group_allsum<NRED>(fmaf(hid, w2[o], cl[o]));
-            const float out = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zo));
-            float t;
-            if (TASK == TASK_CLS) t = ((int)x[I] == o) ? 1.0f : 0.0f;   // one-hot(int(y)) (CLS:73-75)
-            else t = x[I];                                               // REG: O == 1
-            const float od = (t - out) * fmaf(-out, out, out);
-            g = fmaf(od, w2[o], g);                                      // pre-update W2 (Q4)
-            lod[o] = clr * od;
-        }
-        lhd_p = g * ldh;
-#pragma unroll
-        for (int o = 0; o < O; ++o) {
-            w2[o] = fmaf(lod[o], hid, w2[o]);
-            cl[o] = fmaf(lod[o], m0, cl[o]);
-        }
-    };
+    if constexpr (I <= 8) {
+        auto row_step = [&](const float (&xprev)[RW], const float (&x)[RW], const float (&xnext)[RW]) {
+            const float z = fmaf(lhd_p, x[I + 1], zp);
+            const float e = __builtin_amdgcn_exp2f(z);
+    #pragma unroll
+            for (int i = 0; i < I; ++i) w1[i] = fmaf(lhd_p, xprev[i], w1[i]);     // row n-1's update
+            nb1 += lhd_p;
+            zp = zpart(xnext);
+            const float hid = __builtin_amdgcn_rcpf(1.0f + e);
+            const float dh = fmaf(-hid, hid, hid);                 // hid (1 - hid)
+            const float ldh = lr * dh;
+            float g = 0.0f;
+            float lod[O];
+    #pragma unroll
+            for (int o = 0; o < O; ++o) {
+                const float zo = group_allsum<NRED>(fmaf(hid, w2[o], cl[o]));
+                const float out = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zo));
+                float t;
+                if (TASK == TASK_CLS) t = ((int)x[I] == o) ? 1.0f : 0.0f;   // one-hot(int(y)) (CLS:73-75)
+                else t = x[I];                                               // REG: O == 1
+                const float od = (t - out) * fmaf(-out, out, out);
+                g = fmaf(od, w2[o], g);                                      // pre-update W2 (Q4)
+                lod[o] = clr * od;
+            }
+            lhd_p = g * ldh;
+    #pragma unroll
+            for (int o = 0; o < O; ++o) {
+                w2[o] = fmaf(lod[o], hid, w2[o]);
+                cl[o] = fmaf(lod[o], m0, cl[o]);
+            }
+        };
 
-    // ring of four row buffers: previous, current, next, and the one being fetched (row n+2).  The data image carries
-    // two padding rows, so the look-ahead never leaves it.
-    float xa[RW], xb[RW], xc[RW], xd[RW];
-    const float* pr = xy + (size_t)n * IPY;
-    lds_load<RW>(pr, xb);
-    lds_load<RW>(pr + IPY, xc);
-#pragma unroll
-    for (int i = 0; i < RW; ++i) xa[i] = 0.0f;
-    zp = zpart(xb);
-    pr += 2 * IPY;
-    for (; n + 3 < Ntr; n += 4) {
-        lds_load<RW>(pr, xd);
-        row_step(xa, xb, xc);
-        lds_load<RW>(pr + IPY, xa);
-        row_step(xb, xc, xd);
-        lds_load<RW>(pr + 2 * IPY, xb);
-        row_step(xc, xd, xa);
-        lds_load<RW>(pr + 3 * IPY, xc);
-        row_step(xd, xa, xb);
-        pr += 4 * IPY;
-    }
-    // tail: up to three rows; afterwards the update of the very last row is still pending
-    float xl[RW];
-    const int rem = Ntr - n;
-    if (rem == 0) {
-#pragma unroll
-        for (int i = 0; i < RW; ++i) xl[i] = xa[i];
-    } else if (rem == 1) {
-        row_step(xa, xb, xc);
-#pragma unroll
-        for (int i = 0; i < RW; ++i) xl[i] = xb[i];
-    } else if (rem == 2) {
-        lds_load<RW>(pr, xd);
-        row_step(xa, xb, xc);
-        row_step(xb, xc, xd);
-#pragma unroll
-        for (int i = 0; i < RW; ++i) xl[i] = xc[i];
+        // ring of four row buffers: previous, current, next, and the one being fetched (row n+2).  The data image carries
+        // two padding rows, so the look-ahead never leaves it.
+        float xa[RW], xb[RW], xc[RW], xd[RW];
+        const float* pr = xy + (size_t)n * IPY;
+        lds_load<RW>(pr, xb);
+        lds_load<RW>(pr + IPY, xc);
+    #pragma unroll
+        for (int i = 0; i < RW; ++i) xa[i] = 0.0f;
+        zp = zpart(xb);
+        pr += 2 * IPY;
+        for (; n + 3 < Ntr; n += 4) {
+            lds_load<RW>(pr, xd);
+            row_step(xa, xb, xc);
+            lds_load<RW>(pr + IPY, xa);
+            row_step(xb, xc, xd);
+            lds_load<RW>(pr + 2 * IPY, xb);
+            row_step(xc, xd, xa);
+            lds_load<RW>(pr + 3 * IPY, xc);
+            row_step(xd, xa, xb);
+            pr += 4 * IPY;
+        }
+        // tail: up to three rows; afterwards the update of the very last row is still pending
+        float xl[RW];
+        const int rem = Ntr - n;
+        if (rem == 0) {
+    #pragma unroll
+            for (int i = 0; i < RW; ++i) xl[i] = xa[i];
+        } else if (rem == 1) {
+            row_step(xa, xb, xc);
+    #pragma unroll
+            for (int i = 0; i < RW; ++i) xl[i] = xb[i];
+        } else if (rem == 2) {
+            lds_load<RW>(pr, xd);
+            row_step(xa, xb, xc);
+            row_step(xb, xc, xd);
+    #pragma unroll
+            for (int i = 0; i < RW; ++i) xl[i] = xc[i];
+        } else {
+            lds_load<RW>(pr, xd);
+            row_step(xa, xb, xc);
+            lds_load<RW>(pr + IPY, xa);
+            row_step(xb, xc, xd);
+            row_step(xc, xd, xa);
+    #pragma unroll
+            for (int i = 0; i < RW; ++i) xl[i] = xd[i];
+        }
+    #pragma unroll
+        for (int i = 0; i < I; ++i) w1[i] = fmaf(lhd_p, xl[i], w1[i]);
+        b1 = -(nb1 + lhd_p);
     } else {
-        lds_load<RW>(pr, xd);
-        row_step(xa, xb, xc);
-        lds_load<RW>(pr + IPY, xa);
-        row_step(xb, xc, xd);
-        row_step(xc, xd, xa);
+        // wide input layers: the 2 I independent FMAs of a row already fill the hazard slots, and a ring of four I-wide
+        // rows would cost more registers than the deferral saves -- plain chain, two rows in flight
+        b1 = -nb1;
+        auto row_plain = [&](const float (&x)[I + 1]) {
+            float z = fmaf(x[0], w1[0], -b1);
 #pragma unroll
-        for (int i = 0; i < RW; ++i) xl[i] = xd[i];
+            for (int i = 1; i < I; ++i) z = fmaf(x[i], w1[i], z);
+            const float hid = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
+            const float ldh = lr * fmaf(-hid, hid, hid);
+            float g = 0.0f;
+            float lod[O];
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                const float zo = group_allsum<NRED>(fmaf(hid, w2[o], cl[o]));
+                const float out = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zo));
+                float t;
+                if (TASK == TASK_CLS) t = ((int)x[I] == o) ? 1.0f : 0.0f;   // one-hot(int(y)) (CLS:73-75)
+                else t = x[I];
+                const float od = (t - out) * fmaf(-out, out, out);
+                g = fmaf(od, w2[o], g);                                      // pre-update W2 (Q4)
+                lod[o] = clr * od;
+            }
+            const float lhd = g * ldh;
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                w2[o] = fmaf(lod[o], hid, w2[o]);
+                cl[o] = fmaf(lod[o], m0, cl[o]);
+            }
+#pragma unroll
+            for (int i = 0; i < I; ++i) w1[i] = fmaf(lhd, x[i], w1[i]);
+            b1 -= lhd;
+        };
+        float ya[I + 1], yb[I + 1];
+        lds_load<I + 1>(xy, ya);
+        lds_load<I + 1>(xy + IPY, yb);
+        const float* pr = xy + 2 * IPY;
+        int m = 0;
+        for (; m + 1 < Ntr; m += 2) {
+            row_plain(ya);
+            lds_load<I + 1>(pr, ya);
+            row_plain(yb);
+            lds_load<I + 1>(pr + IPY, yb);
+            pr += 2 * IPY;
+        }
+        if (m < Ntr) row_plain(ya);
     }
-#pragma unroll
-    for (int i = 0; i < I; ++i) w1[i] = fmaf(lhd_p, xl[i], w1[i]);
-    b1 = -(nb1 + lhd_p);
 
     if (act) {
 #pragma unroll
@@ -466,13 +514,28 @@ __device__ __forceinline__ void sgd_sweep(const float* __restrict__ w_in, float*
 }
 
 template <int TASK, int I, int O>
-__device__ __forceinline__ void sgd_sweep_dispatch(const float* w_in, float* w_out, const float* xy, const float* gdata, int Ntr,
-                                                   int H, float lr) {
+__device__ __forceinline__ void sgd_sweep_select(const float* w_in, float* w_out, const float* xy, const float* gdata, int Ntr,
+                                                 int H, float lr) {
     if (H <= 4) sgd_sweep<TASK, I, O, 2>(w_in, w_out, xy, gdata, Ntr, H, lr);
     else if (H <= 8) sgd_sweep<TASK, I, O, 3>(w_in, w_out, xy, gdata, Ntr, H, lr);
     else if (H <= 16) sgd_sweep<TASK, I, O, 4>(w_in, w_out, xy, gdata, Ntr, H, lr);
     else if (H <= 32) sgd_sweep<TASK, I, O, 5>(w_in, w_out, xy, gdata, Ntr, H, lr);
     else sgd_sweep<TASK, I, O, 6>(w_in, w_out, xy, gdata, Ntr, H, lr);
+}
+// wide input layers keep ~2 I + 40 registers per lane inside the epoch; inlined into the segment kernels (twice, five lane-group
+// variants each) that pressure spills the kernels' own loop state even in runs that never take a Langevin step (rocprofv3:
+// 2.9x the algorithmic HBM writes on the Ionosphere workload came from scratch).  An epoch is 10^5 cycles: a real call costs
+// nothing.
+template <int TASK, int I, int O>
+__device__ __attribute__((noinline)) void sgd_sweep_call(const float* w_in, float* w_out, const float* xy, const float* gdata,
+                                                         int Ntr, int H, float lr) {
+    sgd_sweep_select<TASK, I, O>(w_in, w_out, xy, gdata, Ntr, H, lr);
+}
+template <int TASK, int I, int O>
+__device__ __forceinline__ void sgd_sweep_dispatch(const float* w_in, float* w_out, const float* xy, const float* gdata, int Ntr,
+                                                   int H, float lr) {
+    if constexpr (I > 8) sgd_sweep_call<TASK, I, O>(w_in, w_out, xy, gdata, Ntr, H, lr);
+    else sgd_sweep_select<TASK, I, O>(w_in, w_out, xy, gdata, Ntr, H, lr);
 }
 
 // ------------------------------------------------------------------------------------------------
