@@ -268,7 +268,12 @@ def dependent_chain(s, W, K, si, slots=16):
             rr.append(rounds)
         per_rounds.append(rr)
     per_acc, per_rounds = np.array(per_acc), np.array(per_rounds)
-    return {"slots_per_round": slots, "accepted_steps_per_interval_mean": float(per_acc.mean()),
+    # floor of an interval: every accepted step of its slowest replica costs one sequential SGD epoch (298 rows x 143 cycles
+    # per row measured with in-kernel stamps, DESIGN.md 4, at the 2.4 GHz shader clock of the stamp runs)
+    epoch_ms = 298 * 143 / 2.4e9 * 1e3
+    floor_ms = float(per_acc.max(axis=1).mean()) * epoch_ms
+    return {"slots_per_round": slots, "sgd_epoch_ms": epoch_ms, "chain_floor_ms_per_interval": floor_ms,
+            "accepted_steps_per_interval_mean": float(per_acc.mean()),
             "accepted_steps_per_interval_max_over_replicas_mean": float(per_acc.max(axis=1).mean()),
             "rounds_per_interval_mean": float(per_rounds.mean()),
             "rounds_per_interval_max_over_replicas_mean": float(per_rounds.max(axis=1).mean()),
@@ -405,6 +410,7 @@ def main():
                                  "fraction is reported because BASELINE.json asks for it"},
         }
         if chain is not None:
+            chain["frac_of_chain_floor"] = chain["chain_floor_ms_per_interval"] / (avg_launch_s * 1e3) if launches else None
             out["dependent_chain"] = chain
         if cpu is not None:
             out["cpu_baseline"] = cpu
