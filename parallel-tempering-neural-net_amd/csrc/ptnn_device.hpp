@@ -2445,13 +2445,18 @@ __device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, floa
         return sSrc[R];
     }
     if (threadIdx.x == 0) {
+        // the carried state's L stays in a register: the only LDS reads of a step (L[k+1], u[k]) have addresses that do not
+        // depend on the decisions, so they run ahead of the chain
         int c = 0, nsw = 0;
+        float Lc = sL[0];
+#pragma unroll 4
         for (int k = 0; k < R - 1; ++k) {
-            float d = sL[k + 1] - sL[c];
+            const float Ln = sL[k + 1];
+            float d = Ln - Lc;
             d = (d < 709.0f) ? d : 709.0f;                  // python min(709, nan) == 709
             const float pr = fminf(1.0f, 0.5f * expf_fast(d));
             if (sU[k] < pr) { sSrc[k] = k + 1; nsw++; }
-            else { sSrc[k] = c; c = k + 1; }
+            else { sSrc[k] = c; c = k + 1; Lc = Ln; }
         }
         sSrc[R - 1] = c;
         sSrc[R] = nsw;
