@@ -89,13 +89,37 @@ def _cpu_chain(args):
     return time.perf_counter() - t0
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask and the cgroup CPU quota, not the machine's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(train, test, n_steps=40):
     """The oracle (float64 numpy restatement, per-row loops like the reference: faithful=True) on the host cores:
     the same 64-replica Langevin workload, n_steps MH steps per replica, one process per core."""
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ptnn_oracle as orc
-    cores = max(1, min(os.cpu_count() or 1, R_PER_GPU))
+    cores = max(1, min(usable_cores(), R_PER_GPU))
     T = orc.temperature_ladder(R_PER_GPU, MAXTEMP)
     jobs = [(g, n_steps, train, test, T[g]) for g in range(R_PER_GPU)]
     ctx = mp.get_context("fork")
