@@ -38,6 +38,13 @@ B_SWAP = 4 * (P + 2)
 # flop per step (Sunspot [4,5,1]): F_RW = 42 811, F_LGextra = 105 082
 F_STEP = 42811 + L_PROB * 105082
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# Chain burn-in before warm-up and timing (Langevin workloads).  The speculative schedules run faster the fewer steps a chain
+# accepts, and acceptance falls as the chains settle (Sunspot: 5 % over the first 1000 steps, 1.2 % around step 10 000), so the
+# throughput of an interval depends on where in the chain it lies.  The timed region therefore always starts after the
+# reference's own burn-in of a standard run (burn_in 0.5 x 10 000 samples per chain, REG:949,1004): whatever --steps and
+# --warmup are, the bench samples the phase whose samples the reference keeps.  DESIGN.md 8 lists the throughput of every
+# phase, start-up included.
+BURN_IN_INTERVALS = 50
 VALU_PEAK_TFLOPS = 157.3
 
 
@@ -224,7 +231,8 @@ def bench_other_config(a):
     train, test = d[dname + "_train"], d[dname + "_test"]
     Pw = topo[0] * topo[1] + topo[1] * topo[2] + topo[1] + topo[2]
     K, W = a.steps, a.warmup
-    S = (W + K + 1) * si + 2
+    B = BURN_IN_INTERVALS if (use_lg and not a.no_burn_in) else 0
+    S = (B + W + K + 1) * si + 2
     s = _lib.Sampler(device_id=int(os.environ.get("LOCAL_RANK", "0")), task=task, n_in=topo[0], n_hidden=topo[1], n_out=topo[2],
                      n_replicas_local=R, n_replicas_global=R, first_global_replica=0, n_samples=S, swap_interval=si,
                      pt_switch_step=switch_step(S), use_langevin=int(use_lg), waves_per_replica=a.waves, schedule=a.schedule,
@@ -245,7 +253,7 @@ def bench_other_config(a):
                 hi = s.steps_done() + 1
                 s.traces(drained, hi - drained, pos_w=False)
                 drained = hi
-    advance(W * si + (1 if task == 0 else 0))               # REG hands off after step k*si, CLS after step k*si - 1
+    advance((B + W) * si + (1 if task == 0 else 0))         # REG hands off after step k*si, CLS after step k*si - 1
     s.sync()
     s.kernel_time(reset=True)
     nsw0, tot0, _ = s.swap_stats()
@@ -312,6 +320,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rw", action="store_true", help="random-walk proposals only (extra data point)")
+    ap.add_argument("--no-burn-in", action="store_true", help="start warm-up and timing at chain step 0 (start-up transient included)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="sunspot64", choices=["sunspot64", "synthetic512", "iris16", "mackey64", "ionosphere256"],
                     help="sunspot64 = the BASELINE metric (default); synthetic512 = BASELINE config 5 shape (FNN 32-512-1, "
@@ -336,16 +345,17 @@ def main():
         return bench_other_config(a)
     train, test, data_desc = load_sunspot()
     si = SWAP_INTERVAL
-    S = (W + K + 1) * si + 2
-    R_global = R_PER_GPU * N
     use_lg = not a.rw
+    B = 0 if a.no_burn_in else BURN_IN_INTERVALS               # chain burn-in before warm-up (see BURN_IN_INTERVALS)
+    S = (B + W + K + 1) * si + 2
+    R_global = R_PER_GPU * N
 
     cpu = None
     if N == 1 and rank == 0 and not a.no_cpu_baseline:
         cpu = cpu_baseline(train, test)      # before the first HIP call: the pool forks
     if N == 1 and not a.force_dist:
         s = make_sampler(train, test, R_PER_GPU, R_global, 0, S, local_rank, use_lg, a.schedule, a.waves, a.groups)
-        s.run(W * si + 1)            # REG hands off after step i = k*si (REG:427): start the timed region on an interval boundary
+        s.run((B + W) * si + 1)      # REG hands off after step i = k*si (REG:427): start the timed region on an interval boundary
         s.sync()
         s.kernel_time(reset=True)
         nsw0, tot0, _ = s.swap_stats()
@@ -357,7 +367,7 @@ def main():
         nsw1, tot1, _ = s.swap_stats()
         accepted = s.state()["num_accepted"]
         steps_done = s.steps_done()
-        chain = dependent_chain(s, W, K, si) if rank == 0 else None
+        chain = dependent_chain(s, B + W, K, si) if rank == 0 else None
     else:
         chain = None
         import torch
@@ -368,7 +378,7 @@ def main():
         from ptnn_amd import distributed as dm
         s = make_sampler(train, test, R_PER_GPU, R_global, rank * R_PER_GPU, S, local_rank, use_lg, a.schedule, a.waves, a.groups)
         lad = dm.ShardedLadder(dm.DeviceShard(s, local_rank), rank, N, dist)
-        lad.run_intervals(W)
+        lad.run_intervals(B + W)
         s.sync()
         s.kernel_time(reset=True)
         nsw0, tot0, _ = s.swap_stats()
@@ -420,6 +430,7 @@ def main():
                                    + ("Langevin p=0.5 lr=0.1" if use_lg else "random-walk") +
                                    f", maxtemp {MAXTEMP}, swap every {si} MH steps; 1 bench step = 1 swap interval",
                        "replicas": R_global, "mh_steps_per_bench_step": si, "proposals": "langevin" if use_lg else "rw",
+                       "chain_burn_in_mh_steps": B * si, "first_timed_mh_step": (B + W) * si + 1, "last_timed_mh_step": (B + W + K) * si,
                        "schedule": a.schedule, "waves_per_replica": a.waves, "groups_per_replica": a.groups},
             "swap_accept_pct": 100.0 * (nsw1 - nsw0) / max(tot1 - tot0, 1),
             "mh_accept_pct": float(100.0 * np.mean(accepted) / max(steps_done, 1)),
