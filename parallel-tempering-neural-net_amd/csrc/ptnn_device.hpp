@@ -516,8 +516,9 @@ __device__ __forceinline__ void sgd_sweep(const float* __restrict__ w_in, float*
 template <int TASK, int I, int O>
 __device__ __forceinline__ void sgd_sweep_select(const float* w_in, float* w_out, const float* xy, const float* gdata, int Ntr,
                                                  int H, float lr) {
-    if (H <= 4) sgd_sweep<TASK, I, O, 2>(w_in, w_out, xy, gdata, Ntr, H, lr);
-    else if (H <= 8) sgd_sweep<TASK, I, O, 3>(w_in, w_out, xy, gdata, Ntr, H, lr);
+    // (no 4-lane variant: the packed schedule runs nets of <= 8 hidden units in 8-lane groups, and every schedule must
+    // commit the same chain bit for bit)
+    if (H <= 8) sgd_sweep<TASK, I, O, 3>(w_in, w_out, xy, gdata, Ntr, H, lr);
     else if (H <= 16) sgd_sweep<TASK, I, O, 4>(w_in, w_out, xy, gdata, Ntr, H, lr);
     else if (H <= 32) sgd_sweep<TASK, I, O, 5>(w_in, w_out, xy, gdata, Ntr, H, lr);
     else sgd_sweep<TASK, I, O, 6>(w_in, w_out, xy, gdata, Ntr, H, lr);
@@ -1519,6 +1520,12 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
                 }
             }
         }
+        // A wave without a step this round (k < K: the last rounds of an interval, or before the temperature switch) still
+        // publishes the tag of its slot: every group waits for EVERY slot's tag below, which keeps the groups within one round
+        // of each other.  Without it a group that publishes nothing for a few rounds is not waited for, can fall two rounds
+        // behind and then polls for a tag that has already been overwritten (seen once in ~25 suite runs as a hand-off timeout).
+        if (G > 1 && !active && lane == 0)
+            granule_store(xs + ((size_t)par * MAX_SLOTS + sidx) * SL_COUNT + (SL_COUNT - 1), epoch, 0.0f);
         STAMP(5);                                         // publish
         __syncthreads();
         STAMP(6);                                         // waiting for the slowest wave of this work-group
@@ -1531,6 +1538,11 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
                 float v;
                 ok = granule_wait(xs + ((size_t)par * MAX_SLOTS) * SL_COUNT + t, epoch, v) && ok;
                 slots[t] = v;
+            }
+            for (int s_ = k + tid; s_ < K; s_ += nthr) {     // heartbeats of the idle slots
+                if (s_ / NW == grp) continue;
+                float v;
+                ok = granule_wait(xs + ((size_t)par * MAX_SLOTS + s_) * SL_COUNT + (SL_COUNT - 1), epoch, v) && ok;
             }
             if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
         }

@@ -1,0 +1,69 @@
+"""Randomised differential test: for random nets / data subsets / ladders, every schedule must commit the same chain bit for bit
+(traces, swap log, counters).  A development aid (the fixed cases live in tests/test_gpu_parity.py)."""
+import os, sys, numpy as np
+R_ = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, R_); sys.path.insert(0, os.path.join(R_, "tests"))
+import parity
+from parity import orc
+
+
+def run(seed=0, ncase=30, verbose=True):
+  d = parity.datasets()
+  rng = np.random.default_rng(seed)
+  bad = 0
+  for case in range(ncase):
+      task = int(rng.integers(0, 2))
+      if task == 0:
+          name, I, O, mt, lr = str(rng.choice(["sunspot", "mackey", "lazer"])), 4, 1, 2, 0.1
+      else:
+          name, I, O, mt, lr = "iris", 4, 3, 10, 0.01
+      H = int(rng.integers(1, 17))
+      ntr = int(rng.integers(3, min(120, d[name + "_train"].shape[0])))
+      nte = int(rng.integers(2, 40))
+      train, test = d[name + "_train"][:ntr], d[name + "_test"][:nte]
+      R = int(rng.choice([2, 3, 4, 6, 8])); si = int(rng.integers(4, 15)); S = int(rng.integers(3, 7)) * si + int(rng.integers(0, 4)) + 2
+      lg = bool(rng.integers(0, 2)) or task == 0
+      seed = int(rng.integers(1, 10**6))
+      topo = (I, H, O); P = orc.num_param(topo)
+      tape = orc.PhiloxTape(seed)
+      w0 = (float(rng.choice([0.3, 1.0])) * np.stack([tape.w_init(r, P) for r in range(R)])).astype(np.float32)
+      T = np.array(orc.temperature_ladder(R, mt), dtype=np.float32)
+      # one-wave cooperative, every speculative layout and the packed schedule sum in the same (wave-local) order: bit-identical.
+      # The cooperative schedule on several waves adds the row likelihoods in another order: compared within round-off.
+      variants = [dict(schedule=1, waves=1), dict(schedule=2, waves=1, groups=1), dict(schedule=2, waves=4, groups=2),
+                  dict(schedule=2, waves=8, groups=1)]
+      if H <= 16:
+          variants.append(dict(schedule=3))
+      variants += [dict(schedule=1, waves=4), dict(schedule=0)]
+      ref = None
+      for v in variants:
+          try:
+              s = parity.make_sampler(task, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=lg, lr=lr, seed=seed, **v)
+          except Exception as e:
+              print("   skip", v, str(e)[:80]); continue
+          s.set_state(w0, T); s.run(-1); s.sync()
+          got = (s.traces(), s.swap_stats(), s.swap_log().copy())
+          s.close()
+          if ref is None:
+              ref, refv = got, v
+              continue
+          loose = v.get("schedule") in (0, 1) and v.get("waves", 0) != 1
+          if loose:
+              same_dec = np.array_equal(got[0]["accept"], ref[0]["accept"])
+              ok = (not same_dec) or (got[1] == ref[1] and np.array_equal(got[2], ref[2]) and
+                                      all(np.allclose(got[0][k], ref[0][k], rtol=2e-5, atol=2e-4, equal_nan=True) for k in ref[0]))
+          else:
+              ok = got[1] == ref[1] and np.array_equal(got[2], ref[2]) and all(np.array_equal(got[0][k], ref[0][k], equal_nan=True) for k in ref[0])
+          if not ok:
+              bad += 1
+              diffs = [k for k in ref[0] if not np.array_equal(got[0][k], ref[0][k], equal_nan=True)]
+              print(f"MISMATCH case {case}: task={task} {name} H={H} ntr={ntr} nte={nte} R={R} S={S} si={si} lg={lg} seed={seed} {refv} vs {v}: {diffs} stats {ref[1]} {got[1]}", flush=True)
+      if verbose:
+          print(f"case {case}: task={task} {name} H={H} ntr={ntr} R={R} S={S} si={si} lg={lg} ok", flush=True)
+  if verbose:
+      print("mismatching variants:", bad)
+  return bad
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 30)

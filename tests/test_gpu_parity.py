@@ -730,3 +730,15 @@ def test_checkpoint_resume_continues_bit_for_bit(case):
             assert np.array_equal(got, want[k]), (case, stop, k)
         assert np.array_equal(b.swap_log(), want_log) and b.swap_stats() == want_stats
         b.close()
+
+
+@pytest.mark.gpu
+def test_random_configurations_commit_the_same_chain_under_every_schedule():
+    """Randomised differential test (profiles/tools/stress_schedules.py, fixed seed): random hidden sizes 1..16, data subsets,
+    ladders, swap intervals and seeds; one-wave cooperative, three speculative layouts, packed and auto must agree bit for
+    bit (several-wave cooperative within round-off).  Found the 4-lane / 8-lane lane-group split of the SGD epoch."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("stress_schedules", os.path.join(parity.ROOT, "profiles", "tools", "stress_schedules.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(seed=2024, ncase=16, verbose=False) == 0
