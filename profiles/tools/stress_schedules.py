@@ -7,20 +7,34 @@ import parity
 from parity import orc
 
 
-def run(seed=0, ncase=30, verbose=True):
+def run(seed=0, ncase=30, verbose=True, shapes="timeseries+iris"):
   d = parity.datasets()
   rng = np.random.default_rng(seed)
   bad = 0
   for case in range(ncase):
-      task = int(rng.integers(0, 2))
-      if task == 0:
-          name, I, O, mt, lr = str(rng.choice(["sunspot", "mackey", "lazer"])), 4, 1, 2, 0.1
+      if shapes == "all":
+          # every compiled (task, I, O) on synthetic data of that shape, hidden layers up to 64 units (mid-sized ones take the
+          # matrix-core forward pass under the cooperative schedule)
+          task, I, O = [(0, 4, 1), (0, 5, 1), (0, 32, 1), (1, 4, 3), (1, 34, 2), (1, 9, 2), (1, 11, 10), (1, 20, 2), (1, 16, 10),
+                        (1, 6, 18)][int(rng.integers(0, 10))]
+          H = int(rng.choice([int(rng.integers(1, 17)), int(rng.integers(17, 65))]))
+          ntr, nte = int(rng.integers(3, 100)), int(rng.integers(2, 40))
+          X = rng.standard_normal((ntr + nte, I)) if task else rng.uniform(0, 1, (ntr + nte, I))
+          y = (np.argmax(X @ rng.standard_normal((I, O)), axis=1).astype(np.float64) if task
+               else np.clip(0.5 + 0.3 * np.sin(X.sum(axis=1)) + 0.02 * rng.standard_normal(ntr + nte), 0, 1))
+          data = np.hstack([X, y[:, None]])
+          train, test = data[:ntr], data[ntr:]
+          name, mt, lr = "synthetic", (10 if task else 2), (0.01 if task else 0.1)
       else:
-          name, I, O, mt, lr = "iris", 4, 3, 10, 0.01
-      H = int(rng.integers(1, 17))
-      ntr = int(rng.integers(3, min(120, d[name + "_train"].shape[0])))
-      nte = int(rng.integers(2, 40))
-      train, test = d[name + "_train"][:ntr], d[name + "_test"][:nte]
+          task = int(rng.integers(0, 2))
+          if task == 0:
+              name, I, O, mt, lr = str(rng.choice(["sunspot", "mackey", "lazer"])), 4, 1, 2, 0.1
+          else:
+              name, I, O, mt, lr = "iris", 4, 3, 10, 0.01
+          H = int(rng.integers(1, 17))
+          ntr = int(rng.integers(3, min(120, d[name + "_train"].shape[0])))
+          nte = int(rng.integers(2, 40))
+          train, test = d[name + "_train"][:ntr], d[name + "_test"][:nte]
       R = int(rng.choice([2, 3, 4, 6, 8])); si = int(rng.integers(4, 15)); S = int(rng.integers(3, 7)) * si + int(rng.integers(0, 4)) + 2
       lg = bool(rng.integers(0, 2)) or task == 0
       seed = int(rng.integers(1, 10**6))
@@ -28,13 +42,15 @@ def run(seed=0, ncase=30, verbose=True):
       tape = orc.PhiloxTape(seed)
       w0 = (float(rng.choice([0.3, 1.0])) * np.stack([tape.w_init(r, P) for r in range(R)])).astype(np.float32)
       T = np.array(orc.temperature_ladder(R, mt), dtype=np.float32)
-      # one-wave cooperative, every speculative layout and the packed schedule sum in the same (wave-local) order: bit-identical.
-      # The cooperative schedule on several waves adds the row likelihoods in another order: compared within round-off.
-      variants = [dict(schedule=1, waves=1), dict(schedule=2, waves=1, groups=1), dict(schedule=2, waves=4, groups=2),
-                  dict(schedule=2, waves=8, groups=1)]
+      # every speculative layout and the packed schedule sum in the same (wave-local) order: bit-identical (and so is the one-wave
+      # cooperative schedule for small nets).  The cooperative schedule on several waves adds the row likelihoods in another
+      # order, and for mid-sized nets takes the matrix-core forward pass: compared within round-off.
+      variants = [dict(schedule=2, waves=1, groups=1), dict(schedule=2, waves=4, groups=2), dict(schedule=2, waves=8, groups=1)]
       if H <= 16:
           variants.append(dict(schedule=3))
-      variants += [dict(schedule=1, waves=4), dict(schedule=0)]
+      if H < 24 or I < 6:
+          variants.append(dict(schedule=1, waves=1))
+      variants += [dict(schedule=1, waves=4), dict(schedule=1, waves=2), dict(schedule=0)]
       ref = None
       for v in variants:
           try:
@@ -44,10 +60,13 @@ def run(seed=0, ncase=30, verbose=True):
           s.set_state(w0, T); s.run(-1); s.sync()
           got = (s.traces(), s.swap_stats(), s.swap_log().copy())
           s.close()
+          if not all(np.isfinite(got[0][k]).all() for k in got[0]):
+              bad += 1
+              print(f"NON-FINITE case {case}: task={task} {name} topo={topo} ntr={ntr} R={R} S={S} si={si} lg={lg} seed={seed} {v}", flush=True)
           if ref is None:
               ref, refv = got, v
               continue
-          loose = v.get("schedule") in (0, 1) and v.get("waves", 0) != 1
+          loose = v.get("schedule") in (0, 1) and (v.get("waves", 0) != 1 or (H >= 24 and I >= 6))
           if loose:
               same_dec = np.array_equal(got[0]["accept"], ref[0]["accept"])
               ok = (not same_dec) or (got[1] == ref[1] and np.array_equal(got[2], ref[2]) and
@@ -66,4 +85,5 @@ def run(seed=0, ncase=30, verbose=True):
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 30)
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 30,
+        shapes=sys.argv[3] if len(sys.argv) > 3 else "timeseries+iris")
