@@ -7,7 +7,7 @@ import parity
 from parity import orc
 
 
-def run(seed=0, ncase=30, verbose=True, shapes="timeseries+iris"):
+def run(seed=0, ncase=30, verbose=True, shapes="timeseries+iris", oracle=False):
   d = parity.datasets()
   rng = np.random.default_rng(seed)
   bad = 0
@@ -65,6 +65,21 @@ def run(seed=0, ncase=30, verbose=True, shapes="timeseries+iris"):
               print(f"NON-FINITE case {case}: task={task} {name} topo={topo} ntr={ntr} R={R} S={S} si={si} lg={lg} seed={seed} {v}", flush=True)
           if ref is None:
               ref, refv = got, v
+              if oracle:                                  # the reference variant against the float64 oracle on the same tape
+                  pt = orc.PTOracle(task, topo, train, test, R, mt, R * S, si, use_lg=lg, l_prob=0.5, lr=lr, seed=seed)
+                  for rep, w in zip(pt.replicas, w0):
+                      rep.__init__(task, topo, pt.train, pt.test, w.astype(np.float64), rep.T, S, lg, 0.5, lr, pt.tape, rep.gid)
+                  o = parity.OracleRun(pt).run()
+                  try:
+                      assert got[1][2] == pt.rounds_done and got[1][1] == pt.total_swap_proposals
+                      for r in range(R):
+                          first = parity.compare_replica_trace(got[0], r, pt.replicas[r], f"case {case} r{r} ")
+                          if first is not None:
+                              i_ = first - 2
+                              assert abs(o.logalpha[r, i_] - o.logu[r, i_]) < 0.05, (r, i_, o.logalpha[r, i_], o.logu[r, i_])
+                  except AssertionError as e:
+                      bad += 1
+                      print(f"ORACLE MISMATCH case {case}: task={task} {name} topo={topo} ntr={ntr} nte={nte} R={R} S={S} si={si} lg={lg} seed={seed}: {str(e)[:300]}", flush=True)
               continue
           loose = v.get("schedule") in (0, 1) and (v.get("waves", 0) != 1 or (H >= 24 and I >= 6))
           if loose:
@@ -86,4 +101,4 @@ def run(seed=0, ncase=30, verbose=True, shapes="timeseries+iris"):
 
 if __name__ == "__main__":
     run(int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 30,
-        shapes=sys.argv[3] if len(sys.argv) > 3 else "timeseries+iris")
+        shapes=sys.argv[3] if len(sys.argv) > 3 else "timeseries+iris", oracle=len(sys.argv) > 4)
