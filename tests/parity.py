@@ -42,12 +42,14 @@ def make_sampler(task, topo, train, test, *, R_local, R_global, first, S, si, us
     return s
 
 
-def compare_replica_trace(tr, r, rep, label=""):
+def compare_replica_trace(tr, r, rep, label="", limit=None):
     """tr: Sampler.traces() dict; rep: oracle Replica run over the same tape.  Returns the first step whose MH
-    decision differs (or None).  Everything before it must agree within the fp32 tolerances."""
-    S = rep.S
-    acc_g = tr["accept"][r].astype(np.int64)
-    acc_o = rep.accept_list.astype(np.int64)
+    decision differs (or None).  Everything before it must agree within the fp32 tolerances.  `limit`: compare only the first
+    `limit` rows (the chains are known to part there for another reason, e.g. a near-tie decision in another replica whose
+    state arrived through an exchange)."""
+    S = rep.S if limit is None else min(rep.S, int(limit))
+    acc_g = tr["accept"][r].astype(np.int64)[:S]
+    acc_o = rep.accept_list.astype(np.int64)[:S]
     diff = np.nonzero(acc_g != acc_o)[0]
     first = int(diff[0]) if diff.size else None          # index into accept_list: decision of step first-2 differed
     upto = S if first is None else first - 1             # rows [0, upto) were produced by identical decisions
