@@ -47,7 +47,8 @@ def run(seed=0, ncase=30, verbose=True, shapes="timeseries+iris", oracle=False):
       # every speculative layout and the packed schedule sum in the same (wave-local) order: bit-identical (and so is the one-wave
       # cooperative schedule for small nets).  The cooperative schedule on several waves adds the row likelihoods in another
       # order, and for mid-sized nets takes the matrix-core forward pass: compared within round-off.
-      variants = [dict(schedule=2, waves=1, groups=1), dict(schedule=2, waves=4, groups=2), dict(schedule=2, waves=8, groups=1)]
+      variants = [dict(schedule=2, waves=1, groups=1), dict(schedule=2, waves=4, groups=2), dict(schedule=2, waves=8, groups=1),
+                  dict(schedule=2, waves=4, groups=4), dict(schedule=2, waves=2, groups=8)]
       if H > 64:
           variants = [dict(schedule=0), dict(schedule=1)]
       if H <= 16:
