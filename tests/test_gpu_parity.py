@@ -746,3 +746,17 @@ def test_random_configurations_commit_the_same_chain_under_every_schedule():
     # every compiled shape on synthetic data, hidden layers up to 64 units: speculative layouts bit-identical, cooperative
     # (several waves / matrix-core forward pass) within round-off, nothing non-finite
     assert mod.run(seed=7, ncase=14, verbose=False, shapes="all", oracle=True) == 0
+
+
+@pytest.mark.gpu
+def test_sharded_ladder_two_ranks_on_one_gpu():
+    """The multi-GPU driver with a REAL cross-process exchange on real device buffers: two ranks share the one GPU of the box
+    and talk over gloo (RCCL refuses two ranks on one device).  Gathered exchange, point-to-point exchange and the gathered
+    exchange under swap_rule 1 must reproduce the single-process device run bit for bit (tests/dist_device_check2.py)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "dist_device_check2.py")], capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    for line in ("OK gather rule 0", "OK p2p rule 0", "OK gather rule 1"):
+        assert line in r.stdout
