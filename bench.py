@@ -373,8 +373,16 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # PTNN_BENCH_REHEARSE=1: every rank on GPU 0, gloo transport -- lets a one-GPU box run the whole N > 1 code path
+        # (RCCL refuses two ranks on one device); the figure it prints is not a measurement of anything
+        rehearse = os.environ.get("PTNN_BENCH_REHEARSE", "0") == "1"
+        if rehearse:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         from ptnn_amd import distributed as dm
         s = make_sampler(train, test, R_PER_GPU, R_global, rank * R_PER_GPU, S, local_rank, use_lg, a.schedule, a.waves, a.groups)
         lad = dm.ShardedLadder(dm.DeviceShard(s, local_rank), rank, N, dist)
@@ -390,7 +398,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
         dt_local = time.perf_counter() - t0
-        t = torch.tensor([dt_local], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt_local], device="cpu" if rehearse else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         launches, kms = s.kernel_time()
