@@ -357,7 +357,7 @@ def main():
         s = make_sampler(train, test, R_PER_GPU, R_global, 0, S, local_rank, use_lg, a.schedule, a.waves, a.groups)
         s.run((B + W) * si + 1)      # REG hands off after step i = k*si (REG:427): start the timed region on an interval boundary
         s.sync()
-        s.kernel_time(reset=True)
+        pre_launches, pre_ms = s.kernel_time(reset=True)     # burn-in + warm-up launches (rocprofv3 --stats averages them in)
         nsw0, tot0, _ = s.swap_stats()
         t0 = time.perf_counter()
         s.run(K * si)
@@ -388,7 +388,7 @@ def main():
         lad = dm.ShardedLadder(dm.DeviceShard(s, local_rank), rank, N, dist)
         lad.run_intervals(B + W)
         s.sync()
-        s.kernel_time(reset=True)
+        pre_launches, pre_ms = s.kernel_time(reset=True)
         nsw0, tot0, _ = s.swap_stats()
         dist.barrier()
         torch.cuda.synchronize()
@@ -445,6 +445,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kname, "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
+                         "avg_launch_ms_all_launches": (kms + pre_ms) / max(launches + pre_launches, 1),
+                         "all_launches": launches + pre_launches,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "valu_tflops": flops_per_launch / avg_launch_s / 1e12 if launches else 0.0,
                          "valu_frac": (flops_per_launch / avg_launch_s / 1e12) / VALU_PEAK_TFLOPS if launches else 0.0,
