@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unordered_map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -230,6 +232,21 @@ int launch_swap(ptnn_handle* h, bool phantom, int mode, bool want_src) {
     return 0;
 }
 
+// The dynamic-LDS ceiling of a kernel is a property of the function, shared by every handle of the process: only ever raise
+// it, so that a handle created later with a smaller data set does not pull it below what an earlier one launches with.
+int raise_lds_limit(const void* func, size_t bytes) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> limit;
+    if (bytes <= 64 * 1024) return 0;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& cur = limit[func];
+    if (bytes > cur) {
+        HIP_TRY(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        cur = bytes;
+    }
+    return 0;
+}
+
 int check_ready(ptnn_handle* h) {
     if (!h) return fail(-1, "null handle");
     if (!h->have_data) return fail(-1, "ptnn_set_data has not been called");
@@ -399,10 +416,8 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         HIP_TRY(hipMalloc(&h->d_data, packed.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(h->d_data, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
         if (!h->d_wide_scratch) HIP_TRY(hipMalloc(&h->d_wide_scratch, (size_t)h->cfg.n_replicas_local * 3 * h->PS * sizeof(float)));
-        if (lds > 64 * 1024) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->shape->seg_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->shape->model_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(h->shape->seg_wide), lds)) return rc;
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(h->shape->model_wide), lds)) return rc;
         h->have_data = true;
         return 0;
     }
@@ -500,11 +515,9 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
     if (h->d_data) { HIP_TRY(hipFree(h->d_data)); h->d_data = nullptr; }
     HIP_TRY(hipMalloc(&h->d_data, packed.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(h->d_data, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (h->seg_lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg)),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->seg_lds));
-    if (h->model_lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(h->shape->model), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->model_lds));
+    if (int rc = raise_lds_limit(reinterpret_cast<const void*>(h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg)),
+                                 h->seg_lds)) return rc;
+    if (int rc = raise_lds_limit(reinterpret_cast<const void*>(h->shape->model), h->model_lds)) return rc;
     h->have_data = true;
     return 0;
 }

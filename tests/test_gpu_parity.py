@@ -760,3 +760,28 @@ def test_sharded_ladder_two_ranks_on_one_gpu():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     for line in ("OK gather rule 0", "OK p2p rule 0", "OK gather rule 1"):
         assert line in r.stdout
+
+
+@pytest.mark.gpu
+def test_two_live_handles_with_different_lds_needs():
+    """The dynamic-LDS ceiling belongs to the kernel function, not to a handle: a second handle with a smaller data set must
+    not lower it under what the first one launches with."""
+    d = ds()
+    from ptnn_amd import ladder, philox
+    topo, R, S, si = (34, 50, 2), 2, 24, 6
+    Pw = orc.num_param(topo)
+
+    def make(train, test):
+        s_ = parity.make_sampler(orc.TASK_CLS, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=False, lr=0.01,
+                                 seed=5, schedule=1)
+        s_.set_state(np.stack([philox.initial_weights(5, r, Pw) for r in range(R)]), ladder.temperatures(R, 10))
+        return s_
+    big = make(d["ions_train"], d["ions_test"])                    # ~150 KB of LDS per work-group
+    small = make(d["ions_train"][:150], d["ions_test"][:60])        # ~100 KB: created later, same kernels
+    small.run(-1)
+    small.sync()
+    big.run(-1)
+    big.sync()
+    assert np.isfinite(big.traces()["likeh"]).all() and np.isfinite(small.traces()["likeh"]).all()
+    big.close()
+    small.close()
