@@ -785,3 +785,33 @@ def test_two_live_handles_with_different_lds_needs():
     assert np.isfinite(big.traces()["likeh"]).all() and np.isfinite(small.traces()["likeh"]).all()
     big.close()
     small.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,topo", [("sunspot", (4, 5, 1)), ("mackey", (4, 10, 1))])
+def test_chains_do_not_depend_on_occupancy(name, topo):
+    """The hand-scheduled SGD rows honour their hazard slots by construction, not by luck of timing: 1024 independent chains
+    (no swap round) run as 1024 work-groups on the GPU -- several waves per SIMD interleaving -- and again in batches of 128
+    (one work-group per CU, one wave per SIMD) must give the same rows bit for bit."""
+    d = ds()
+    from ptnn_amd import ladder, philox
+    Rg, S, si, seed = 1024, 60, 1000, 9
+    Pw = orc.num_param(topo)
+    T = ladder.temperatures(Rg, 2)
+    W0 = np.stack([philox.initial_weights(seed, r, Pw) for r in range(Rg)])
+
+    def run(Rl, first):
+        s = parity.make_sampler(0, topo, d[name + "_train"], d[name + "_test"], R_local=Rl, R_global=Rg, first=first, S=S, si=si,
+                                use_lg=True, lr=0.1, seed=seed, schedule=3)
+        s.set_state(W0[first:first + Rl], T[first:first + Rl])
+        while s.steps_done() < S - 1:
+            s.run_segment()
+        s.sync()
+        tr = s.traces()
+        s.close()
+        return tr
+    big = run(Rg, 0)
+    for b in range(0, Rg, 128):
+        small = run(128, b)
+        for k in big:
+            assert np.array_equal(big[k][b:b + 128], small[k]), (b, k)
