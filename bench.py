@@ -368,8 +368,20 @@ def main():
         accepted = s.state()["num_accepted"]
         steps_done = s.steps_done()
         chain = dependent_chain(s, B + W, K, si) if rank == 0 else None
+        # beside it, untimed by the contract: a whole run of the reference's standard length from the chain start (start-up
+        # transient and burn-in included), so that the line also says what a user's run_chains() sees end to end
+        whole = None
+        if rank == 0 and B > 0:
+            s2 = make_sampler(train, test, R_PER_GPU, R_global, 0, 100 * si + 2, local_rank, use_lg, a.schedule, a.waves, a.groups)
+            s2.run(1)
+            s2.sync()
+            tw = time.perf_counter()
+            s2.run(100 * si)
+            s2.sync()
+            whole = {"value": R_global * 100 * si / (time.perf_counter() - tw), "unit": "samples/s", "mh_steps": "1..%d" % (100 * si)}
+            s2.close()
     else:
-        chain = None
+        chain = whole = None
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -454,6 +466,8 @@ def main():
                          "note": "instruction-issue bound by construction (sequential SGD rows, AI 627 flop/B); the HBM "
                                  "fraction is reported because BASELINE.json asks for it"},
         }
+        if whole is not None:
+            out["from_chain_start"] = whole
         if chain is not None:
             chain["frac_of_chain_floor"] = chain["chain_floor_ms_per_interval"] / (avg_launch_s * 1e3) if launches else None
             out["dependent_chain"] = chain
