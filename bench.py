@@ -320,6 +320,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rw", action="store_true", help="random-walk proposals only (extra data point)")
+    ap.add_argument("--no-whole-run", action="store_true", help="skip the extra whole-run leg (from_chain_start); used under rocprofv3 so "
+                    "that its per-kernel averages cover the launches of the measured sampler only")
     ap.add_argument("--no-burn-in", action="store_true", help="start warm-up and timing at chain step 0 (start-up transient included)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="sunspot64", choices=["sunspot64", "synthetic512", "iris16", "mackey64", "ionosphere256"],
@@ -371,7 +373,7 @@ def main():
         # beside it, untimed by the contract: a whole run of the reference's standard length from the chain start (start-up
         # transient and burn-in included), so that the line also says what a user's run_chains() sees end to end
         whole = None
-        if rank == 0 and B > 0:
+        if rank == 0 and B > 0 and not a.no_whole_run:
             s2 = make_sampler(train, test, R_PER_GPU, R_global, 0, 100 * si + 2, local_rank, use_lg, a.schedule, a.waves, a.groups)
             s2.run(1)
             s2.sync()
