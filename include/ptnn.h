@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PTNN_ABI_VERSION 1
+#define PTNN_ABI_VERSION 2
 
 #define PTNN_TASK_REG 0 /* Gaussian likelihood + eta = log tau^2 (REG) */
 #define PTNN_TASK_CLS 1 /* multinomial likelihood on softmax-of-sigmoid outputs (CLS) */
@@ -96,14 +96,64 @@ int ptnn_set_ladder(ptnn_handle *h, const float *temperatures_global);
 
 /* Advances every local replica by up to n_steps MH steps (ptReplica.run loop body, REG:313-437) and performs the
  * swap rounds that fall inside (ParallelTempering.swap_procedure + round loop, REG:659-690, 719-752), including the
- * phantom last round when the chain end is reached.  n_steps < 0 = run to the end.  Single-GPU only
- * (n_replicas_local == n_replicas_global).  Asynchronous: returns once the work is queued; ptnn_sync waits. */
+ * phantom last round when the chain end is reached.  n_steps < 0 = run to the end.  A handle that owns only a
+ * block of the ladder (n_replicas_local < n_replicas_global) needs a communicator (ptnn_comm_init / ptnn_comm_init_host)
+ * and every rank calls ptnn_run with the same n_steps: the swap rounds then exchange through it.  Asynchronous: returns
+ * once the work is queued (the "boundary" exchange waits once per swap round for the permutation); ptnn_sync waits. */
 int ptnn_run(ptnn_handle *h, int n_steps);
 int ptnn_sync(ptnn_handle *h);
 /* number of MH steps queued so far (0 .. S-1) */
 int ptnn_steps_done(ptnn_handle *h);
 
-/* ---- sharded ladder (one handle per GPU): the pieces of one swap round, driven by the host between collectives ---- */
+/* ---- sharded ladder: one handle per GPU, each owning a contiguous, equally sized block of the temperature ladder ----
+ * Replaces the reference's star topology (every replica ships [w, eta, L, T] to the parent through a multiprocessing.Queue
+ * each round and blocks on an Event, REG:427-437 <-> 694-759).  Replicas are independent for a swap interval, so the only
+ * exchange step is the swap round; every rank computes the identical cascade (uniforms are Philox(seed; round, pair)), hence
+ * identical chains for every GPU count.  Two exchanges (ptnn_comm_set_mode):
+ *   PTNN_XCHG_GATHER    one in-place all-gather per round of the exchange rows {(w, eta), cached langevin_gradient, L} of all
+ *                       replicas (R_global x (8 P + 16) bytes), cascade + row copy on the device, NO host wait: pack kernel,
+ *                       collective and swap kernel are queued on the handle's stream behind the segment kernel.
+ *   PTNN_XCHG_BOUNDARY  all-gather of the R_global posted scalars L (4 R bytes), cascade on the device, permutation to the
+ *                       host (one wait), then ONE grouped send/recv of the rows that cross a GPU boundary: per GPU at most one
+ *                       (w, eta) row arrives from below (the carried state; its source may be several GPUs down: xGMI is a
+ *                       full mesh, it goes there directly), at most one from the GPU above, and at most one leaves each way
+ *                        -- 4 (P + 1) bytes each.  swap_rule 0 only.
+ *   PTNN_XCHG_AUTO      GATHER while the gathered buffer is <= 4 MiB (every BASELINE net but the 32-512-1 one), else BOUNDARY.
+ */
+#define PTNN_XCHG_AUTO 0
+#define PTNN_XCHG_GATHER 1
+#define PTNN_XCHG_BOUNDARY 2
+
+/* RCCL transport (xGMI on one node).  Rank 0 obtains a unique id (ncclGetUniqueId; 128 bytes) and hands it to every rank by
+ * whatever rendezvous launched them; every rank then calls ptnn_comm_init(h, id, 128, rank, nranks) with
+ * rank == first_global_replica / n_replicas_local (ncclCommInitRank on the handle's device: collective, blocks until all
+ * ranks have joined).  librccl.so is loaded on the first call (dlopen; $PTNN_RCCL_LIBRARY overrides the path), so single-GPU
+ * users never load it.  Collectives run on the handle's own stream. */
+int ptnn_comm_unique_id(void *id_out, int nbytes);
+int ptnn_comm_init(ptnn_handle *h, const void *unique_id, int nbytes, int rank, int nranks);
+
+/* Host-staged transport: the library stages through pinned host memory and calls back.  For fabrics other than RCCL and
+ * for tests (RCCL refuses two ranks on one device; a one-GPU box rehearses the N > 1 path with this).
+ *   all_gather(ctx, buf, bytes_per_rank): buf holds nranks blocks, this rank's block is filled; fill the others. 0 = OK.
+ *   send_recv(ctx, n, peer[n], is_send[n], buf[n], bytes): n messages of `bytes` bytes each, in an order both ends of
+ *     every pair agree on (ascending global destination slot); complete all of them before returning.  0 = OK. */
+typedef int (*ptnn_all_gather_fn)(void *ctx, void *buf, int64_t bytes_per_rank);
+typedef int (*ptnn_send_recv_fn)(void *ctx, int n, const int32_t *peer, const int32_t *is_send, void *const *buf, int64_t bytes);
+int ptnn_comm_init_host(ptnn_handle *h, int rank, int nranks, ptnn_all_gather_fn all_gather, ptnn_send_recv_fn send_recv, void *ctx);
+
+int ptnn_comm_set_mode(ptnn_handle *h, int mode);
+/* what crossed GPU boundaries so far: payload bytes this rank sent and received, swap rounds exchanged, the mode in use */
+int ptnn_comm_stats(ptnn_handle *h, int64_t *bytes_sent, int64_t *bytes_received, int64_t *rounds, int32_t *mode);
+/* releases the communicator (ncclCommDestroy); ptnn_destroy does it too */
+int ptnn_comm_finalize(ptnn_handle *h);
+
+/* Pure host function (no GPU): which rows rank `rank` receives and sends for the permutation src[R_global] of one round
+ * (slot k receives the state of slot src[k]) when every rank owns n_local consecutive slots.  Messages are listed in ascending
+ * global destination slot.  msg[4 * m + {0,1,2,3}] = {is_send, peer rank, local row (destination row of a receive, source row
+ * of a send), global destination slot}.  Returns the number of messages (<= max_msgs) or negative. */
+int ptnn_route(const int32_t *src, int n_global, int n_local, int rank, int32_t *msg, int max_msgs);
+
+/* ---- the pieces of one swap round, for callers that drive the exchange themselves ---- */
 /* queue MH steps up to and including the next hand-off step (or the chain end); returns in *handoff 1 when a swap
  * round is due after it, 2 when the due round is the phantom end-of-chain round, 0 otherwise.  Asynchronous. */
 int ptnn_run_segment(ptnn_handle *h, int *handoff);
@@ -173,6 +223,13 @@ int ptnn_evaluate(ptnn_handle *h, const float *w, const float *tau_sq, int n, fl
 int ptnn_langevin_gradient(ptnn_handle *h, const float *w_in, int n, float *w_out);
 /* the random tape of MH step `step` of global replica `replica`: noise [P] normals, scal[3] = {lx, u, n_eta} */
 int ptnn_tape(ptnn_handle *h, int replica, int step, float *noise, float *scal);
+
+/* What this handle will launch, as one line of JSON text written into buf (returns its length, or negative): the segment
+ * kernel the schedule resolved to for this topology / data set / replica count, its grid, block and dynamic LDS size, the
+ * work-groups per replica and speculative slots per round, and what the runtime reports for it (blocks per CU from
+ * hipOccupancyMaxActiveBlocksPerMultiprocessor, VGPRs, scratch bytes).  After ptnn_set_data.  The reference has no
+ * counterpart (its "schedule" is one OS process per chain, REG:709-712); bench.py and the profiles name kernels with it. */
+int ptnn_describe(ptnn_handle *h, char *buf, int nbytes);
 
 /* timing of the dominant kernel, measured with HIP events on the library's stream around every segment launch
  * since the last reset: launches, total milliseconds */

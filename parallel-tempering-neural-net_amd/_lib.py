@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 1
+ABI_VERSION = 2
 TASK_REG, TASK_CLS = 0, 1
 
 
@@ -36,6 +36,12 @@ _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
 _vpp = C.POINTER(C.c_void_p)
 
+# callbacks of the host-staged transport (ptnn_all_gather_fn / ptnn_send_recv_fn of include/ptnn.h)
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+SEND_RECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _ip, _ip, _vpp, C.c_int64)
+XCHG_AUTO, XCHG_GATHER, XCHG_BOUNDARY = 0, 1, 2
+UNIQUE_ID_BYTES = 128
+
 # every symbol include/ptnn.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "ptnn_abi_version": (C.c_int, []),
@@ -49,6 +55,13 @@ SYMBOLS = {
     "ptnn_run": (C.c_int, [C.c_void_p, C.c_int]),
     "ptnn_sync": (C.c_int, [C.c_void_p]),
     "ptnn_steps_done": (C.c_int, [C.c_void_p]),
+    "ptnn_comm_unique_id": (C.c_int, [C.c_void_p, C.c_int]),
+    "ptnn_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "ptnn_comm_init_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ptnn_comm_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "ptnn_comm_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _ip]),
+    "ptnn_comm_finalize": (C.c_int, [C.c_void_p]),
+    "ptnn_route": (C.c_int, [_ip, C.c_int, C.c_int, C.c_int, _ip, C.c_int]),
     "ptnn_run_segment": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "ptnn_swap_L_ptr": (C.c_int, [C.c_void_p, C.c_int, _vpp]),
     "ptnn_swap_set_L": (C.c_int, [C.c_void_p, C.c_int, _fp]),
@@ -70,6 +83,7 @@ SYMBOLS = {
     "ptnn_evaluate": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, _fp]),
     "ptnn_langevin_gradient": (C.c_int, [C.c_void_p, _fp, C.c_int, _fp]),
     "ptnn_tape": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp]),
+    "ptnn_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "ptnn_kernel_time": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "ptnn_debug_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "ptnn_text_round": (C.c_int, [C.POINTER(C.c_double), C.c_int64, C.c_char_p]),
@@ -102,6 +116,29 @@ def _f32(a):
 
 def _ptr(a, typ=_fp):
     return None if a is None else a.ctypes.data_as(typ)
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through libptnn (loads librccl.so): 128 bytes rank 0 hands to every rank."""
+    lib = load_library()
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    if lib.ptnn_comm_unique_id(buf, UNIQUE_ID_BYTES) < 0:
+        raise PtnnError(lib.ptnn_last_error().decode())
+    return buf.raw
+
+
+def route(src, n_local, rank):
+    """ptnn_route: the rows `rank` receives / sends for the permutation src -> (recvs, sends), each a list of
+    (local row, peer rank, global destination slot) in ascending global destination slot.  Pure host function."""
+    lib = load_library()
+    src = np.ascontiguousarray(src, dtype=np.int32)
+    msg = np.empty((src.size + 1, 4), np.int32)
+    n = lib.ptnn_route(_ptr(src, _ip), src.size, int(n_local), int(rank), _ptr(msg, _ip), msg.shape[0])
+    if n < 0:
+        raise PtnnError(lib.ptnn_last_error().decode())
+    recvs = [(int(m[2]), int(m[1]), int(m[3])) for m in msg[:n] if m[0] == 0]
+    sends = [(int(m[2]), int(m[1]), int(m[3])) for m in msg[:n] if m[0] == 1]
+    return recvs, sends
 
 
 class Sampler:
@@ -164,6 +201,49 @@ class Sampler:
 
     def steps_done(self):
         return self.lib.ptnn_steps_done(self.h)
+
+    # ---- sharded ladder: communicators ----
+    def comm_init(self, unique_id, rank, nranks):
+        """RCCL communicator over the ranks that own the blocks of this ladder (collective: every rank calls it)."""
+        self._check(self.lib.ptnn_comm_init(self.h, unique_id, len(unique_id), int(rank), int(nranks)))
+
+    def comm_init_host(self, rank, nranks, all_gather, send_recv):
+        """Host-staged transport: all_gather(buf: uint8 array [nranks, bytes_per_rank]) fills the other ranks' blocks in place;
+        send_recv(msgs: list of (peer, is_send, uint8 array)) completes all messages.  Exceptions become an error return."""
+        def _ag(ctx, buf, nbytes):
+            try:
+                arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(int(nranks), int(nbytes)))
+                all_gather(arr)
+                return 0
+            except Exception:                                   # noqa: BLE001 -- must not unwind through C
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        def _sr(ctx, n, peer, is_send, bufs, nbytes):
+            try:
+                msgs = [(int(peer[k]), bool(is_send[k]),
+                         np.ctypeslib.as_array(C.cast(bufs[k], C.POINTER(C.c_uint8)), shape=(int(nbytes),))) for k in range(n)]
+                send_recv(msgs)
+                return 0
+            except Exception:                                   # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._callbacks = (ALL_GATHER_FN(_ag), SEND_RECV_FN(_sr))      # keep them alive as long as the handle
+        self._check(self.lib.ptnn_comm_init_host(self.h, int(rank), int(nranks), C.cast(self._callbacks[0], C.c_void_p),
+                                                 C.cast(self._callbacks[1], C.c_void_p), None))
+
+    def comm_set_mode(self, mode):
+        self._check(self.lib.ptnn_comm_set_mode(self.h, int(mode)))
+
+    def comm_stats(self):
+        a, b, r, m = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        self._check(self.lib.ptnn_comm_stats(self.h, C.byref(a), C.byref(b), C.byref(r), C.byref(m)))
+        return dict(bytes_sent=a.value, bytes_received=b.value, rounds=r.value, mode={0: "none", 1: "gather", 2: "boundary"}[m.value])
+
+    def comm_finalize(self):
+        self._check(self.lib.ptnn_comm_finalize(self.h))
 
     def run_segment(self):
         ho = C.c_int(0)
@@ -284,6 +364,13 @@ class Sampler:
         buf = (C.c_uint64 * 160)()
         self._check(self.lib.ptnn_debug_stamps(self.h, buf))
         return list(buf)
+
+    def describe(self):
+        """What the handle launches (kernel, grid, LDS, occupancy) as a dict; see ptnn_describe."""
+        import json
+        buf = C.create_string_buffer(2048)
+        self._check(self.lib.ptnn_describe(self.h, buf, len(buf)))
+        return json.loads(buf.value.decode())
 
     def kernel_time(self, reset=False):
         n, ms = C.c_int64(), C.c_double()

@@ -4,6 +4,7 @@
 // parent's swap loop (REG = multicore-pt-regression/pt_timeseries_regression.py:223-485, 659-771;
 // CLS = multicore-pt-classification/pt_classification.py:232-494, 668-776).
 #include "ptnn_shapes.hpp"
+#include "ptnn_comm.hpp"
 #include "../../include/ptnn.h"
 
 #include <algorithm>
@@ -79,6 +80,7 @@ struct ptnn_handle {
     int Npad = 0;
     bool fw_mfma = false;           // cooperative schedule: forward pass on the matrix cores (24 <= H <= 64, I >= 6)
     int groups = 1;                 // work-groups (CUs) per replica in the speculative schedule
+    int blocks_per_cu = 0;          // occupancy of the segment kernel as the runtime reports it (0 = not queried)
     unsigned epoch_base = 0;
     int num_cus = 0;
     unsigned long long *d_xslots = nullptr, *d_xw = nullptr;
@@ -109,6 +111,9 @@ struct ptnn_handle {
     int* h_src = nullptr;
     float* d_xchg = nullptr;                                // [R_global][XS] exchange rows of the gathered sharding mode                                   // pinned staging for the permutation of a round (sharded ladder)
     long long* d_counters = nullptr;
+    // sharded ladder: transport and what a swap round moves through it
+    Comm comm;
+    std::vector<RowMsg> route;
     // kernel timing (HIP events on our stream)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing;
     size_t timing_used = 0;
@@ -256,45 +261,9 @@ int check_ready(ptnn_handle* h) {
 
 }  // namespace
 
-extern "C" {
-
-int ptnn_abi_version(void) { return PTNN_ABI_VERSION; }
-const char* ptnn_last_error(void) { return g_err.c_str(); }
-
-int ptnn_supports(int task, int n_in, int n_hidden, int n_out) {
-    return (find_shape(task, n_in, n_out) != nullptr && n_hidden >= 1 && n_hidden <= MAX_HIDDEN) ? 1 : 0;
-}
-
-int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
-    if (!cfg || !out) return fail(-1, "null argument");
-    if (cfg->struct_bytes != (int32_t)sizeof(ptnn_config))
-        return fail(-1, "ptnn_config size mismatch: caller %d, library %d", cfg->struct_bytes, (int)sizeof(ptnn_config));
-    if (cfg->task != PTNN_TASK_REG && cfg->task != PTNN_TASK_CLS) return fail(-1, "unknown task %d", cfg->task);
-    if (cfg->n_in < 1 || cfg->n_hidden < 1 || cfg->n_out < 1) return fail(-1, "bad topology");
-    if (cfg->task == PTNN_TASK_REG && cfg->n_out != 1) return fail(-1, "regression needs n_out == 1");
-    const Shape* sh = find_shape(cfg->task, cfg->n_in, cfg->n_out);
-    if (!sh)
-        return fail(-3, "no gfx950 kernel compiled for task=%d n_in=%d n_out=%d: add it to PTNN_SHAPES and rebuild",
-                    cfg->task, cfg->n_in, cfg->n_out);
-    if (cfg->n_hidden > MAX_HIDDEN)
-        return fail(-3, "n_hidden=%d > %d: the SGD sweep holds one hidden unit per thread of one work-group", cfg->n_hidden, MAX_HIDDEN);
-    if (cfg->n_replicas_local < 1 || cfg->n_replicas_global < 2 || cfg->first_global_replica < 0 ||
-        cfg->first_global_replica + cfg->n_replicas_local > cfg->n_replicas_global)
-        return fail(-1, "bad replica partition: local=%d global=%d first=%d", cfg->n_replicas_local,
-                    cfg->n_replicas_global, cfg->first_global_replica);
-    if (cfg->n_samples < 2) return fail(-1, "n_samples must be >= 2");
-    if (cfg->swap_interval < 1) return fail(-1, "swap_interval must be >= 1 (the reference divides by it, REG:427)");
-    if (cfg->swap_rule != 0 && cfg->swap_rule != 1) return fail(-1, "swap_rule must be 0 (reference cascade) or 1 (even/odd Metropolis)");
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev));
-    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(-2, "device %d not present (%d devices)", cfg->device_id, ndev);
-    HIP_TRY(hipSetDevice(cfg->device_id));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device_id));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(-2, "device %d is %s; libptnn is built for gfx950 only", cfg->device_id, prop.gcnArchName);
-
-    ptnn_handle* h = new ptnn_handle();
+namespace {
+// everything of ptnn_create that can fail after the handle exists: the caller destroys the handle on a non-zero return
+int create_buffers(ptnn_handle* h, const ptnn_config* cfg, const Shape* sh, const hipDeviceProp_t& prop) {
     h->cfg = *cfg;
     h->shape = sh;
     h->num_cus = prop.multiProcessorCount;
@@ -306,8 +275,6 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
     h->FWS = round_up4(I + 1 + O);
     h->max_rounds = cfg->n_samples / cfg->swap_interval + 2;
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    if (cfg->trace_capacity < 0 || (cfg->trace_capacity > 0 && cfg->trace_capacity < 2))
-        return fail(-1, "trace_capacity must be 0 (= n_samples) or >= 2");
     h->cap = (cfg->trace_capacity > 0 && cfg->trace_capacity < cfg->n_samples) ? cfg->trace_capacity : cfg->n_samples;
     const size_t Rl = cfg->n_replicas_local, R = cfg->n_replicas_global, S = h->cap;
     HIP_TRY(hipMalloc(&h->d_state[0], Rl * h->PS * sizeof(float)));
@@ -346,6 +313,57 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
     HIP_TRY(hipMemsetAsync(h->d_L_handoff, 0, R * sizeof(float), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_L_final, 0, R * sizeof(float), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_src_log, 0xff, (size_t)h->max_rounds * R * sizeof(int), h->stream));
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int ptnn_abi_version(void) { return PTNN_ABI_VERSION; }
+const char* ptnn_last_error(void) { return g_err.c_str(); }
+
+int ptnn_supports(int task, int n_in, int n_hidden, int n_out) {
+    return (find_shape(task, n_in, n_out) != nullptr && n_hidden >= 1 && n_hidden <= MAX_HIDDEN) ? 1 : 0;
+}
+
+int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
+    if (!cfg || !out) return fail(-1, "null argument");
+    if (cfg->struct_bytes != (int32_t)sizeof(ptnn_config))
+        return fail(-1, "ptnn_config size mismatch: caller %d, library %d", cfg->struct_bytes, (int)sizeof(ptnn_config));
+    if (cfg->task != PTNN_TASK_REG && cfg->task != PTNN_TASK_CLS) return fail(-1, "unknown task %d", cfg->task);
+    if (cfg->n_in < 1 || cfg->n_hidden < 1 || cfg->n_out < 1) return fail(-1, "bad topology");
+    if (cfg->task == PTNN_TASK_REG && cfg->n_out != 1) return fail(-1, "regression needs n_out == 1");
+    const Shape* sh = find_shape(cfg->task, cfg->n_in, cfg->n_out);
+    if (!sh)
+        return fail(-3, "no gfx950 kernel compiled for task=%d n_in=%d n_out=%d: add it to PTNN_SHAPES and rebuild",
+                    cfg->task, cfg->n_in, cfg->n_out);
+    if (cfg->n_hidden > MAX_HIDDEN)
+        return fail(-3, "n_hidden=%d > %d: the SGD sweep holds one hidden unit per thread of one work-group", cfg->n_hidden, MAX_HIDDEN);
+    if (cfg->n_replicas_local < 1 || cfg->n_replicas_global < 2 || cfg->first_global_replica < 0 ||
+        cfg->first_global_replica + cfg->n_replicas_local > cfg->n_replicas_global)
+        return fail(-1, "bad replica partition: local=%d global=%d first=%d", cfg->n_replicas_local,
+                    cfg->n_replicas_global, cfg->first_global_replica);
+    if (cfg->n_samples < 2) return fail(-1, "n_samples must be >= 2");
+    if (cfg->swap_interval < 1) return fail(-1, "swap_interval must be >= 1 (the reference divides by it, REG:427)");
+    if (cfg->swap_rule != 0 && cfg->swap_rule != 1) return fail(-1, "swap_rule must be 0 (reference cascade) or 1 (even/odd Metropolis)");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(-2, "device %d not present (%d devices)", cfg->device_id, ndev);
+    HIP_TRY(hipSetDevice(cfg->device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(-2, "device %d is %s; libptnn is built for gfx950 only", cfg->device_id, prop.gcnArchName);
+
+    if (cfg->trace_capacity < 0 || (cfg->trace_capacity > 0 && cfg->trace_capacity < 2))
+        return fail(-1, "trace_capacity must be 0 (= n_samples) or >= 2");
+    ptnn_handle* h = new ptnn_handle();
+    if (int rc = create_buffers(h, cfg, sh, prop)) {       // frees whatever was allocated (stream included); g_err keeps the cause
+        const std::string why = g_err;
+        ptnn_destroy(h);
+        g_err = why;
+        return rc;
+    }
     *out = h;
     return 0;
 }
@@ -354,6 +372,7 @@ int ptnn_destroy(ptnn_handle* h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device_id);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->comm.release();
     void* ptrs[] = {h->d_data, h->d_state[0], h->d_state[1], h->d_rec_w, h->d_gd_w[0], h->d_gd_w[1], h->d_gd_valid[0], h->d_gd_valid[1], h->d_st_f, h->d_st_i, h->d_temps,
                     h->d_L_handoff, h->d_L_final, h->d_L_raw, h->d_prior_post, h->d_temps_global, h->d_pos_w, h->d_likeh, h->d_rmse_tr, h->d_rmse_te, h->d_acc_tr,
                     h->d_acc_te, h->d_accept, h->d_src, h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_stamps, h->d_wide_scratch, h->d_xt};
@@ -476,8 +495,6 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         if (h->cfg.groups_per_replica > 0) G = h->cfg.groups_per_replica;
         else { while (G < 4 && Rl * (G * 2) <= h->num_cus) G *= 2; }
         if (G != 1 && G != 2 && G != 4 && G != 8) return fail(-1, "groups_per_replica must be 0 (auto), 1, 2, 4 or 8");
-        if (G > 1 && Rl * G > h->num_cus * 2)              // groups of one replica wait for each other: all must be resident
-            return fail(-3, "%d replicas x %d work-groups cannot all be resident on %d CUs", Rl, G, h->num_cus);
         int k = nw ? nw : (G > 1 ? 4 : 8);
         while (k > 1 && spec_lds_floats(Nall, IPY, h->PS, H, h->FWS, k, G) * sizeof(float) > LDS_MAX) k >>= 1;
         if (nw && k != nw) {
@@ -489,6 +506,22 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         else {
             h->speculative = true; h->nthreads = k * 64; h->groups = G;
             h->seg_lds = spec_lds_floats(Nall, IPY, h->PS, H, h->FWS, k, G) * sizeof(float);
+            if (G > 1) {
+                // The work-groups of one replica wait for each other inside the kernel, so all Rl x G of them must be
+                // resident at once: ask the runtime how many blocks of THIS kernel (its registers, this LDS size, this block
+                // size) fit on a CU instead of guessing, and refuse the configuration otherwise (a non-resident partner would
+                // be a bounded spin and an error from ptnn_sync).  The count is for a GPU this handle has to itself: other
+                // handles or processes on the same device take CUs this query does not see.
+                const void* fn = reinterpret_cast<const void*>(h->shape->spec);
+                if (int rc = raise_lds_limit(fn, h->seg_lds)) return rc;
+                int per_cu = 0;
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, h->nthreads, h->seg_lds));
+                h->blocks_per_cu = per_cu;
+                if ((long long)Rl * G > (long long)per_cu * h->num_cus)
+                    return fail(-3, "%d replicas x %d work-groups cannot all be resident: %d work-group(s) of %d threads with %zu B "
+                                    "of LDS fit on each of the %d CUs; use fewer groups_per_replica or the packed schedule",
+                                Rl, G, per_cu, h->nthreads, h->seg_lds, h->num_cus);
+            }
             if (h->d_xslots) { HIP_TRY(hipFree(h->d_xslots)); h->d_xslots = nullptr; }
             if (h->d_xw) { HIP_TRY(hipFree(h->d_xw)); h->d_xw = nullptr; }
             if (G > 1) {
@@ -526,6 +559,7 @@ int ptnn_set_state(ptnn_handle* h, const float* w0, const float* temperatures) {
     if (!h || !w0 || !temperatures) return fail(-1, "null argument");
     if (!h->have_data) return fail(-1, "call ptnn_set_data before ptnn_set_state");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(h->stream));                // a restart must not overtake a run still in flight
     const int Rl = h->cfg.n_replicas_local, P = h->P, PS = h->PS, S = h->cap;
     std::vector<float> st((size_t)Rl * PS, 0.0f), ones((size_t)Rl * PS, 1.0f);
     for (int r = 0; r < Rl; ++r) std::memcpy(&st[(size_t)r * PS], w0 + (size_t)r * P, P * sizeof(float));
@@ -546,12 +580,11 @@ int ptnn_set_state(ptnn_handle* h, const float* w0, const float* temperatures) {
     HIP_TRY(hipMemset(h->d_acc_te, 0, (size_t)Rl * S * sizeof(float)));
     HIP_TRY(hipMemset(h->d_accept, 0, (size_t)Rl * S * sizeof(int)));
     HIP_TRY(hipMemset(h->d_likeh, 0, (size_t)Rl * S * sizeof(float)));
-    std::vector<float> onesP(P, 1.0f);
-    const float m100 = -100.0f;
-    for (int r = 0; r < Rl; ++r) {
-        HIP_TRY(hipMemcpy(h->d_pos_w + (size_t)r * S * P, onesP.data(), P * sizeof(float), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(h->d_likeh + (size_t)r * S, &m100, sizeof(float), hipMemcpyHostToDevice));
-    }
+    // one strided copy per trace instead of one small copy per replica (a whole-run restart is part of the benchmark's timed region)
+    std::vector<float> m100((size_t)Rl, -100.0f);
+    HIP_TRY(hipMemcpy2D(h->d_pos_w, (size_t)S * P * sizeof(float), ones.data(), (size_t)PS * sizeof(float), (size_t)P * sizeof(float), Rl,
+                        hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy2D(h->d_likeh, (size_t)S * sizeof(float), m100.data(), sizeof(float), sizeof(float), Rl, hipMemcpyHostToDevice));
     h->flip = 0; h->cur = 0; h->rounds_done = 0; h->finalized = false; h->drained = 0; h->first_row = 0;
     HIP_TRY(hipMemset(h->d_counters, 0, 2 * sizeof(long long)));
     h->have_state = true;
@@ -568,10 +601,55 @@ int ptnn_set_ladder(ptnn_handle* h, const float* temperatures_global) {
 
 int ptnn_steps_done(ptnn_handle* h) { return h ? h->cur : -1; }
 
+// what a swap round moves between GPUs for this handle: AUTO = gather while the gathered buffer stays small
+static int resolved_xchg_mode(const ptnn_handle* h) {
+    if (h->cfg.swap_rule == 1) return PTNN_XCHG_GATHER;       // the moved state brings likelihood and prior along: rows only
+    if (h->comm.mode != PTNN_XCHG_AUTO) return h->comm.mode;
+    const size_t gathered = (size_t)h->cfg.n_replicas_global * xchg_row_floats(h->PS) * sizeof(float);
+    return gathered <= (size_t)4 << 20 ? PTNN_XCHG_GATHER : PTNN_XCHG_BOUNDARY;
+}
+
+// One swap round of a sharded ladder (the handle owns a block of it), everything queued on the handle's stream.
+static int comm_swap_round(ptnn_handle* h, bool phantom) {
+    Comm& c = h->comm;
+    const int Rl = h->cfg.n_replicas_local, R = h->cfg.n_replicas_global;
+    if (resolved_xchg_mode(h) == PTNN_XCHG_GATHER) {
+        if (int rc = launch_swap(h, phantom, -1, false)) return rc;                     // exchange rows of the local replicas
+        if (!c.all_gather(h->d_xchg, (size_t)Rl * xchg_row_floats(h->PS) * sizeof(float), h->stream)) return fail(-7, "%s", c.err.c_str());
+        if (int rc = launch_swap(h, phantom, phantom ? (2 | 4) : (3 | 4), false)) return rc;   // identical cascade + source rows
+    } else {
+        if (!c.all_gather(phantom ? h->d_L_final : h->d_L_handoff, (size_t)Rl * sizeof(float), h->stream)) return fail(-7, "%s", c.err.c_str());
+        if (phantom) {                                                                  // counted, result discarded (Q13)
+            if (int rc = launch_swap(h, true, 2, false)) return rc;
+        } else {
+            if (int rc = launch_swap(h, false, 0, true)) return rc;                     // cascade only: src[R]
+            HIP_TRY(hipMemcpyAsync(h->h_src, h->d_src, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));                                   // the one host wait of this mode
+            route_rows(h->h_src, R, Rl, c.rank, h->route);
+            float* cur = h->d_state[h->flip];
+            float* next = h->d_state[h->flip ^ 1];
+            const size_t PS = h->PS;
+            if (!c.exchange_rows(h->route, PS * sizeof(float), h->stream,
+                                 [&](int row) { return static_cast<void*>(cur + (size_t)row * PS); },
+                                 [&](int row) { return static_cast<void*>(next + (size_t)row * PS); }))
+                return fail(-7, "%s", c.err.c_str());
+            if (int rc = launch_swap(h, false, 3, false)) return rc;                    // local moves (arrived rows stay), count, log
+        }
+    }
+    if (!phantom) h->flip ^= 1;
+    h->rounds_done += 1;
+    c.rounds += 1;
+    return 0;
+}
+
 int ptnn_run(ptnn_handle* h, int n_steps) {
     if (int rc = check_ready(h)) return rc;
-    if (h->cfg.n_replicas_local != h->cfg.n_replicas_global)
-        return fail(-1, "ptnn_run drives a whole ladder on one GPU; use ptnn_run_segment + ptnn_swap_* for a sharded ladder");
+    // with a communicator attached the swap rounds go through it, also when it has a single rank (rehearsal of the path)
+    const bool sharded = h->comm.kind != COMM_NONE;
+    if (h->cfg.n_replicas_local != h->cfg.n_replicas_global && !sharded)
+        return fail(-1, "this handle owns replicas %d..%d of %d: attach a communicator first (ptnn_comm_init / ptnn_comm_init_host), "
+                        "or drive the pieces yourself with ptnn_run_segment + ptnn_swap_*", h->cfg.first_global_replica,
+                    h->cfg.first_global_replica + h->cfg.n_replicas_local - 1, h->cfg.n_replicas_global);
     if (h->cfg.swap_rule == 1 && !h->have_ladder) return fail(-1, "swap_rule 1 needs ptnn_set_ladder (all temperatures)");
     const int S = h->cfg.n_samples;
     const int last = S - 1;                                  // steps are i = 0 .. S-2
@@ -587,21 +665,118 @@ int ptnn_run(ptnn_handle* h, int n_steps) {
         if (int rc = launch_segment(h, h->cur, stop - h->cur)) return rc;
         h->cur = stop;
         if (handoff) {
-            if (int rc = launch_swap(h, false, 3, false)) return rc;
-            h->flip ^= 1;
-            h->rounds_done += 1;
+            if (sharded) {
+                if (int rc = comm_swap_round(h, false)) return rc;
+            } else {
+                if (int rc = launch_swap(h, false, 3, false)) return rc;
+                h->flip ^= 1;
+                h->rounds_done += 1;
+            }
         }
     }
     if (h->cur == last && !h->finalized) {
         // Q13: the parent loops int(S/si) rounds; a round beyond the replicas' hand-offs consumes the end-of-chain
         // vectors, is counted in swap_perc and its result is discarded
         if (h->cfg.swap_rule == 0 && S / h->cfg.swap_interval > h->rounds_done) {
-            if (int rc = launch_swap(h, true, 2, false)) return rc;
-            h->rounds_done += 1;
+            if (sharded) {
+                if (int rc = comm_swap_round(h, true)) return rc;
+            } else {
+                if (int rc = launch_swap(h, true, 2, false)) return rc;
+                h->rounds_done += 1;
+            }
         }
         h->finalized = true;
     }
     return 0;
+}
+
+// ---- communicators of the sharded ladder ----
+static int comm_check_partition(ptnn_handle* h, int rank, int nranks) {
+    if (!h) return fail(-1, "null handle");
+    if (h->comm.kind != COMM_NONE) return fail(-1, "this handle already has a communicator");
+    const int Rl = h->cfg.n_replicas_local, R = h->cfg.n_replicas_global;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(-1, "bad rank %d of %d", rank, nranks);
+    if (Rl * nranks != R || h->cfg.first_global_replica != rank * Rl)
+        return fail(-1, "the ladder must be cut into equal contiguous blocks: rank %d of %d owns replicas %d..%d of %d, expected "
+                        "first_global_replica == rank * n_replicas_local and n_replicas_local * nranks == n_replicas_global",
+                    rank, nranks, h->cfg.first_global_replica, h->cfg.first_global_replica + Rl - 1, R);
+    return 0;
+}
+
+int ptnn_comm_unique_id(void* id_out, int nbytes) {
+    if (!id_out || nbytes < (int)sizeof(ncclUniqueId)) return fail(-1, "the unique id needs a buffer of %d bytes", (int)sizeof(ncclUniqueId));
+    std::string why;
+    const RcclApi* api = rccl_api(why);
+    if (!api) return fail(-7, "cannot load RCCL: %s", why.c_str());
+    ncclUniqueId id;
+    const ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(-7, "ncclGetUniqueId failed: %s", api->GetErrorString(r));
+    std::memcpy(id_out, &id, sizeof id);
+    return (int)sizeof id;
+}
+
+int ptnn_comm_init(ptnn_handle* h, const void* unique_id, int nbytes, int rank, int nranks) {
+    if (int rc = comm_check_partition(h, rank, nranks)) return rc;
+    if (!unique_id || nbytes != (int)sizeof(ncclUniqueId)) return fail(-1, "the unique id must be the %d bytes ptnn_comm_unique_id wrote", (int)sizeof(ncclUniqueId));
+    std::string why;
+    const RcclApi* api = rccl_api(why);
+    if (!api) return fail(-7, "cannot load RCCL: %s", why.c_str());
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof id);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = api->CommInitRank(&comm, nranks, id, rank);
+    if (r != ncclSuccess) return fail(-7, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, nranks, h->cfg.device_id, api->GetErrorString(r));
+    h->comm.api = api; h->comm.nccl = comm; h->comm.rank = rank; h->comm.nranks = nranks; h->comm.kind = COMM_RCCL;
+    return 0;
+}
+
+int ptnn_comm_init_host(ptnn_handle* h, int rank, int nranks, ptnn_all_gather_fn all_gather, ptnn_send_recv_fn send_recv, void* ctx) {
+    if (int rc = comm_check_partition(h, rank, nranks)) return rc;
+    if (!all_gather || !send_recv) return fail(-1, "null callback");
+    h->comm.h_all_gather = all_gather; h->comm.h_send_recv = send_recv; h->comm.h_ctx = ctx;
+    h->comm.rank = rank; h->comm.nranks = nranks; h->comm.kind = COMM_HOST;
+    return 0;
+}
+
+int ptnn_comm_set_mode(ptnn_handle* h, int mode) {
+    if (!h) return fail(-1, "null handle");
+    if (mode != PTNN_XCHG_AUTO && mode != PTNN_XCHG_GATHER && mode != PTNN_XCHG_BOUNDARY) return fail(-1, "unknown exchange mode %d", mode);
+    if (mode == PTNN_XCHG_BOUNDARY && h->cfg.swap_rule != 0)
+        return fail(-3, "the boundary exchange implements the reference's cascade (swap_rule 0) only: use the gathered exchange");
+    h->comm.mode = mode;
+    return 0;
+}
+
+int ptnn_comm_stats(ptnn_handle* h, int64_t* bytes_sent, int64_t* bytes_received, int64_t* rounds, int32_t* mode) {
+    if (!h) return fail(-1, "null handle");
+    if (bytes_sent) *bytes_sent = h->comm.bytes_sent;
+    if (bytes_received) *bytes_received = h->comm.bytes_received;
+    if (rounds) *rounds = h->comm.rounds;
+    if (mode) *mode = h->comm.kind == COMM_NONE ? 0 : resolved_xchg_mode(h);
+    return 0;
+}
+
+int ptnn_comm_finalize(ptnn_handle* h) {
+    if (!h) return fail(-1, "null handle");
+    (void)hipSetDevice(h->cfg.device_id);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->comm.release();
+    return 0;
+}
+
+int ptnn_route(const int32_t* src, int n_global, int n_local, int rank, int32_t* msg, int max_msgs) {
+    if (!src || !msg || n_local < 1 || n_global < n_local || n_global % n_local != 0 || rank < 0 || rank >= n_global / n_local)
+        return fail(-1, "bad argument");
+    for (int k = 0; k < n_global; ++k)
+        if (src[k] < 0 || src[k] >= n_global) return fail(-1, "src[%d] = %d is not a slot", k, src[k]);
+    std::vector<RowMsg> r;
+    route_rows(src, n_global, n_local, rank, r);
+    if ((int)r.size() > max_msgs) return fail(-1, "%d messages, room for %d", (int)r.size(), max_msgs);
+    for (size_t m = 0; m < r.size(); ++m) {
+        msg[4 * m] = r[m].is_send; msg[4 * m + 1] = r[m].peer; msg[4 * m + 2] = r[m].local_row; msg[4 * m + 3] = r[m].global_dst;
+    }
+    return (int)r.size();
 }
 
 int ptnn_sync(ptnn_handle* h) {
@@ -961,6 +1136,31 @@ int ptnn_tape(ptnn_handle* h, int replica, int step, float* noise, float* scal) 
     return 0;
 }
 
+int ptnn_describe(ptnn_handle* h, char* buf, int nbytes) {
+    if (!h || !buf || nbytes < 1) return fail(-1, "bad argument");
+    if (!h->have_data) return fail(-1, "ptnn_set_data has not been called (the schedule depends on the data set)");
+    const char* kern = h->wide ? "segment_wide_kernel" : (h->packed ? "segment_pack_kernel" : (h->speculative ? "segment_spec_kernel" : "segment_kernel"));
+    const void* fn = reinterpret_cast<const void*>(h->wide ? h->shape->seg_wide : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg)));
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, h->nthreads, h->seg_lds));
+    hipFuncAttributes fa{};
+    HIP_TRY(hipFuncGetAttributes(&fa, fn));
+    const int grid = h->cfg.n_replicas_local * ((h->speculative && !h->packed) ? h->groups : 1);
+    const int slots = h->wide || !h->speculative ? 1 : (h->packed ? pack_slots(h->pk_nred) : h->groups * (h->nthreads / WAVE));
+    const int n = std::snprintf(buf, (size_t)nbytes,
+                                "{\"kernel\": \"ptnn::%s<%d,%d,%d>\", \"schedule\": \"%s\", \"grid_blocks\": %d, \"block_threads\": %d, "
+                                "\"lds_bytes\": %zu, \"groups_per_replica\": %d, \"slots_per_round\": %d, \"num_cus\": %d, "
+                                "\"blocks_per_cu\": %d, \"vgprs\": %d, \"scratch_bytes\": %zu, \"forward_mfma\": %d, \"exchange\": \"%s\"}",
+                                kern, h->cfg.task, h->cfg.n_in, h->cfg.n_out,
+                                h->wide ? "cooperative-wide" : (h->packed ? "packed-speculative" : (h->speculative ? "speculative" : "cooperative")),
+                                grid, h->nthreads, h->seg_lds, h->groups, slots, h->num_cus, per_cu, fa.numRegs, (size_t)fa.localSizeBytes,
+                                (h->fw_mfma || (h->wide && h->cfg.n_hidden % 32 == 0)) ? 1 : 0,
+                                h->comm.kind == COMM_NONE ? "none" : (resolved_xchg_mode(h) == PTNN_XCHG_GATHER ? "gather" : "boundary"));
+    if (n < 0 || n >= nbytes) return fail(-1, "buffer of %d bytes is too small for the description", nbytes);
+    return n;
+}
+
 int ptnn_kernel_time(ptnn_handle* h, int reset, int64_t* launches, double* total_ms) {
     if (!h) return fail(-1, "null handle");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
@@ -988,6 +1188,14 @@ static bool float_format_ok(const char* fmt) {
     const size_t fl = std::strlen(fmt);
     bool ok = fl >= 2 && fl < 16 && fmt[0] == '%' && std::strchr("eEfFgG", fmt[fl - 1]) != nullptr;
     for (size_t k = 1; ok && k + 1 < fl; ++k) ok = std::strchr("0123456789.+- #", fmt[k]) != nullptr;
+    // width and precision stay far inside the 400-byte slot ptnn_savetxt formats a value into
+    for (size_t k = 1; ok && k + 1 < fl;) {
+        if (fmt[k] >= '0' && fmt[k] <= '9') {
+            long v = 0;
+            while (k + 1 < fl && fmt[k] >= '0' && fmt[k] <= '9') v = v * 10 + (fmt[k++] - '0');
+            ok = v <= 40;
+        } else ++k;
+    }
     return ok;
 }
 
@@ -1017,7 +1225,9 @@ int ptnn_savetxt(const char* path, const double* data, int64_t rows, int64_t col
                 used = 0;
             }
             if (c) buf[used++] = ' ';
-            used += (size_t)std::snprintf(buf.data() + used, 400, fmt, data[r * cols + c]);
+            const int w = std::snprintf(buf.data() + used, 400, fmt, data[r * cols + c]);
+            if (w < 0 || w >= 400) { std::fclose(f); return fail(-1, "value %g does not fit the text slot with format '%s'", data[r * cols + c], fmt); }
+            used += (size_t)w;
         }
         buf[used++] = '\n';
     }

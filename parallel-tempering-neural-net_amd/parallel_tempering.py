@@ -32,9 +32,9 @@ class ParallelTemperingBase:
     rmse_fmt = None                   # REG '%1.8f' (REG:462-464), CLS '%1.2f' (CLS:473-475)
 
     def __init__(self, use_langevin_gradients, learn_rate, traindata, testdata, topology, num_chains, maxtemp,
-                 NumSample, swap_interval, langevin_prob, path, *, seed=None, device=None, waves_per_replica=0,
-                 schedule=0, groups_per_replica=0, trace_capacity=0, swap_rule=0, shared_noise=False, write_files=True,
-                 io_threads=None):
+                 NumSample, swap_interval, langevin_prob, path, *, seed=None, device=None, devices=None, exchange="auto",
+                 transport=None, waves_per_replica=0, schedule=0, groups_per_replica=0, trace_capacity=0, swap_rule=0,
+                 shared_noise=False, write_files=True, io_threads=None):
         # FNN chain variables (REG:491-494)
         self.traindata = traindata
         self.testdata = testdata
@@ -60,6 +60,17 @@ class ParallelTemperingBase:
             seed = int.from_bytes(os.urandom(8), "little")       # the reference never seeds its generators
         self.seed = int(seed)
         self.device = int(os.environ.get("PTNN_DEVICE", "0")) if device is None else int(device)
+        # devices=[0, 1, ...]: the ladder is cut into len(devices) equal contiguous blocks, one per GPU; the swap rounds exchange
+        # over RCCL inside libptnn (where the reference forks one process per chain and pipes every vector through the parent,
+        # REG:694-771).  $PTNN_DEVICES="0,1,2,3" does the same for an unmodified driver script.  `exchange`: "auto", "gather"
+        # or "boundary" (include/ptnn.h); `transport`: None = RCCL when the devices are distinct, host-staged otherwise.
+        if devices is None and os.environ.get("PTNN_DEVICES"):
+            devices = [int(v) for v in os.environ["PTNN_DEVICES"].split(",")]
+        self.devices = None if devices is None else [int(d) for d in devices]
+        if self.devices is not None and self.num_chains % len(self.devices) != 0:
+            raise ValueError(f"num_chains = {self.num_chains} cannot be cut into {len(self.devices)} equal blocks (one per device)")
+        self.exchange = {"auto": _lib.XCHG_AUTO, "gather": _lib.XCHG_GATHER, "boundary": _lib.XCHG_BOUNDARY}[exchange]
+        self.transport = transport
         self.waves_per_replica = int(waves_per_replica)
         self.schedule = int(schedule)            # 0 auto, 1 cooperative, 2 speculative (include/ptnn.h)
         self.groups_per_replica = int(groups_per_replica)
@@ -126,15 +137,22 @@ class ParallelTemperingBase:
         lib = _lib.load_library()
         if not lib.ptnn_supports(self.task, I, H, O):
             raise _lib.PtnnError(f"no gfx950 kernel for task={self.task} topology={[I, H, O]} in {_lib.library_path()}: "
-                                 f"add X({self.task}, {I}, {O}) to PTNN_SHAPES (csrc/ptnn.hip) and rebuild; n_hidden <= 64")
-        self._sampler = _lib.Sampler(
-            device_id=self.device, task=self.task, n_in=I, n_hidden=H, n_out=O,
-            n_replicas_local=self.num_chains, n_replicas_global=self.num_chains, first_global_replica=0,
+                                 f"add X({self.task}, {I}, {O}) to PTNN_SHAPES (csrc/ptnn_shapes.hpp) and to SHAPES in "
+                                 f"__graft_entry__.py, then rebuild; n_hidden may be anything up to 512")
+        config = dict(
+            task=self.task, n_in=I, n_hidden=H, n_out=O, n_replicas_global=self.num_chains,
             n_samples=S, swap_interval=int(self.swap_interval), pt_switch_step=self._pt_switch_step(),
             use_langevin=1 if self.use_langevin_gradients is True else 0, waves_per_replica=self.waves_per_replica,
-            schedule=self.schedule, groups_per_replica=self.groups_per_replica, trace_capacity=self.trace_capacity, swap_rule=self.swap_rule, shared_noise=int(self.shared_noise),
+            schedule=self.schedule, groups_per_replica=self.groups_per_replica, trace_capacity=self.trace_capacity,
+            swap_rule=self.swap_rule, shared_noise=int(self.shared_noise),
             l_prob=float(self.langevin_prob), learn_rate=float(self.learn_rate), step_w=0.025, step_eta=0.2,
             sigma_squared=25.0, nu_1=0.0, nu_2=0.0, seed=self.seed)
+        if self.devices is not None and len(self.devices) > 1:
+            from . import distributed
+            self._sampler = distributed.LadderGroup(self.devices, exchange=self.exchange, transport=self.transport, **config)
+        else:
+            dev = self.device if self.devices is None else self.devices[0]
+            self._sampler = _lib.Sampler(device_id=dev, n_replicas_local=self.num_chains, first_global_replica=0, **config)
         self._sampler.set_data(train, test)
         self._sampler.set_state(self._w0, self.temperatures)
         if self.swap_rule == 1:

@@ -1,6 +1,7 @@
-"""Child process of test_sharded_ladder_driver_on_device_matches_plain_run: world-size-1 rehearsal of distributed.py on the GPU."""
+"""Child process of test_rccl_communicator_world_size_one: the RCCL transport of libptnn (ptnn_comm_init -> dlopen librccl,
+ncclCommInitRank, in-place ncclAllGather on the handle's own stream) at world size 1 -- the only RCCL world a one-GPU box
+allows -- in both exchange modes and under swap_rule 1, against the plain single-handle run.  No torch in this process."""
 import os
-import socket
 import sys
 
 import numpy as np
@@ -8,21 +9,13 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def main():
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    import torch
-    import torch.distributed as dist
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1)
     import parity
     from parity import orc
-    from ptnn_amd import distributed as dm, ladder, philox
+    from ptnn_amd import _lib, ladder, philox
     d = parity.datasets()
     train, test = d["sunspot_train"], d["sunspot_test"]
     topo, R, S, si = (4, 5, 1), 16, 8 * 12 + 3, 12
@@ -35,27 +28,32 @@ def main():
         if rule:
             s_.set_ladder(ladder.temperatures(R, 2))
         return s_
-    try:
-        for mode, rule in (("gather", 0), ("p2p", 0), ("gather", 1)):
-            ref = make(rule)
-            ref.run(-1)
-            ref.sync()
-            want, want_log, want_stats = ref.traces(), ref.swap_log(), ref.swap_stats()
-            ref.close()
-            assert want_stats[0] > 0
-            s = make(rule)
-            lad = dm.ShardedLadder(dm.DeviceShard(s, 0), 0, 1, dist, mode=mode)
-            lad.run_intervals(None)
-            s.sync()
-            got = s.traces()
-            for k in want:
-                assert np.array_equal(got[k], want[k]), (mode, k)
-            assert np.array_equal(s.swap_log(), want_log), mode
-            assert s.swap_stats() == want_stats, mode
-            s.close()
-            print("OK", mode, "rule", rule, flush=True)
-    finally:
-        dist.destroy_process_group()
+    assert "torch" not in sys.modules
+    for mode, rule in ((_lib.XCHG_GATHER, 0), (_lib.XCHG_BOUNDARY, 0), (_lib.XCHG_GATHER, 1)):
+        ref = make(rule)
+        ref.run(-1)
+        ref.sync()
+        want, want_log, want_stats = ref.traces(), ref.swap_log(), ref.swap_stats()
+        ref.close()
+        assert want_stats[0] > 0
+        s = make(rule)
+        s.comm_init(_lib.comm_unique_id(), 0, 1)
+        s.comm_set_mode(mode)
+        s.run(40)                                            # in chunks, like a caller that drains a trace ring
+        s.run(-1)
+        s.sync()
+        got = s.traces()
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (mode, k)
+        assert np.array_equal(s.swap_log(), want_log), mode
+        assert s.swap_stats() == want_stats, mode
+        st = s.comm_stats()
+        assert st["rounds"] == want_stats[2] and st["mode"] == {1: "gather", 2: "boundary"}[mode], st
+        assert s.describe()["exchange"] == st["mode"]
+        s.close()
+        print("OK", st["mode"], "rule", rule, flush=True)
+    assert "torch" not in sys.modules
+    print("OK no torch", flush=True)
 
 
 if __name__ == "__main__":

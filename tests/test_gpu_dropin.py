@@ -166,3 +166,62 @@ def test_run_chains_checkpoint_and_resume(key, tmp_path):
             pa = os.path.join(root, f)
             pb = pa.replace(str(tmp_path / "a"), str(tmp_path / "b"))
             assert open(pa, "rb").read() == open(pb, "rb").read(), f
+
+
+@pytest.mark.parametrize("key,devices,exchange", [("reg", [0, 0], "auto"), ("reg", [0, 0, 0, 0], "boundary"), ("cls", [0, 0], "boundary"),
+                                                  ("cls", [0, 0, 0, 0], "gather"), ("reg_nophantom", [0, 0], "boundary")])
+def test_run_chains_on_a_sharded_ladder_equals_one_device(key, devices, exchange, tmp_path):
+    """`ParallelTempering(..., devices=[...])`: run_chains() itself cuts the ladder into one block per listed device and the
+    swap rounds exchange inside libptnn (REG:694-771 replaced end to end).  The box has one GPU, so it is listed several
+    times: one handle and one host thread per block, host-staged ThreadTransport between them (RCCL refuses a device twice) --
+    the same ptnn_run / comm_swap_round code the RCCL path runs.  Return tuple and every result file must equal the one-device
+    run bit for bit."""
+    os.makedirs(tmp_path / "a")
+    os.makedirs(tmp_path / "b")
+    a = _run(key, tmp_path / "a")
+    b = _run(key, tmp_path / "b", devices=devices, exchange=exchange)
+    for x, y in zip(a[2], b[2]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    assert (a[1].num_swap, a[1].total_swap_proposals) == (b[1].num_swap, b[1].total_swap_proposals)
+    stats = b[1]._sampler.comm_stats()
+    assert len(stats) == len(devices) and all(st["rounds"] == b[1].rounds for st in stats)
+    want_mode = "gather" if exchange in ("auto", "gather") else "boundary"
+    assert all(st["mode"] == want_mode for st in stats)
+    assert sum(st["bytes_sent"] for st in stats) == sum(st["bytes_received"] for st in stats) > 0
+    for root, _, files in os.walk(tmp_path / "a"):
+        for f in files:
+            pa = os.path.join(root, f)
+            assert open(pa, "rb").read() == open(pa.replace(str(tmp_path / "a"), str(tmp_path / "b")), "rb").read(), f
+
+
+def test_sharded_run_chains_checkpoint_and_resume(tmp_path):
+    """Checkpoint / resume of a sharded ladder: one blob per block behind an index, resumed in a new object."""
+    global _RUN_KW
+    os.makedirs(tmp_path / "a")
+    os.makedirs(tmp_path / "b")
+    a = _run("reg", tmp_path / "a")[2]
+    ck = str(tmp_path / "ck.npz")
+    try:
+        _RUN_KW = dict(checkpoint_path=ck, checkpoint_every=7, max_steps=23)
+        g, pt, res = _run("reg", tmp_path / "b", devices=[0, 0], exchange="boundary")
+        assert res is None and os.path.exists(ck)
+        _RUN_KW = dict(checkpoint_path=ck, checkpoint_every=9, resume_from=ck)
+        b = _run("reg", tmp_path / "b", devices=[0, 0], exchange="boundary")[2]
+    finally:
+        _RUN_KW = {}
+    for x, y in zip(a, b):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+
+
+def test_sharded_handle_without_communicator_is_refused():
+    import ptnn_amd  # noqa: F401
+    from ptnn_amd import _lib
+    d = parity.datasets()
+    s = parity.make_sampler(0, (4, 5, 1), d["sunspot_train"], d["sunspot_test"], R_local=2, R_global=4, first=2, S=20, si=5,
+                            use_lg=False, lr=0.1, seed=1)
+    s.set_state(np.zeros((2, 31), np.float32), np.ones(2, np.float32))
+    with pytest.raises(_lib.PtnnError, match="communicator"):
+        s.run(-1)
+    with pytest.raises(_lib.PtnnError, match="equal contiguous blocks"):
+        s.comm_init_host(0, 2, lambda b: None, lambda m: None)      # this handle is rank 1 of 2, not rank 0
+    s.close()

@@ -28,7 +28,7 @@ FUNC_CASES = {"reg_sunspot_4_5_1": "sunspot", "reg_mackey_4_10_1": "mackey", "cl
 def test_library_is_the_hip_build():
     import ptnn_amd
     lib = ptnn_amd.load_library()
-    assert lib.ptnn_abi_version() == 1
+    assert lib.ptnn_abi_version() == 2
     assert lib.ptnn_supports(0, 4, 5, 1) == 1 and lib.ptnn_supports(1, 34, 50, 2) == 1
     assert lib.ptnn_supports(0, 4, 65, 1) == 1 and lib.ptnn_supports(0, 32, 512, 1) == 1
     assert lib.ptnn_supports(0, 4, 513, 1) == 0 and lib.ptnn_supports(0, 7, 5, 1) == 0
@@ -602,16 +602,17 @@ def test_even_odd_swap_rule_option(task):
 
 
 @pytest.mark.gpu
-def test_sharded_ladder_driver_on_device_matches_plain_run():
-    """The multi-GPU driver (distributed.py) on the real device buffers, rehearsed at world size 1 over RCCL: both exchange
-    modes must reproduce the chain of the single-GPU path bit for bit (traces, swap log, counters).  Runs in a child process
-    (tests/dist_device_check.py) so that torch initialises the GPU before libptnn does, as in bench.py."""
+def test_rccl_communicator_world_size_one():
+    """The RCCL transport inside libptnn (ptnn_comm_init: dlopen librccl, ncclCommInitRank, in-place ncclAllGather on the
+    handle's stream) at world size 1, both exchange modes and swap_rule 1: same chain as the plain run bit for bit (traces,
+    swap log, counters).  Child process (tests/dist_device_check.py) that never imports torch."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "dist_device_check.py")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "OK gather rule 0" in r.stdout and "OK p2p rule 0" in r.stdout and "OK gather rule 1" in r.stdout
+    for line in ("OK gather rule 0", "OK boundary rule 0", "OK gather rule 1", "OK no torch"):
+        assert line in r.stdout
 
 
 @pytest.mark.gpu
@@ -750,15 +751,16 @@ def test_random_configurations_commit_the_same_chain_under_every_schedule():
 
 @pytest.mark.gpu
 def test_sharded_ladder_two_ranks_on_one_gpu():
-    """The multi-GPU driver with a REAL cross-process exchange on real device buffers: two ranks share the one GPU of the box
-    and talk over gloo (RCCL refuses two ranks on one device).  Gathered exchange, point-to-point exchange and the gathered
-    exchange under swap_rule 1 must reproduce the single-process device run bit for bit (tests/dist_device_check2.py)."""
+    """ptnn_run on a sharded ladder with a REAL cross-process exchange on real device buffers: two processes share the one GPU
+    of the box, each owns half of the ladder through the C ABI and they talk through the host-staged transport over gloo (RCCL
+    refuses two ranks on one device).  Gathered exchange, boundary exchange and the gathered exchange under swap_rule 1 must
+    reproduce the single-handle run bit for bit (tests/dist_device_check2.py)."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "dist_device_check2.py")], capture_output=True, text=True, timeout=400)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    for line in ("OK gather rule 0", "OK p2p rule 0", "OK gather rule 1"):
+    for line in ("OK gather rule 0", "OK boundary rule 0", "OK gather rule 1"):
         assert line in r.stdout
 
 
@@ -815,3 +817,23 @@ def test_chains_do_not_depend_on_occupancy(name, topo):
         small = run(128, b)
         for k in big:
             assert np.array_equal(big[k][b:b + 128], small[k]), (b, k)
+
+
+@pytest.mark.gpu
+def test_multi_group_schedule_is_refused_when_not_resident():
+    """The work-groups of one replica wait for each other inside the speculative kernel, so all of them must be resident at
+    once.  The library asks hipOccupancyMaxActiveBlocksPerMultiprocessor for the kernel it is about to launch (its registers,
+    block size and dynamic LDS) and refuses a configuration that cannot be co-resident instead of spinning into a timeout."""
+    import ptnn_amd  # noqa: F401
+    from ptnn_amd import _lib
+    d = ds()
+    ok = parity.make_sampler(0, (4, 10, 1), d["mackey_train"], d["mackey_test"], R_local=64, R_global=64, first=0, S=20, si=5,
+                             use_lg=True, lr=0.1, seed=1, schedule=2, groups=4)
+    info = ok.describe()
+    assert info["schedule"] == "speculative" and info["groups_per_replica"] == 4 and info["grid_blocks"] == 256
+    assert info["blocks_per_cu"] >= 1 and info["scratch_bytes"] >= 0
+    ok.close()
+    too_many = info["blocks_per_cu"] * info["num_cus"] // 4 + 1
+    with pytest.raises(_lib.PtnnError, match="cannot all be resident"):
+        parity.make_sampler(0, (4, 10, 1), d["mackey_train"], d["mackey_test"], R_local=too_many, R_global=too_many, first=0,
+                            S=20, si=5, use_lg=True, lr=0.1, seed=1, schedule=2, groups=4)

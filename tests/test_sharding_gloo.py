@@ -1,9 +1,18 @@
-"""N > 1 path on CPU: the sharded-ladder driver (parallel-tempering-neural-net_amd/distributed.py) over `gloo`,
-world_size 2 and 4, with the oracle as the compute engine behind the shard protocol.  The sharded run must reproduce
-the single-process oracle run bit for bit (results identical for every GPU count at a fixed seed)."""
+"""N > 1 path on CPU (no GPU in this container).  What can run here is everything of the sharded ladder that is host logic:
+
+* `ptnn_route` -- the C routing function of libptnn (which rows cross which GPU boundary) -- against the properties SURVEY 8e
+  states, for permutations the cascade can produce;
+* the two host-staged transports of distributed.py (gloo between processes at world size 2 and 4, ThreadTransport between
+  the threads of one process) moving real bytes in the order the library asks for them;
+* the round protocol of `comm_swap_round` (csrc/ptnn.hip), restated here over the ORACLE as compute engine (`OracleRank`):
+  gathered exchange, boundary exchange (all-gather of L, replicated cascade, routed rows) and the gathered exchange under
+  swap_rule 1 must reproduce the single-process oracle run bit for bit -- results identical for every GPU count at a fixed seed.
+
+The device side of the same protocol is tested on the GPU box (tests/dist_device_check*.py, test_gpu_dropin.py)."""
 import os
 import socket
 import sys
+import threading
 
 import numpy as np
 import pytest
@@ -14,190 +23,182 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import ptnn_oracle as orc  # noqa: E402
 
 
-def _load_distributed():
-    import ptnn_amd
-    from ptnn_amd import distributed
-    return distributed
+def _lib():
+    import __graft_entry__
+    __graft_entry__.build()
+    import ptnn_amd  # noqa: F401
+    from ptnn_amd import _lib
+    return _lib
 
 
 def test_route_is_consistent_between_ranks():
-    dm = _load_distributed()
+    lib = _lib()
     rng = np.random.default_rng(0)
-    for world, Rl in ((2, 2), (4, 4), (8, 32), (8, 128)):
+    for world, Rl in ((2, 2), (4, 4), (8, 32), (8, 128), (1, 8)):
         R = world * Rl
         for _ in range(20):
             # permutations the cascade can produce: bubble pass with random swap decisions
             u = rng.uniform(size=R - 1)
             src, _ = orc.swap_cascade(list(rng.normal(0, 2, R)), u)
-            plans = [dm.route(src, r, world, Rl) for r in range(world)]
-            sent = sorted((r, peer, src_l + r * Rl) for r, (rc, sd) in enumerate(plans) for src_l, peer in sd)
-            recvd = sorted((peer, r, src[dst_l + r * Rl]) for r, (rc, sd) in enumerate(plans) for dst_l, peer in rc)
-            assert sent == recvd                       # every receive has its matching send (same source row)
+            plans = [lib.route(src, Rl, r) for r in range(world)]
+            sent = sorted((r, peer, row + r * Rl, dst) for r, (rc, sd) in enumerate(plans) for row, peer, dst in sd)
+            recvd = sorted((peer, r, src[dst], dst) for r, (rc, sd) in enumerate(plans) for row, peer, dst in rc)
+            assert sent == recvd                       # every receive has its matching send (same source row, same slot)
             for r, (rc, sd) in enumerate(plans):
-                below = [p for _, p in rc if p < r]
-                above = [p for _, p in rc if p > r]
+                assert all(row + r * Rl == dst for row, _, dst in rc)
+                below = [p for _, p, _ in rc if p < r]
+                above = [p for _, p, _ in rc if p > r]
                 assert len(below) <= 1 and len(above) <= 1      # at most one row from below, one from above
                 assert all(p == r + 1 for p in above)
+                assert len([p for _, p, _ in sd if p > r]) <= 1 and len([p for _, p, _ in sd if p < r]) <= 1
             # per ordered pair, both ends list their messages in the same (global destination) order
             for a in range(world):
                 for b in range(world):
-                    if a == b:
-                        continue
-                    s_order = [src_l + a * Rl for src_l, peer in plans[a][1] if peer == b]
-                    r_order = [src[dst_l + b * Rl] for dst_l, peer in plans[b][0] if peer == a]
-                    assert s_order == r_order
+                    if a != b:
+                        assert [d for _, p, d in plans[a][1] if p == b] == [d for _, p, d in plans[b][0] if p == a]
+    with pytest.raises(lib.PtnnError):
+        lib.route([0, 1, 2, 7], 2, 0)
 
 
-class OracleShard:
-    """The shard protocol of distributed.py implemented by oracle replicas (float64, CPU tensors)."""
+class OracleRank:
+    """One rank of a sharded ladder: the round protocol of comm_swap_round (csrc/ptnn.hip) over oracle replicas (float64)."""
 
-    def __init__(self, pt_args, rank, world):
-        import torch
-        self.torch = torch
+    def __init__(self, pt_args, rank, world, transport, mode, lib):
         full = orc.PTOracle(*pt_args["args"], **pt_args["kw"])
+        self.lib, self.rank, self.world, self.mode = lib, rank, world, mode
+        self.all_gather, self.send_recv = transport
         self.task, self.si, self.S, self.tape = full.task, full.si, full.S, full.tape
-        self.R_global = full.R
-        self.R_local = full.R // world
-        self.first = rank * self.R_local
-        self.reps = full.replicas[self.first:self.first + self.R_local]
+        self.R = full.R
+        self.Rl = full.R // world
+        self.first = rank * self.Rl
+        self.reps = full.replicas[self.first:self.first + self.Rl]
         self.P = full.P
         self.PS = self.P + 1
-        self.cur = 0
-        self.rounds_done = 0
-        self.num_swap = 0
-        self.finalized = False
-        self.L = [torch.zeros(self.R_global, dtype=torch.float64), torch.zeros(self.R_global, dtype=torch.float64)]
-        self.rows_cur = torch.zeros(self.R_local, self.PS, dtype=torch.float64)
-        self.rows_next = torch.zeros(self.R_local, self.PS, dtype=torch.float64)
         self.swap_rule = int(pt_args["kw"].get("swap_rule", 0))
         self.temps = list(full.temperatures)
-        self.XS = self.PS + 4                       # gather mode: {w, eta | L handoff | L final | untempered L | prior}
-        self.xchg = torch.zeros(self.R_global * self.XS, dtype=torch.float64)
+        self.rounds_done = self.num_swap = 0
+        self.bytes_rows = 0
+        self.XS = self.PS + 3                       # exchange row: {w, eta | posted L | untempered L | prior}
 
-    def run_segment(self):
-        last = self.S - 1
-        ho = 0
-        if self.cur < last:
-            while self.cur < last:
-                i = self.cur
-                for rep in self.reps:
-                    rep.step(i)
-                self.cur += 1
-                if orc.swap_trigger(self.task, i, self.si):
-                    ho = 1
-                    break
-        if ho == 0 and self.cur == last and not self.finalized:
-            self.finalized = True
-            if self.swap_rule == 0 and int(self.S / self.si) > self.rounds_done:
-                ho = 2
-        for k, rep in enumerate(self.reps):
-            self.L[0][self.first + k] = rep.posted_L()
-            self.L[1][self.first + k] = rep.likelihood
-            self.rows_cur[k, :self.P] = self.torch.from_numpy(np.asarray(rep.w))
-            self.rows_cur[k, self.P] = rep.eta
-        return ho
+    def _gather(self, arr):
+        """arr: float64 [R, width], this rank's rows filled -> all rows filled."""
+        width = arr.shape[1]
+        buf = arr.reshape(self.world, self.Rl * width).view(np.uint8)
+        self.all_gather(buf)
 
-    def sync(self):
-        pass
-
-    def steps_done(self):
-        return self.cur
-
-    def L_tensor(self, phantom):
-        return self.L[1 if phantom else 0]
-
-    def row_tensors(self, local):
-        return self.rows_cur[local], self.rows_next[local]
-
-    # ---- gather mode of the shard protocol ----
-    def xchg_tensor(self):
-        return self.xchg
-
-    def pack(self, phantom):
-        X = self.xchg.view(self.R_global, self.XS)
-        for k in range(self.R_local):
-            X[self.first + k, :self.PS] = self.rows_cur[k]
-            X[self.first + k, self.PS] = self.L[0][self.first + k]
-            X[self.first + k, self.PS + 1] = self.L[1][self.first + k]
-            X[self.first + k, self.PS + 2] = self.reps[k].likelihood * self.reps[k].adapttemp
-            X[self.first + k, self.PS + 3] = self.reps[k].prior_current
-
-    def before_collective(self):
-        pass
-
-    def after_collective(self):
-        pass
-
-    def apply_gathered(self, phantom):
-        X = self.xchg.view(self.R_global, self.XS)
-        if self.swap_rule == 1:                     # even/odd Metropolis exchange on the gathered untempered likelihoods
-            import math
-            R = self.R_global
-            u = self.tape.swap_uniforms(self.rounds_done, R - 1)
-            raw = X[:, self.PS + 2].tolist()
-            src = list(range(R))
-            for k in range(self.rounds_done & 1, R - 1, 2):
-                dd = (1.0 / self.temps[k] - 1.0 / self.temps[k + 1]) * (raw[k + 1] - raw[k])
-                pr = 1.0 if dd != dd else min(1.0, math.exp(min(dd, 80.0)))
-                if u[k] < pr:
-                    src[k], src[k + 1] = k + 1, k
-                    self.num_swap += 1
+    def swap_round(self, phantom):
+        R, Rl, P, PS = self.R, self.Rl, self.P, self.PS
+        posted = [rep.likelihood if phantom else rep.posted_L() for rep in self.reps]
+        u = self.tape.swap_uniforms(self.rounds_done, R - 1)
+        if self.mode == "gather" or self.swap_rule == 1:
+            X = np.zeros((R, self.XS))
             for k, rep in enumerate(self.reps):
-                sg = src[self.first + k]
-                if sg != self.first + k:
-                    row = X[sg]
-                    rep.w = row[:self.P].numpy().copy()
-                    rep.eta = float(row[self.P])
-                    rep.prior_current = float(row[self.PS + 3])
-                    rep.likelihood = float(row[self.PS + 2]) / rep.adapttemp
-            self.rounds_done += 1
-            return
-        L = X[:, self.PS + (1 if phantom else 0)].tolist()
-        u = self.tape.swap_uniforms(self.rounds_done, self.R_global - 1)
-        src, nsw = orc.swap_cascade(L, u)
-        if not phantom:
-            for k, rep in enumerate(self.reps):
-                row = X[int(src[self.first + k])]
-                rep.w = row[:self.P].numpy().copy()
-                rep.eta = float(row[self.P])
-        self.num_swap += nsw
+                row = X[self.first + k]
+                row[:P], row[P], row[PS] = rep.w, rep.eta, posted[k]
+                row[PS + 1], row[PS + 2] = rep.likelihood * rep.adapttemp, rep.prior_current
+            self._gather(X)
+            if self.swap_rule == 1:
+                import math
+                src = list(range(R))
+                for k in range(self.rounds_done & 1, R - 1, 2):
+                    dd = (1.0 / self.temps[k] - 1.0 / self.temps[k + 1]) * (X[k + 1, PS + 1] - X[k, PS + 1])
+                    pr = 1.0 if dd != dd else min(1.0, math.exp(min(dd, 80.0)))
+                    if u[k] < pr:
+                        src[k], src[k + 1] = k + 1, k
+                        self.num_swap += 1
+                for k, rep in enumerate(self.reps):
+                    sg = src[self.first + k]
+                    if sg != self.first + k:
+                        rep.w, rep.eta = X[sg, :P].copy(), float(X[sg, P])
+                        rep.prior_current = float(X[sg, PS + 2])
+                        rep.likelihood = float(X[sg, PS + 1]) / rep.adapttemp
+            else:
+                src, nsw = orc.swap_cascade(X[:, PS].tolist(), u)
+                if not phantom:
+                    for k, rep in enumerate(self.reps):
+                        sg = int(src[self.first + k])
+                        rep.w, rep.eta = X[sg, :P].copy(), float(X[sg, P])
+                self.num_swap += nsw
+        else:                                               # boundary exchange
+            L = np.zeros((R, 1))
+            L[self.first:self.first + Rl, 0] = posted
+            self._gather(L)
+            src, nsw = orc.swap_cascade(L[:, 0].tolist(), u)
+            if not phantom:
+                cur = np.stack([np.concatenate([rep.w, [rep.eta]]) for rep in self.reps])
+                nxt = np.zeros_like(cur)
+                recvs, sends = self.lib.route(src, Rl, self.rank)
+                msgs = sorted([(dst, peer, False, nxt[row].view(np.uint8)) for row, peer, dst in recvs] +
+                              [(dst, peer, True, cur[row].view(np.uint8)) for row, peer, dst in sends])
+                if msgs:
+                    self.send_recv([(peer, is_send, buf) for _, peer, is_send, buf in msgs])
+                    self.bytes_rows += 8 * PS * len(msgs)
+                for k in range(Rl):
+                    sl = int(src[self.first + k]) - self.first
+                    if 0 <= sl < Rl:
+                        nxt[k] = cur[sl]
+                for k, rep in enumerate(self.reps):
+                    rep.w, rep.eta = nxt[k, :P].copy(), float(nxt[k, P])
+            self.num_swap += nsw
         self.rounds_done += 1
 
-    def swap_cascade(self, phantom):
-        L = self.L[1 if phantom else 0].tolist()
-        u = self.tape.swap_uniforms(self.rounds_done, self.R_global - 1)
-        src, nsw = orc.swap_cascade(L, u)
-        self._nsw = nsw
-        return np.array(src, dtype=np.int32)
+    def run(self):                                          # the loop of ptnn_run
+        for i in range(self.S - 1):
+            for rep in self.reps:
+                rep.step(i)
+            if orc.swap_trigger(self.task, i, self.si):
+                self.swap_round(False)
+        if self.swap_rule == 0 and int(self.S / self.si) > self.rounds_done:
+            self.swap_round(True)
+        return self
 
-    def swap_apply(self, src, phantom):
-        if not phantom:
-            for k in range(self.R_local):
-                sl = int(src[self.first + k]) - self.first
-                if 0 <= sl < self.R_local:
-                    self.rows_next[k] = self.rows_cur[sl]
-            for k, rep in enumerate(self.reps):
-                rep.w = self.rows_next[k, :self.P].numpy().copy()
-                rep.eta = float(self.rows_next[k, self.P])
-        self.num_swap += self._nsw
-        self.rounds_done += 1
+    def result(self):
+        return dict(pos_w=np.stack([r.pos_w for r in self.reps]), accept=np.stack([r.accept_list for r in self.reps]),
+                    likeh=np.stack([r.likeh for r in self.reps]), rmse=np.stack([r.rmse_train for r in self.reps]),
+                    num_swap=self.num_swap, rounds=self.rounds_done, bytes_rows=self.bytes_rows)
 
 
-def _worker(rank, world, port, pt_args, outdir, mode="gather"):
+def _case(datasets, task, rule):
+    if task == orc.TASK_REG:
+        args = (task, (4, 5, 1), datasets["sunspot_train"], datasets["sunspot_test"], 8, 2, 8 * 43, 5)
+        kw = dict(use_lg=True, l_prob=0.5, lr=0.1, seed=31)        # S = 43: no phantom; hand-offs at i = 5..40
+    else:
+        args = (task, (4, 12, 3), datasets["iris_train"], datasets["iris_test"], 8, 10, 8 * 40, 5)
+        kw = dict(use_lg=False, l_prob=0.5, lr=0.01, seed=32)      # S = 40: S % si == 0 -> phantom round
+    if rule:
+        kw["swap_rule"] = 1
+    return dict(args=args, kw=kw)
+
+
+def _check(results, ref, world, mode):
+    Rl = 8 // world
+    rows = 0
+    for rank, z in enumerate(results):
+        for k in range(Rl):
+            rep = ref.replicas[rank * Rl + k]
+            assert (z["pos_w"][k] == rep.pos_w).all()
+            assert (z["accept"][k] == rep.accept_list).all()
+            assert (z["likeh"][k] == rep.likeh).all()
+            assert (z["rmse"][k] == rep.rmse_train).all()
+        assert int(z["num_swap"]) == ref.num_swap and int(z["rounds"]) == ref.rounds_done
+        rows += int(z["bytes_rows"])
+    assert ref.num_swap > 0
+    if mode == "boundary":
+        # something crossed a shard boundary, and never more than two rows in + two rows out per rank per round
+        assert 0 < rows <= ref.rounds_done * world * 4 * 8 * (ref.P + 1)
+
+
+def _worker(rank, world, port, pt_args, outdir, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
     import torch.distributed as dist
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    dm = _load_distributed()
-    shard = OracleShard(pt_args, rank, world)
-    lad = dm.ShardedLadder(shard, rank, world, dist, mode=mode)
-    lad.run_intervals(None)
-    np.savez(os.path.join(outdir, f"rank{rank}.npz"),
-             pos_w=np.stack([r.pos_w for r in shard.reps]), accept=np.stack([r.accept_list for r in shard.reps]),
-             likeh=np.stack([r.likeh for r in shard.reps]), rmse=np.stack([r.rmse_train for r in shard.reps]),
-             num_swap=shard.num_swap, rounds=shard.rounds_done, bytes_moved=lad.bytes_moved)
+    lib = _lib()
+    from ptnn_amd import distributed as dm
+    r = OracleRank(pt_args, rank, world, dm.gloo_transport(dist), mode, lib).run()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **r.result())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -210,36 +211,41 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,task,mode", [(2, orc.TASK_REG, "gather"), (4, orc.TASK_CLS, "gather"),
-                                             (2, orc.TASK_REG, "p2p"), (4, orc.TASK_CLS, "p2p"), (4, orc.TASK_REG, "gather-rule1")])
-def test_sharded_ladder_matches_single_process(tmp_path, datasets, world, task, mode):
+CASES = [(2, orc.TASK_REG, "gather", 0), (4, orc.TASK_CLS, "gather", 0), (2, orc.TASK_REG, "boundary", 0),
+         (4, orc.TASK_CLS, "boundary", 0), (4, orc.TASK_REG, "gather", 1)]
+
+
+@pytest.mark.parametrize("world,task,mode,rule", CASES)
+def test_sharded_ladder_over_gloo_matches_single_process(tmp_path, datasets, world, task, mode, rule):
     import torch.multiprocessing as mp
-    if task == orc.TASK_REG:
-        args = (task, (4, 5, 1), datasets["sunspot_train"], datasets["sunspot_test"], 8, 2, 8 * 43, 5)
-        kw = dict(use_lg=True, l_prob=0.5, lr=0.1, seed=31)        # S = 43: no phantom; hand-offs at i = 5..40
-    else:
-        args = (task, (4, 12, 3), datasets["iris_train"], datasets["iris_test"], 8, 10, 8 * 40, 5)
-        kw = dict(use_lg=False, l_prob=0.5, lr=0.01, seed=32)      # S = 40: S % si == 0 -> phantom round
-    if mode == "gather-rule1":
-        kw["swap_rule"] = 1
-        mode = "gather"
-    pt_args = dict(args=args, kw=kw)
-    ref = orc.PTOracle(*args, **kw).run()
+    pt_args = _case(datasets, task, rule)
+    ref = orc.PTOracle(*pt_args["args"], **pt_args["kw"]).run()
     mp.spawn(_worker, args=(world, _free_port(), pt_args, str(tmp_path), mode), nprocs=world, join=True)
-    Rl = 8 // world
-    moved = 0
-    for rank in range(world):
-        z = np.load(tmp_path / f"rank{rank}.npz")
-        for k in range(Rl):
-            rep = ref.replicas[rank * Rl + k]
-            assert (z["pos_w"][k] == rep.pos_w).all()
-            assert (z["accept"][k] == rep.accept_list).all()
-            assert (z["likeh"][k] == rep.likeh).all()
-            assert (z["rmse"][k] == rep.rmse_train).all()
-        assert int(z["num_swap"]) == ref.num_swap and int(z["rounds"]) == ref.rounds_done
-        moved += int(z["bytes_moved"])
-    assert ref.num_swap > 0
-    # something actually crossed a shard boundary, and never more than two rows in + two rows out per rank per round
-    assert moved > 0
-    if mode == "p2p":
-        assert moved <= ref.rounds_done * world * 4 * 4 * (ref.P + 1)
+    _check([np.load(tmp_path / f"rank{rank}.npz") for rank in range(world)], ref, world, mode)
+
+
+@pytest.mark.parametrize("world,task,mode,rule", CASES + [(8, orc.TASK_REG, "boundary", 0)])
+def test_sharded_ladder_over_thread_transport_matches_single_process(datasets, world, task, mode, rule):
+    """The same protocol between the threads of one process: the transport `ParallelTempering(devices=[...])` falls back to
+    when a device is listed twice."""
+    lib = _lib()
+    from ptnn_amd import distributed as dm
+    pt_args = _case(datasets, task, rule)
+    ref = orc.PTOracle(*pt_args["args"], **pt_args["kw"]).run()
+    tt = dm.ThreadTransport(world)
+    ranks = [OracleRank(pt_args, r, world, tt.callbacks(r), mode, lib) for r in range(world)]
+    errs = []
+
+    def go(r):
+        try:
+            r.run()
+        except Exception as e:                               # noqa: BLE001
+            errs.append(e)
+            tt._barrier.abort()
+    th = [threading.Thread(target=go, args=(r,)) for r in ranks]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    _check([r.result() for r in ranks], ref, world, mode)
