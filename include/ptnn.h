@@ -194,6 +194,11 @@ int ptnn_stream(ptnn_handle *h, void **hip_stream);
  * rmse_* / acc_* [R,nsteps] (REG:403-423); accept_count [R,nsteps] = accept_list (REG:380). */
 int ptnn_get_traces(ptnn_handle *h, int step0, int nsteps, float *pos_w, float *likeh, float *rmse_train,
                     float *rmse_test, float *acc_train, float *acc_test, int32_t *accept_count);
+/* The scalar trace rows as the device keeps them, rows [R, nsteps, 8] float32: {likeh, rmse_train, rmse_test, acc_train,
+ * acc_test, accept_count (int32 bits), log alpha of the step as the kernel computed it (REG:372: diff_likelihood + diff_prior +
+ * diff_prop; diagnostic, the parity tests measure the fp32 error of the MH decision with it), 0}.  Does not mark rows as
+ * fetched.  Same range rules as ptnn_get_traces. */
+int ptnn_get_trace_rows(ptnn_handle *h, int step0, int nsteps, float *rows);
 /* num_swap / total_swap_proposals (REG:501-502, 680-688) */
 int ptnn_get_swap_stats(ptnn_handle *h, int64_t *num_swap, int64_t *total_proposals, int32_t *rounds_done);
 /* src permutation of every completed round, [rounds, R_global] (tests) */

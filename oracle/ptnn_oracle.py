@@ -290,6 +290,7 @@ class Replica:
         self.w = np.array(w0, dtype=np.float64)
         self.pt_samples = S * 0.6
         self.init_count = 0
+        self.lik_stale = False                             # Q12: (w, eta) arrived through a swap, likelihood / prior still the old state's
         I = topo[0]
         self.y_train, self.y_test = train[:, I], test[:, I]
         if task == TASK_REG:                               # R14 (REG:266-285)
@@ -317,6 +318,7 @@ class Replica:
             self.adapttemp = 1
             self.likelihood = self._lik(self.train, self.w, self.tau_pro)[0]
             self.init_count = 1
+            self.lik_stale = False                          # re-evaluated on the current w (the prior is not: REG:322-324)
         lx, u, n_eta = self.tape.step_scalars(self.noise_gid, i)
         noise = self.tape.w_noise(self.noise_gid, i, self.P)
         if self.use_lg and lx < self.l_prob:
@@ -354,8 +356,13 @@ class Replica:
         self.likeh[i + 1, 0] = lik_prop if self.task == TASK_REG else lik_prop * self.adapttemp
         self.last_logalpha = diff_likelihood + diff_prior + diff_prop
         self.last_u = u
+        self.last_stale = self.lik_stale
+        # size of the terms log alpha is the small difference of (the parity tests state fp32 error bounds relative to it)
+        self.last_scale = (abs(lik_prop) + abs(self.likelihood) + abs(prior_prop) + abs(self.prior_current) +
+                           ((abs(first) + abs(second)) / self.adapttemp if diff_prop != 0 else 0.0))
         if u < mh_prob:
             self.num_accepted += 1
+            self.lik_stale = False
             self.likelihood = lik_prop
             self.prior_current = prior_prop
             self.w = w_proposal
@@ -410,6 +417,7 @@ class PTOracle:
         self.total_swap_proposals = 0
         self.rounds_done = 0
         self.src_log = []
+        self.L_log = []                                     # the scalars every round decided on (swap_rule 0)
 
     def swap_round_even_odd(self):
         """Option swap_rule = 1, parity unpinned: the reference has no such rule; this restates the textbook
@@ -453,12 +461,15 @@ class PTOracle:
         self.total_swap_proposals += R - 1
         self.rounds_done += 1
         self.src_log.append(list(src))
+        self.L_log.append([float(v) for v in L])
         if apply:                                           # R11/Q12: only (w, eta) move; likelihood/prior stay stale
             ws = [rep.w for rep in self.replicas]
             etas = [rep.eta for rep in self.replicas]
             for k, rep in enumerate(self.replicas):
                 rep.w = ws[src[k]]
                 rep.eta = etas[src[k]]
+                if src[k] != k:
+                    rep.lik_stale = True
         return src
 
     def run(self):

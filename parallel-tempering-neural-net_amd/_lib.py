@@ -74,6 +74,7 @@ SYMBOLS = {
     "ptnn_swap_pack": (C.c_int, [C.c_void_p, C.c_int]),
     "ptnn_swap_apply_gathered": (C.c_int, [C.c_void_p, C.c_int]),
     "ptnn_get_traces": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _ip]),
+    "ptnn_get_trace_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp]),
     "ptnn_get_swap_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _ip]),
     "ptnn_get_swap_log": (C.c_int, [C.c_void_p, _ip, C.c_int]),
     "ptnn_get_state": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _ip, _ip, _ip]),
@@ -307,6 +308,13 @@ class Sampler:
                                              _ptr(out["rmse_train"]), _ptr(out["rmse_test"]), _ptr(out["acc_train"]),
                                              _ptr(out["acc_test"]), _ptr(out["accept"], _ip)))
         return out
+
+    def log_alpha(self, step0=0, nsteps=None):
+        """log alpha of MH steps step0 .. step0+nsteps-1 as the kernel computed it, [R, nsteps] (row i + 1 belongs to step i)."""
+        n = self.S - 1 - step0 if nsteps is None else nsteps
+        rows = np.empty((self.R, n, 8), np.float32)
+        self._check(self.lib.ptnn_get_trace_rows(self.h, step0 + 1, n, _ptr(rows)))
+        return rows[:, :, 6].copy()
 
     def swap_stats(self):
         a, b, r = C.c_int64(), C.c_int64(), C.c_int32()

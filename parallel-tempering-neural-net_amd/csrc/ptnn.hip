@@ -68,7 +68,7 @@ struct ptnn_handle {
     ptnn_config cfg{};
     const Shape* shape = nullptr;
     hipStream_t stream = nullptr;
-    int P = 0, PS = 0, IPY = 0, FWS = 0, Ntr = 0, Nte = 0, nthreads = 64;
+    int P = 0, PS = 0, PW = 0, IPY = 0, FWS = 0, Ntr = 0, Nte = 0, nthreads = 64;
     size_t seg_lds = 0, model_lds = 0;
     int model_threads = 64;
     bool speculative = false;
@@ -83,7 +83,7 @@ struct ptnn_handle {
     int blocks_per_cu = 0;          // occupancy of the segment kernel as the runtime reports it (0 = not queried)
     unsigned epoch_base = 0;
     int num_cus = 0;
-    unsigned long long *d_xslots = nullptr, *d_xw = nullptr;
+    unsigned long long *d_xslots = nullptr, *d_xw = nullptr, *d_xverdict = nullptr;
     int* d_error = nullptr;
     unsigned long long* d_stamps = nullptr;
     bool have_data = false, have_state = false, finalized = false;
@@ -104,9 +104,8 @@ struct ptnn_handle {
     float *d_L_handoff = nullptr, *d_L_final = nullptr;
     float *d_L_raw = nullptr, *d_prior_post = nullptr, *d_temps_global = nullptr;   // swap_rule 1
     bool have_ladder = false;
-    float *d_pos_w = nullptr, *d_likeh = nullptr, *d_rmse_tr = nullptr, *d_rmse_te = nullptr, *d_acc_tr = nullptr,
-          *d_acc_te = nullptr;
-    int* d_accept = nullptr;
+    float *d_pos_w = nullptr;       // [Rl][cap][PW]
+    float *d_scal = nullptr;        // [Rl][cap][TR_COUNT] scalar trace rows
     int *d_src = nullptr, *d_src_log = nullptr;
     int* h_src = nullptr;
     float* d_xchg = nullptr;                                // [R_global][XS] exchange rows of the gathered sharding mode                                   // pinned staging for the permutation of a round (sharded ladder)
@@ -141,9 +140,8 @@ struct ptnn_handle {
         p.st_f = d_st_f; p.st_i = d_st_i; p.temps = d_temps;
         p.L_handoff = d_L_handoff; p.L_final = d_L_final;
         p.L_raw = (cfg.swap_rule == 1) ? d_L_raw : nullptr; p.prior_post = d_prior_post;
-        p.tr_pos_w = d_pos_w; p.tr_likeh = d_likeh; p.tr_rmse_tr = d_rmse_tr; p.tr_rmse_te = d_rmse_te;
-        p.tr_acc_tr = d_acc_tr; p.tr_acc_te = d_acc_te; p.tr_accept = d_accept;
-        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.noise_shared = cfg.shared_noise ? 1 : 0; p.pk_nred = pk_nred; p.xt = d_xt; p.Npad = Npad; p.fw_mfma = fw_mfma ? 1 : 0; p.forward_bf16 = cfg.forward_bf16;
+        p.tr_pos_w = d_pos_w; p.tr_scal = d_scal; p.PW = PW;
+        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.xverdict = d_xverdict; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.noise_shared = cfg.shared_noise ? 1 : 0; p.pk_nred = pk_nred; p.xt = d_xt; p.Npad = Npad; p.fw_mfma = fw_mfma ? 1 : 0; p.forward_bf16 = cfg.forward_bf16;
         return p;
     }
 };
@@ -271,6 +269,7 @@ int create_buffers(ptnn_handle* h, const ptnn_config* cfg, const Shape* sh, cons
     const int I = cfg->n_in, H = cfg->n_hidden, O = cfg->n_out;
     h->P = I * H + H * O + H + O;
     h->PS = round_up4(h->P + 1);
+    h->PW = (h->P + 15) & ~15;                             // pos_w trace rows: whole 64-byte sectors
     h->IPY = round_up4(I + 2);                             // x[I], y, then 1 + x[n].x[n-1] for the pipelined SGD epoch
     h->FWS = round_up4(I + 1 + O);
     h->max_rounds = cfg->n_samples / cfg->swap_interval + 2;
@@ -292,13 +291,8 @@ int create_buffers(ptnn_handle* h, const ptnn_config* cfg, const Shape* sh, cons
     HIP_TRY(hipMalloc(&h->d_L_raw, R * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_prior_post, R * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_temps_global, R * sizeof(float)));
-    HIP_TRY(hipMalloc(&h->d_pos_w, Rl * S * h->P * sizeof(float)));
-    HIP_TRY(hipMalloc(&h->d_likeh, Rl * S * sizeof(float)));
-    HIP_TRY(hipMalloc(&h->d_rmse_tr, Rl * S * sizeof(float)));
-    HIP_TRY(hipMalloc(&h->d_rmse_te, Rl * S * sizeof(float)));
-    HIP_TRY(hipMalloc(&h->d_acc_tr, Rl * S * sizeof(float)));
-    HIP_TRY(hipMalloc(&h->d_acc_te, Rl * S * sizeof(float)));
-    HIP_TRY(hipMalloc(&h->d_accept, Rl * S * sizeof(int)));
+    HIP_TRY(hipMalloc(&h->d_pos_w, Rl * S * h->PW * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->d_scal, Rl * S * TR_COUNT * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_src, R * sizeof(int)));
     HIP_TRY(hipHostMalloc(&h->h_src, R * sizeof(int), hipHostMallocDefault));
     HIP_TRY(hipMalloc(&h->d_xchg, (size_t)R * xchg_row_floats(h->PS) * sizeof(float)));
@@ -374,8 +368,7 @@ int ptnn_destroy(ptnn_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->comm.release();
     void* ptrs[] = {h->d_data, h->d_state[0], h->d_state[1], h->d_rec_w, h->d_gd_w[0], h->d_gd_w[1], h->d_gd_valid[0], h->d_gd_valid[1], h->d_st_f, h->d_st_i, h->d_temps,
-                    h->d_L_handoff, h->d_L_final, h->d_L_raw, h->d_prior_post, h->d_temps_global, h->d_pos_w, h->d_likeh, h->d_rmse_tr, h->d_rmse_te, h->d_acc_tr,
-                    h->d_acc_te, h->d_accept, h->d_src, h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_stamps, h->d_wide_scratch, h->d_xt};
+                    h->d_L_handoff, h->d_L_final, h->d_L_raw, h->d_prior_post, h->d_temps_global, h->d_pos_w, h->d_scal, h->d_src, h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_xverdict, h->d_stamps, h->d_wide_scratch, h->d_xt};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_src) (void)hipHostFree(h->h_src);
@@ -524,12 +517,15 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
             }
             if (h->d_xslots) { HIP_TRY(hipFree(h->d_xslots)); h->d_xslots = nullptr; }
             if (h->d_xw) { HIP_TRY(hipFree(h->d_xw)); h->d_xw = nullptr; }
+            if (h->d_xverdict) { HIP_TRY(hipFree(h->d_xverdict)); h->d_xverdict = nullptr; }
             if (G > 1) {
                 const size_t ns = (size_t)Rl * 2 * MAX_SLOTS * SL_COUNT, nx = (size_t)Rl * 2 * MAX_SLOTS * 2 * h->PS;
                 HIP_TRY(hipMalloc(&h->d_xslots, ns * sizeof(unsigned long long)));
                 HIP_TRY(hipMalloc(&h->d_xw, nx * sizeof(unsigned long long)));
                 HIP_TRY(hipMemset(h->d_xslots, 0, ns * sizeof(unsigned long long)));
                 HIP_TRY(hipMemset(h->d_xw, 0, nx * sizeof(unsigned long long)));
+                HIP_TRY(hipMalloc(&h->d_xverdict, (size_t)Rl * 2 * MAX_SLOTS * sizeof(unsigned long long)));
+                HIP_TRY(hipMemset(h->d_xverdict, 0, (size_t)Rl * 2 * MAX_SLOTS * sizeof(unsigned long long)));
                 h->epoch_base = 1;                              // tag 0 = never written
             }
         }
@@ -573,18 +569,15 @@ int ptnn_set_state(ptnn_handle* h, const float* w0, const float* temperatures) {
     HIP_TRY(hipMemset(h->d_st_f, 0, (size_t)Rl * SF_COUNT * sizeof(float)));
     HIP_TRY(hipMemset(h->d_st_i, 0, (size_t)Rl * SI_COUNT * sizeof(int)));
     HIP_TRY(hipMemcpy(h->d_temps, temperatures, Rl * sizeof(float), hipMemcpyHostToDevice));
-    // row 0 of every trace (Q7): pos_w = 1, likeh = -100, the rest 0
-    HIP_TRY(hipMemset(h->d_rmse_tr, 0, (size_t)Rl * S * sizeof(float)));
-    HIP_TRY(hipMemset(h->d_rmse_te, 0, (size_t)Rl * S * sizeof(float)));
-    HIP_TRY(hipMemset(h->d_acc_tr, 0, (size_t)Rl * S * sizeof(float)));
-    HIP_TRY(hipMemset(h->d_acc_te, 0, (size_t)Rl * S * sizeof(float)));
-    HIP_TRY(hipMemset(h->d_accept, 0, (size_t)Rl * S * sizeof(int)));
-    HIP_TRY(hipMemset(h->d_likeh, 0, (size_t)Rl * S * sizeof(float)));
-    // one strided copy per trace instead of one small copy per replica (a whole-run restart is part of the benchmark's timed region)
-    std::vector<float> m100((size_t)Rl, -100.0f);
-    HIP_TRY(hipMemcpy2D(h->d_pos_w, (size_t)S * P * sizeof(float), ones.data(), (size_t)PS * sizeof(float), (size_t)P * sizeof(float), Rl,
+    // row 0 of every trace (Q7): pos_w = 1, likeh = -100, the rest 0.  One strided copy per trace instead of one small copy
+    // per replica (a whole-run restart is part of the benchmark's timed region)
+    HIP_TRY(hipMemset(h->d_scal, 0, (size_t)Rl * S * TR_COUNT * sizeof(float)));
+    std::vector<float> row0((size_t)Rl * TR_COUNT, 0.0f);
+    for (int r = 0; r < Rl; ++r) row0[(size_t)r * TR_COUNT + TR_LIKEH] = -100.0f;
+    HIP_TRY(hipMemcpy2D(h->d_pos_w, (size_t)S * h->PW * sizeof(float), ones.data(), (size_t)PS * sizeof(float), (size_t)P * sizeof(float), Rl,
                         hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy2D(h->d_likeh, (size_t)S * sizeof(float), m100.data(), sizeof(float), sizeof(float), Rl, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy2D(h->d_scal, (size_t)S * TR_COUNT * sizeof(float), row0.data(), TR_COUNT * sizeof(float), TR_COUNT * sizeof(float), Rl,
+                        hipMemcpyHostToDevice));
     h->flip = 0; h->cur = 0; h->rounds_done = 0; h->finalized = false; h->drained = 0; h->first_row = 0;
     HIP_TRY(hipMemset(h->d_counters, 0, 2 * sizeof(long long)));
     h->have_state = true;
@@ -917,14 +910,59 @@ int ptnn_get_traces(ptnn_handle* h, int step0, int nsteps, float* pos_w, float* 
         }
         return hipSuccess;
     };
-    HIP_TRY(copy2d(pos_w, h->d_pos_w, sizeof(float), P));
-    HIP_TRY(copy2d(likeh, h->d_likeh, sizeof(float), 1));
-    HIP_TRY(copy2d(rmse_train, h->d_rmse_tr, sizeof(float), 1));
-    HIP_TRY(copy2d(rmse_test, h->d_rmse_te, sizeof(float), 1));
-    HIP_TRY(copy2d(acc_train, h->d_acc_tr, sizeof(float), 1));
-    HIP_TRY(copy2d(acc_test, h->d_acc_te, sizeof(float), 1));
-    HIP_TRY(copy2d(accept_count, h->d_accept, sizeof(int), 1));
+    if (pos_w) {
+        // device rows are padded to PW floats (whole sectors); the caller's array is dense: one strided copy per replica
+        // and ring piece
+        const size_t PW = h->PW;
+        for (int r = 0; r < Rl; ++r) {
+            int done = 0;
+            while (done < nsteps) {
+                const int slot = (step0 + done) % cap;
+                const int n = std::min(nsteps - done, cap - slot);
+                HIP_TRY(hipMemcpy2D(pos_w + ((size_t)r * nsteps + done) * P, (size_t)P * sizeof(float),
+                                    h->d_pos_w + ((size_t)r * cap + slot) * PW, PW * sizeof(float), (size_t)P * sizeof(float), n,
+                                    hipMemcpyDeviceToHost));
+                done += n;
+            }
+        }
+    }
+    if (likeh || rmse_train || rmse_test || acc_train || acc_test || accept_count) {
+        // the scalars of a step sit in one 32-byte row on the device (one sector per step instead of seven); the per-file
+        // arrays of the reference's layout (REG:454-481) are split out here
+        std::vector<float> rows((size_t)Rl * nsteps * TR_COUNT);
+        HIP_TRY(copy2d(rows.data(), h->d_scal, sizeof(float), TR_COUNT));
+        float* outs[5] = {likeh, rmse_train, rmse_test, acc_train, acc_test};
+        const int cols[5] = {TR_LIKEH, TR_RMSE_TR, TR_RMSE_TE, TR_ACC_TR, TR_ACC_TE};
+        const size_t n = (size_t)Rl * nsteps;
+        for (int c = 0; c < 5; ++c)
+            if (outs[c])
+                for (size_t k = 0; k < n; ++k) outs[c][k] = rows[k * TR_COUNT + cols[c]];
+        if (accept_count)
+            for (size_t k = 0; k < n; ++k) std::memcpy(&accept_count[k], &rows[k * TR_COUNT + TR_ACCEPT], sizeof(int32_t));
+    }
     h->drained = std::max(h->drained, step0 + nsteps - 1);
+    return 0;
+}
+
+int ptnn_get_trace_rows(ptnn_handle* h, int step0, int nsteps, float* rows) {
+    if (int rc = check_ready(h)) return rc;
+    if (!rows) return fail(-1, "null argument");
+    const int S = h->cfg.n_samples, Rl = h->cfg.n_replicas_local, cap = h->cap;
+    if (step0 < 0 || nsteps < 1 || step0 + nsteps > S) return fail(-1, "trace range [%d, %d) outside [0, %d)", step0, step0 + nsteps, S);
+    if (step0 + nsteps > h->cur + 1) return fail(-1, "rows up to %d requested but only %d MH steps have been queued", step0 + nsteps - 1, h->cur);
+    if (step0 < h->first_row || step0 < h->cur + 1 - cap) return fail(-1, "row %d is no longer (or was never) on this device", step0);
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t rowb = TR_COUNT * sizeof(float);
+    int done = 0;
+    while (done < nsteps) {                                  // the range may wrap around the ring
+        const int slot = (step0 + done) % cap;
+        const int n = std::min(nsteps - done, cap - slot);
+        HIP_TRY(hipMemcpy2D(reinterpret_cast<char*>(rows) + (size_t)done * rowb, (size_t)nsteps * rowb,
+                            reinterpret_cast<const char*>(h->d_scal) + (size_t)slot * rowb, (size_t)cap * rowb, (size_t)n * rowb, Rl,
+                            hipMemcpyDeviceToHost));
+        done += n;
+    }
     return 0;
 }
 

@@ -30,6 +30,18 @@ constexpr uint32_t STREAM_STEP = 0, STREAM_WNOISE = 1, STREAM_SWAP = 2, STREAM_I
 // per-replica float state (st_f) and int state (st_i) slots
 enum { SF_LIK = 0, SF_PRIOR, SF_TAU_LAST, SF_REC_RMSE_TR, SF_REC_RMSE_TE, SF_REC_ACC_TR, SF_REC_ACC_TE, SF_COUNT = 8 };
 enum { SI_NACC = 0, SI_UNUSED, SI_LG_COUNT, SI_LG_ACC, SI_COUNT = 4 };   // accepted steps, -, Langevin steps proposed / accepted
+// scalar trace row of MH step i (row i + 1): what the per-chain result files need beside pos_w (REG:454-481) -- likeh_list
+// column 0 (REG:391 / CLS:404), rmse_train, rmse_test, acc_train, acc_test, accept_list (the count BEFORE the step, REG:380, as
+// int bits) -- plus the step's log alpha as the kernel computed it (diagnostic: the parity tests measure its fp32 error with it)
+enum { TR_LIKEH = 0, TR_RMSE_TR, TR_RMSE_TE, TR_ACC_TR, TR_ACC_TE, TR_ACCEPT, TR_LOGALPHA, TR_PAD, TR_COUNT = 8 };
+
+// one lane writes the whole row: two 16-byte stores into one 32-byte sector
+__device__ __forceinline__ void store_trace_row(float* __restrict__ row, float likeh, float rm_tr, float rm_te, float ac_tr, float ac_te,
+                                                int accept_before, float logalpha) {
+    float4* q = reinterpret_cast<float4*>(row);
+    q[0] = make_float4(likeh, rm_tr, rm_te, ac_tr);
+    q[1] = make_float4(ac_te, __int_as_float(accept_before), logalpha, 0.0f);
+}
 
 struct SegParams {
     int H, P, PS;            // hidden units, parameters, state row length (P + 1 rounded up to 4)
@@ -55,14 +67,14 @@ struct SegParams {
     float* L_final;          // [Rglobal] end-of-chain scalar (REG:442 / CLS:451)
     float* L_raw;            // [Rglobal] untempered log-likelihood of the current state (swap_rule 1 only)
     float* prior_post;       // [Rglobal] prior of the current state (swap_rule 1 only)
-    float* tr_pos_w;         // [Rl][S][P]
-    float* tr_likeh;         // [Rl][S]
-    float* tr_rmse_tr; float* tr_rmse_te; float* tr_acc_tr; float* tr_acc_te;   // [Rl][S]
-    int* tr_accept;          // [Rl][S]
+    float* tr_pos_w;         // [Rl][S][PW]: pos_w rows padded to whole 64-byte sectors (pad written as zeros: no partial-sector writes)
+    int PW;                  // P rounded up to 16 floats
+    float* tr_scal;          // [Rl][S][TR_COUNT]: the scalars of a step in ONE 32-byte row (one sector instead of seven)
     // speculative schedule across G work-groups (CUs) per replica
     int G;                   // work-groups per replica (1 = no cross-CU exchange)
     unsigned epoch_base;     // granule tags of this launch are epoch_base + round
-    unsigned long long* xslots;   // [Rl][2][MAX_SLOTS][16] result granules
+    unsigned long long* xverdict; // [Rl][2][MAX_SLOTS] one {tag, accepted?} granule per slot and round: all a foreign group polls
+    unsigned long long* xslots;   // [Rl][2][MAX_SLOTS][16] result granules of an ACCEPTED slot (read by the other groups at commit)
     unsigned long long* xw;       // [Rl][2][MAX_SLOTS][2 PS] accepted-proposal granules
     int* error_flag;         // != 0 after a launch: a bounded spin expired
     unsigned long long* stamps;   // diagnostic build only (PTNN_STAMPS): cycle sums per phase, else unused
@@ -523,20 +535,34 @@ __device__ __forceinline__ void sgd_sweep_select(const float* w_in, float* w_out
     else if (H <= 32) sgd_sweep<TASK, I, O, 5>(w_in, w_out, xy, gdata, Ntr, H, lr);
     else sgd_sweep<TASK, I, O, 6>(w_in, w_out, xy, gdata, Ntr, H, lr);
 }
-// wide input layers keep ~2 I + 40 registers per lane inside the epoch; inlined into the segment kernels (twice, five lane-group
-// variants each) that pressure spills the kernels' own loop state even in runs that never take a Langevin step (rocprofv3:
-// 2.9x the algorithmic HBM writes on the Ionosphere workload came from scratch).  An epoch is 10^5 cycles: a real call costs
-// nothing.
+// The epoch is called out of line from the cooperative and the multi-CU speculative kernels: inlined (twice, four lane-group
+// variants each) its registers pushed the kernels' own loop state into scratch even in runs that never take a Langevin step --
+// rocprofv3 WRITE_SIZE: 2.9x the algorithmic bytes on the Ionosphere workload, 2.1x on Iris (51 VGPRs spilled, 208 B of
+// scratch per lane written back every launch), 24 spilled VGPRs in the Mackey-Glass kernel.  An epoch is 10^4..10^5 cycles: a
+// real call costs nothing.  The 4-H-1 time-series nets with H <= 16 are the exception: their row loop is the hand-scheduled
+// asm with fixed physical registers, some of them callee-saved in the AMDGPU calling convention (v40-v47, v56-v63, s36-s72),
+// which a callee would have to save to a stack frame -- that loop stays inline (it needs 27 VGPRs, no spill comes from it), only
+// the wider lane groups (H > 16) go through the call.  The packed kernel always inlines its lane-group variant.
 template <int TASK, int I, int O>
 __device__ __attribute__((noinline)) void sgd_sweep_call(const float* w_in, float* w_out, const float* xy, const float* gdata,
                                                          int Ntr, int H, float lr) {
-    sgd_sweep_select<TASK, I, O>(w_in, w_out, xy, gdata, Ntr, H, lr);
+    if constexpr (TASK == TASK_REG && I == 4 && O == 1) {
+        if (H <= 32) sgd_sweep<TASK, I, O, 5>(w_in, w_out, xy, gdata, Ntr, H, lr);
+        else sgd_sweep<TASK, I, O, 6>(w_in, w_out, xy, gdata, Ntr, H, lr);
+    } else {
+        sgd_sweep_select<TASK, I, O>(w_in, w_out, xy, gdata, Ntr, H, lr);
+    }
 }
 template <int TASK, int I, int O>
 __device__ __forceinline__ void sgd_sweep_dispatch(const float* w_in, float* w_out, const float* xy, const float* gdata, int Ntr,
                                                    int H, float lr) {
-    if constexpr (I > 8) sgd_sweep_call<TASK, I, O>(w_in, w_out, xy, gdata, Ntr, H, lr);
-    else sgd_sweep_select<TASK, I, O>(w_in, w_out, xy, gdata, Ntr, H, lr);
+    if constexpr (TASK == TASK_REG && I == 4 && O == 1) {
+        if (H <= 8) sgd_sweep<TASK, I, O, 3>(w_in, w_out, xy, gdata, Ntr, H, lr);
+        else if (H <= 16) sgd_sweep<TASK, I, O, 4>(w_in, w_out, xy, gdata, Ntr, H, lr);
+        else sgd_sweep_call<TASK, I, O>(w_in, w_out, xy, gdata, Ntr, H, lr);
+    } else {
+        sgd_sweep_call<TASK, I, O>(w_in, w_out, xy, gdata, Ntr, H, lr);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1255,15 +1281,11 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
         STAMP(5);                                         // prior, MH, state update
         // trace row i+1 (the only HBM traffic of a step)
         const size_t tpos = trow + (size_t)((i + 1) % p.trace_cap);
-        float* prow = p.tr_pos_w + tpos * (size_t)P;
-        for (int j = tid; j < P; j += nthr) prow[j] = l.rec_w[j];
+        float* prow = p.tr_pos_w + tpos * (size_t)p.PW;
+        for (int j = tid; j < p.PW; j += nthr) prow[j] = (j < P) ? l.rec_w[j] : 0.0f;
         if (tid == 0) {
-            p.tr_likeh[tpos] = (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp;   // REG:391 / CLS:404
-            p.tr_accept[tpos] = acc_before;                                            // REG:380
-            p.tr_rmse_tr[tpos] = rec_rmse_tr;
-            p.tr_rmse_te[tpos] = rec_rmse_te;
-            p.tr_acc_tr[tpos] = rec_acc_tr;
-            p.tr_acc_te[tpos] = rec_acc_te;
+            store_trace_row(p.tr_scal + tpos * TR_COUNT, (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp /* REG:391 / CLS:404 */,
+                            rec_rmse_tr, rec_rmse_te, rec_acc_tr, rec_acc_te, acc_before /* REG:380 */, logalpha);
         }
         STAMP(6);                                         // trace row
     }
@@ -1302,7 +1324,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
 // by (1 - (1-a)^k) / a for acceptance rate a and k waves.  Each wave runs its whole step alone (wave-local LDS
 // scratch, no work-group barrier inside a step), so the result does not depend on the number of waves.
 // ------------------------------------------------------------------------------------------------
-enum { SL_ACCEPT = 0, SL_LIKPROP, SL_PRIORPROP, SL_ETAPRO, SL_RM_TR, SL_RM_TE, SL_AC_TR, SL_AC_TE, SL_LG, SL_ADAPT, SL_COUNT = 16 };
+enum { SL_ACCEPT = 0, SL_LIKPROP, SL_PRIORPROP, SL_ETAPRO, SL_RM_TR, SL_RM_TE, SL_AC_TR, SL_AC_TE, SL_LG, SL_ADAPT, SL_LOGALPHA, SL_COUNT = 16 };
 constexpr int MAX_SLOTS = 64;          // speculative steps per round: work-groups per replica x waves per work-group
 constexpr unsigned SPIN_LIMIT = 1u << 22;   // x (s_sleep 2 + one L2 round trip) = a few seconds, then the launch gives up
 
@@ -1368,6 +1390,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
     // exchange areas of this replica (G > 1): [parity][slot][16] result granules, [parity][slot][2 PS] proposal granules
     granule_t* xs = p.xslots + (size_t)r * 2 * MAX_SLOTS * SL_COUNT;
     granule_t* xw = p.xw + (size_t)r * 2 * MAX_SLOTS * 2 * PS;
+    granule_t* xv = p.xverdict + (size_t)r * 2 * MAX_SLOTS;
 
     {
         const float4* src = reinterpret_cast<const float4*>(p.data);
@@ -1508,41 +1531,44 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
                 sl[SL_ACCEPT] = acc_mine ? 1.0f : 0.0f;
                 sl[SL_LIKPROP] = lik_prop; sl[SL_PRIORPROP] = prior_prop; sl[SL_ETAPRO] = eta_pro;
                 sl[SL_RM_TR] = rm_tr; sl[SL_RM_TE] = rm_te; sl[SL_AC_TR] = ac_tr; sl[SL_AC_TE] = ac_te;
-                sl[SL_LG] = lg ? 1.0f : 0.0f; sl[SL_ADAPT] = adapttemp;
+                sl[SL_LG] = lg ? 1.0f : 0.0f; sl[SL_ADAPT] = adapttemp; sl[SL_LOGALPHA] = logalpha;
             }
-            if (G > 1) {
-                // publish my slot (one 128-byte wave store) and, if accepted, the proposal and its SGD epoch
+            if (G > 1 && acc_mine) {
+                // an accepted slot publishes its record (one 128-byte wave store), the proposal and its SGD epoch: the other
+                // groups read them at commit, and only then
                 gsync<true>();
                 if (lane < SL_COUNT) granule_store(xs + ((size_t)par * MAX_SLOTS + sidx) * SL_COUNT + lane, epoch, sl[lane]);
-                if (acc_mine) {
-                    granule_t* xo = xw + ((size_t)par * MAX_SLOTS + sidx) * 2 * PS;
-                    for (int e = lane; e < 2 * PS; e += WAVE) granule_store(xo + e, epoch, mine[e]);   // my_prop ++ my_pgd
-                }
+                granule_t* xo = xw + ((size_t)par * MAX_SLOTS + sidx) * 2 * PS;
+                for (int e = lane; e < 2 * PS; e += WAVE) granule_store(xo + e, epoch, mine[e]);   // my_prop ++ my_pgd
             }
         }
-        // A wave without a step this round (k < K: the last rounds of an interval, or before the temperature switch) still
-        // publishes the tag of its slot: every group waits for EVERY slot's tag below, which keeps the groups within one round
-        // of each other.  Without it a group that publishes nothing for a few rounds is not waited for, can fall two rounds
-        // behind and then polls for a tag that has already been overwritten (seen once in ~25 suite runs as a hand-off timeout).
-        if (G > 1 && !active && lane == 0)
-            granule_store(xs + ((size_t)par * MAX_SLOTS + sidx) * SL_COUNT + (SL_COUNT - 1), epoch, 0.0f);
+        // Every slot, every round: ONE 8-byte verdict granule {tag, accepted?} -- the verdicts of a replica's round are one
+        // contiguous row, which is all a foreign group polls (everything else it needs of a rejected foreign slot -- the
+        // Langevin coin, eta_pro -- follows from the tape and the shared chain state; rocprofv3: 22 MB per launch of granule
+        // traffic when every slot published and every group polled 16 granules per slot).  A wave without a step this round
+        // (k < K: the last rounds of an interval, or before the temperature switch) publishes too: every group waits for
+        // EVERY slot's tag below, which keeps the groups within one round of each other (two-deep buffers suffice).
+        if (G > 1 && lane == 0) granule_store(xv + (size_t)par * MAX_SLOTS + sidx, epoch, (active && acc_mine) ? 1.0f : 0.0f);
         STAMP(5);                                         // publish
         __syncthreads();
         STAMP(6);                                         // waiting for the slowest wave of this work-group
         if (G > 1) {
-            // gather the slots of the other work-groups of this replica
+            // verdicts of the other work-groups' slots: one thread per slot (K <= 64: the lanes of wave 0 read one row)
             bool ok = true;
-            for (int t = tid; t < k * SL_COUNT; t += nthr) {
-                const int s_ = t / SL_COUNT;
-                if (s_ / NW == grp) continue;
-                float v;
-                ok = granule_wait(xs + ((size_t)par * MAX_SLOTS) * SL_COUNT + t, epoch, v) && ok;
-                slots[t] = v;
-            }
-            for (int s_ = k + tid; s_ < K; s_ += nthr) {     // heartbeats of the idle slots
-                if (s_ / NW == grp) continue;
-                float v;
-                ok = granule_wait(xs + ((size_t)par * MAX_SLOTS + s_) * SL_COUNT + (SL_COUNT - 1), epoch, v) && ok;
+            if (tid < K && tid / NW != grp) {
+                const int s_ = tid;
+                float v = 0.0f;
+                ok = granule_wait(xv + (size_t)par * MAX_SLOTS + s_, epoch, v);
+                if (s_ < k) {
+                    uint32_t x[4];
+                    philox4x32_10(0u, (uint32_t)(i + s_), p.noise_shared ? 0u : (uint32_t)gid, STREAM_STEP, p.seed_lo, p.seed_hi, x);
+                    float n2, n3;
+                    box_muller(x[2], x[3], n2, n3);          // the same scalars tape_step hands the slot's owner
+                    float* fs = slots + s_ * SL_COUNT;
+                    fs[SL_ACCEPT] = v;
+                    fs[SL_LG] = (p.use_lg && u23(x[0]) < p.l_prob) ? 1.0f : 0.0f;
+                    fs[SL_ETAPRO] = (TASK == TASK_REG) ? fmaf(p.step_eta, n2, eta) : eta;
+                }
             }
             if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
         }
@@ -1557,29 +1583,35 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
             const bool acc_me = (sidx == m);
             const float* srcw = acc_me ? my_prop : rec_w;
             const size_t tpos = trow + (size_t)((j + 1) % p.trace_cap);
-            float* prow = p.tr_pos_w + tpos * (size_t)P;
-            for (int e = lane; e < P; e += WAVE) prow[e] = srcw[e];
+            float* prow = p.tr_pos_w + tpos * (size_t)p.PW;
+            for (int e = lane; e < p.PW; e += WAVE) prow[e] = (e < P) ? srcw[e] : 0.0f;
             if (lane == 0) {
-                p.tr_likeh[tpos] = (TASK == TASK_REG) ? sl[SL_LIKPROP] : sl[SL_LIKPROP] * sl[SL_ADAPT];
-                p.tr_accept[tpos] = nacc;                                   // count BEFORE this step (REG:380)
-                p.tr_rmse_tr[tpos] = acc_me ? sl[SL_RM_TR] : rec_rmse_tr;
-                p.tr_rmse_te[tpos] = acc_me ? sl[SL_RM_TE] : rec_rmse_te;
-                p.tr_acc_tr[tpos] = acc_me ? sl[SL_AC_TR] : rec_acc_tr;
-                p.tr_acc_te[tpos] = acc_me ? sl[SL_AC_TE] : rec_acc_te;
+                store_trace_row(p.tr_scal + tpos * TR_COUNT, (TASK == TASK_REG) ? sl[SL_LIKPROP] : sl[SL_LIKPROP] * sl[SL_ADAPT],
+                                acc_me ? sl[SL_RM_TR] : rec_rmse_tr, acc_me ? sl[SL_RM_TE] : rec_rmse_te,
+                                acc_me ? sl[SL_AC_TR] : rec_acc_tr, acc_me ? sl[SL_AC_TE] : rec_acc_te,
+                                nacc /* count BEFORE this step (REG:380) */, sl[SL_LOGALPHA]);
             }
         }
         lg_count += __popcll(bal_lg & ((ncommit >= 64) ? ~0ull : ((1ull << ncommit) - 1ull)));
         if (TASK == TASK_REG) tau_eta_last = slots[(ncommit - 1) * SL_COUNT + SL_ETAPRO];
         __syncthreads();                                    // every reader of rec_w is done
         if (m < k) {
+            const int owner = m / NW;
+            bool ok = true;
+            if (G > 1 && owner != grp) {                      // the accepted slot ran elsewhere: fetch its record
+                if (tid < SL_COUNT) {
+                    float v = 0.0f;
+                    ok = granule_wait(xs + ((size_t)par * MAX_SLOTS + m) * SL_COUNT + tid, epoch, v);
+                    slots[m * SL_COUNT + tid] = v;
+                }
+                if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
+            }
             const float* sm = slots + m * SL_COUNT;
             nacc += 1;
             lik = sm[SL_LIKPROP]; prior_cur = sm[SL_PRIORPROP]; eta = sm[SL_ETAPRO];
             rec_rmse_tr = sm[SL_RM_TR]; rec_rmse_te = sm[SL_RM_TE]; rec_acc_tr = sm[SL_AC_TR]; rec_acc_te = sm[SL_AC_TE];
             gd_valid = p.use_lg ? 1 : 0;
             lg_acc += (sm[SL_LG] != 0.0f) ? 1 : 0;
-            const int owner = m / NW;
-            bool ok = true;
             if (owner == grp) {
                 const float* wacc = priv0 + (size_t)(m - grp * NW) * wfl;
                 for (int e = tid; e < P; e += nthr) {
@@ -1742,7 +1774,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
     const int ev_first = sweeping ? PK_SWEEP_WAVES : 0, ev_n = PK_WAVES - ev_first;
     int i = step_begin;
     int tpos0 = (step_begin + 1) % p.trace_cap;            // ring position of the trace row of step i
-    const float inv_P = 1.0f / (float)P;
+    const float inv_P = 1.0f / (float)P, inv_PW = 1.0f / (float)p.PW;
     while (i < end) {
         if (i == p.switch_step) {
             if (wave == 0) {
@@ -1868,7 +1900,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
             }
             const float logalpha = (sl[SL_LIKPROP] - lik) + (sl[SL_PRIORPROP] - prior_cur) + diff_prop;
             const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
-            if (on && l16 == 0) sl[SL_ACCEPT] = (s_scal(s_)[1] < mh) ? 1.0f : 0.0f;
+            if (on && l16 == 0) { sl[SL_ACCEPT] = (s_scal(s_)[1] < mh) ? 1.0f : 0.0f; sl[SL_LOGALPHA] = logalpha; }
         }
         __syncthreads();
         STAMP(5);                                           // MH
@@ -1878,11 +1910,11 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
         const unsigned long long bal_acc = __ballot(f_acc), bal_lg = __ballot(f_lg);
         const int m = bal_acc ? (__ffsll((long long)bal_acc) - 1) : k;
         const int ncommit = (m < k) ? m + 1 : k;
-        for (int item = tid; item < ncommit * P; item += nthr) {     // trace rows: all (slot, element) pairs at once
-            const int s_ = (int)(((float)item + 0.5f) * inv_P), e = item - s_ * P;
+        for (int item = tid; item < ncommit * p.PW; item += nthr) {  // trace rows: all (slot, element) pairs at once
+            const int s_ = (int)(((float)item + 0.5f) * inv_PW), e = item - s_ * p.PW;
             int tp = tpos0 + s_;
             if (tp >= p.trace_cap) tp -= p.trace_cap;
-            p.tr_pos_w[(trow + (size_t)tp) * (size_t)P + e] = ((s_ == m) ? s_prop(s_) : rec_w)[e];
+            p.tr_pos_w[(trow + (size_t)tp) * (size_t)p.PW + e] = (e < P) ? ((s_ == m) ? s_prop(s_) : rec_w)[e] : 0.0f;
         }
         if (tid < ncommit) {
             const int s_ = tid;
@@ -1891,14 +1923,9 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
             int tp = tpos0 + s_;
             if (tp >= p.trace_cap) tp -= p.trace_cap;
             const size_t tpos = trow + (size_t)tp;
-            {
-                p.tr_likeh[tpos] = (TASK == TASK_REG) ? sl[SL_LIKPROP] : sl[SL_LIKPROP] * sl[SL_ADAPT];
-                p.tr_accept[tpos] = nacc;
-                p.tr_rmse_tr[tpos] = acc_me ? sl[SL_RM_TR] : rec_rmse_tr;
-                p.tr_rmse_te[tpos] = acc_me ? sl[SL_RM_TE] : rec_rmse_te;
-                p.tr_acc_tr[tpos] = acc_me ? sl[SL_AC_TR] : rec_acc_tr;
-                p.tr_acc_te[tpos] = acc_me ? sl[SL_AC_TE] : rec_acc_te;
-            }
+            store_trace_row(p.tr_scal + tpos * TR_COUNT, (TASK == TASK_REG) ? sl[SL_LIKPROP] : sl[SL_LIKPROP] * sl[SL_ADAPT],
+                            acc_me ? sl[SL_RM_TR] : rec_rmse_tr, acc_me ? sl[SL_RM_TE] : rec_rmse_te,
+                            acc_me ? sl[SL_AC_TR] : rec_acc_tr, acc_me ? sl[SL_AC_TE] : rec_acc_te, nacc, sl[SL_LOGALPHA]);
         }
         lg_count += __popcll(bal_lg & ((1ull << ncommit) - 1ull));
         if (TASK == TASK_REG) tau_eta_last = slots[(ncommit - 1) * SL_COUNT + SL_ETAPRO];
@@ -2323,7 +2350,8 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
         const int acc_before = nacc;
         __syncthreads();                                    // every reader of w_cur / w_gd of this step is done
         const size_t tpos = trow + (size_t)((i + 1) % p.trace_cap);
-        float* prow = p.tr_pos_w + tpos * (size_t)P;
+        float* prow = p.tr_pos_w + tpos * (size_t)p.PW;
+        for (int j = P + tid; j < p.PW; j += nthr) prow[j] = 0.0f;
         if (accept) {
             nacc += 1;
             lik = lik_prop; prior_cur = prior_prop; eta = eta_pro;
@@ -2338,12 +2366,8 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
             for (int j = tid; j < P; j += nthr) prow[j] = rec_w[j];
         }
         if (tid == 0) {
-            p.tr_likeh[tpos] = (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp;
-            p.tr_accept[tpos] = acc_before;
-            p.tr_rmse_tr[tpos] = rec_rmse_tr;
-            p.tr_rmse_te[tpos] = rec_rmse_te;
-            p.tr_acc_tr[tpos] = rec_acc_tr;
-            p.tr_acc_te[tpos] = rec_acc_te;
+            store_trace_row(p.tr_scal + tpos * TR_COUNT, (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp, rec_rmse_tr, rec_rmse_te,
+                            rec_acc_tr, rec_acc_te, acc_before, logalpha);
         }
         __syncthreads();
     }

@@ -462,10 +462,17 @@ def gen_ladder(out):
 # --------------------------------------------------------------------------------------------
 # F9: statistical targets from long reference runs with the reference's OWN random numbers
 # --------------------------------------------------------------------------------------------
+# Every run of a configuration starts from the SAME initial weights (the parent's np.random is seeded with W0_SEED for
+# initialize_chains, REG:649) and differs in the noise only (np.random / random re-seeded with `seed` before run_chains; the
+# forked chains inherit that state, REG:709-712).  The spread of a statistic across the seeds is then the reference's own Monte
+# Carlo error for that start, which is what the GPU runs from the same start are held against.
+W0_SEED = 4242
 STATS = [  # key, module, topo, dataset, use_lg, lr, R, maxtemp, S per replica, swap_ratio, seeds
-    ("sunspot_rw_r8", "REG", [4, 5, 1], "sunspot", False, 0.1, 8, 2, 5000, 0.01, (1, 2, 3)),
-    ("sunspot_lg_r8", "REG", [4, 5, 1], "sunspot", True, 0.1, 8, 2, 2500, 0.01, (1, 2, 3)),
-    ("iris_rw_r8", "CLS", [4, 12, 3], "iris", False, 0.01, 8, 10, 5000, 0.02, (1, 2, 3)),
+    ("sunspot_rw_r8", "REG", [4, 5, 1], "sunspot", False, 0.1, 8, 2, 5000, 0.01, (1, 2, 3, 4, 5)),
+    ("sunspot_lg_r8", "REG", [4, 5, 1], "sunspot", True, 0.1, 8, 2, 2500, 0.01, (1, 2, 3, 4, 5)),
+    ("iris_rw_r8", "CLS", [4, 12, 3], "iris", False, 0.01, 8, 10, 5000, 0.02, (1, 2, 3, 4, 5)),
+    ("mackey_lg_r8", "REG", [4, 10, 1], "mackey", True, 0.1, 8, 2, 2500, 0.01, (1, 2, 3, 4, 5)),
+    ("ions_rw_r8", "CLS", [34, 50, 2], "ions", False, 0.01, 8, 10, 1500, 0.02, (1, 2, 3, 4, 5)),
 ]
 
 
@@ -481,15 +488,17 @@ def gen_stats(ds, out, only=None):
         for seed in seeds:
             tmp = tempfile.mkdtemp()
             mkdirs(tmp)
-            np.random.seed(seed)
-            pyrandom.seed(seed)
             t0 = time.time()
             with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
                 if modname == "REG":
                     pt = mod.ParallelTempering(use_lg, lr, train, test, topo, R, maxtemp, NumSample, si, 0.5, tmp)
                 else:
                     pt = mod.ParallelTempering(use_lg, lr, train, test, topo, R, maxtemp, NumSample, si, tmp)
+                np.random.seed(W0_SEED)
                 pt.initialize_chains(0.5)
+                w0 = [np.asarray(c.w, dtype=np.float64).tolist() for c in pt.chains]
+                np.random.seed(seed)
+                pyrandom.seed(seed)
                 res = pt.run_chains()
             wall = time.time() - t0
             pos_w = res[0]                                   # (P, R*(S-b))
@@ -504,8 +513,13 @@ def gen_stats(ds, out, only=None):
             shutil.rmtree(tmp)
             print("F9", key, "seed", seed, "%.1fs" % wall, "swap%%=%.2f" % float(res[8]), flush=True)
         with open(os.path.join(out, f"stats_{key}.json"), "w") as f:
+            # scalars as JSON; the arrays (initial weights float64, per-run posterior means / variances float32) beside it
+            np.savez_compressed(os.path.join(out, f"stats_{key}.npz"), w0=np.array(w0, dtype=np.float64),
+                                w_mean=np.array([r.pop("w_mean") for r in runs], dtype=np.float32),
+                                w_var=np.array([r.pop("w_var") for r in runs], dtype=np.float32))
             json.dump(dict(key=key, module=modname, topology=topo, dataset=dname, use_lg=use_lg, lr=lr, R=R,
-                           maxtemp=maxtemp, S=S, swap_interval=si, cores=os.cpu_count(), runs=runs), f)
+                           maxtemp=maxtemp, S=S, swap_interval=si, cores=os.cpu_count(), w0_seed=W0_SEED, runs=runs,
+                           arrays=f"stats_{key}.npz"), f)
 
 
 def main():

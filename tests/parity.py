@@ -15,9 +15,83 @@ import ptnn_oracle as orc  # noqa: E402
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # fp32 kernel vs float64 oracle: unit values rel 1e-5 / abs 1e-6, log-likelihood sums rel 1e-5 (+ abs 2e-3
-# on sums of several hundred terms), MH decisions identical until |log alpha - log u| is inside the fp32 noise
+# on sums of several hundred terms), MH decisions identical until |log alpha - log u| is inside the fp32 error of log alpha.
 RTOL, ATOL = 2e-5, 2e-6
-LOGALPHA_SLACK = 5e-3
+
+# ---- the fp32 error of the MH decision: measured, not guessed ----------------------------------------------------------------
+# log alpha = (lik_prop - lik) + (prior_prop - prior) + diff_prop (REG:365-372) is a small difference of large terms, so its
+# fp32 error is proportional to their size `scale` = |lik_prop| + |lik| + |prior_prop| + |prior| + (|first| + |second|) / T
+# (oracle: Replica.last_scale), not to log alpha.  The kernels record the log alpha they decided on (column 6 of
+# ptnn_get_trace_rows), so the error is measured directly against the float64 oracle on the same tape.  On the MI355X, over every
+# step of the nine F4 trajectories (profiles/tools/logalpha_probe.py -> profiles/r02_logalpha_error.json):
+#
+#   trajectory (net, kernel)                     steps   scale (median)   max |error|   max |error| / scale
+#   reg_rw          4-5-1    speculative          199        183            8.7e-5          9.2e-7
+#   reg_lg          4-5-1    packed                99        519            5.8e-4          3.3e-7
+#   reg_lg_mackey   4-10-1   speculative           59        758            4.4e-4          5.4e-7
+#   cls_rw          4-12-3   cooperative          199        423            1.8e-5          4.2e-8
+#   cls_lg          4-12-3   speculative           99        810            6.6e-4          7.6e-7
+#   cls_rw_ions     34-50-2  cooperative (MFMA)    59       6225            2.0e-4          3.3e-8
+#   reg_rw_noswitch 4-5-1    speculative           56        255            2.4e-5          6.9e-8
+#   reg_lg_wide     32-96-1  wide                  29      12980            1.5e-3          1.1e-7
+#   cls_lg_wide     34-100-2 wide                  29      12386            2.0e-3          1.2e-7
+#
+# i.e. below SURVEY 8d's 1e-3 for every net of BASELINE configs 1-4 and 16 ulp of the largest term at worst.  The bound the
+# tests hold every step to is twice the largest measured ratio; a decision may differ from the oracle's only where log u lies
+# within that bound of the oracle's log alpha (and, where the kernel's value is at hand, between the two values).
+# With swap rounds the reference keeps `likelihood` and `prior_current` of the state that LEFT a slot (Q12, REG:435-438): until
+# the next accepted step log alpha compares a fresh likelihood of the arrived state with a stale one of another state, so the
+# fp32 evaluation errors of the two no longer cancel (a single chain's proposal and current state differ by one small step and
+# round alike).  Measured over every multi-replica test of the suite (PTNN_PARITY_PROBE=file pytest -m gpu, condensed in
+# profiles/r02_logalpha_error.json): at most 8.0e-6 of the scale on such steps (Mackey-Glass, 64 replicas, tau^2 ~ 1e-4:
+# 2.6e-2 on a scale of 3275), 5.1e-6 on the other steps of runs with swaps (Sunspot, 64 replicas: the arrived state carries the
+# fp32 history of another chain, and the prior stays stale across the temperature switch).
+LOGALPHA_REL = 2e-6              # single chain: 2 x the largest measured ratio (9.2e-7)
+LOGALPHA_REL_COUPLED = 1e-5      # chains coupled through swaps, likelihood current: 2 x 5.1e-6
+LOGALPHA_REL_STALE = 2e-5        # steps deciding on a stale likelihood after a swap (Q12): 2.5 x 8.0e-6
+LOGALPHA_ABS = 1e-5              # v_exp_f32 and the compare u < exp(log alpha) in fp32
+SWAP_L_REL = 2e-5                # a posted scalar L is one likelihood evaluation (times T for REG): same class as a stale step
+MIN_IDENTICAL_STEPS = 50         # decisions identical for at least the first 50 steps
+
+
+def logalpha_slack(scale, rel=LOGALPHA_REL):
+    return rel * float(scale) + LOGALPHA_ABS
+
+
+def check_logalpha_error(la_gpu, la_oracle, scale, label="", rel=LOGALPHA_REL):
+    """Every step whose inputs were still identical: the kernel's log alpha within the measured fp32 bound of the oracle's.
+    `rel`: a constant or one value per step."""
+    la_gpu, la_oracle, scale = (np.asarray(v, dtype=np.float64) for v in (la_gpu, la_oracle, scale))
+    rel = np.broadcast_to(np.asarray(rel, dtype=np.float64), scale.shape)
+    ok = np.isfinite(la_oracle) & np.isfinite(la_gpu)
+    err = np.abs(la_gpu - la_oracle)[ok]
+    lim = (rel * scale + LOGALPHA_ABS)[ok]
+    if os.environ.get("PTNN_PARITY_PROBE"):                 # measurement mode: record the ratios instead of judging them
+        import json
+        with open(os.environ["PTNN_PARITY_PROBE"], "a") as f:
+            ratio = err / scale[ok]
+            k = int(np.argmax(ratio)) if err.size else -1
+            f.write(json.dumps(dict(label=label, test=os.environ.get("PYTEST_CURRENT_TEST", ""), steps=int(err.size),
+                                    max_err=float(err.max()) if err.size else 0.0, max_ratio=float(ratio.max()) if err.size else 0.0,
+                                    at_step=int(np.flatnonzero(ok)[k]) if err.size else -1,
+                                    scale_there=float(scale[ok][k]) if err.size else 0.0,
+                                    rel_there=float(rel[ok][k]) if err.size else 0.0,
+                                    max_ratio_by_rel={str(v): float(ratio[rel[ok] == v].max()) for v in np.unique(rel[ok])})) + "\n")
+        return float(err.max()) if err.size else 0.0
+    bad = err > lim
+    assert not bad.any(), (f"{label}log alpha off by {err[bad].max():.3g} (bound {lim[bad][np.argmax(err[bad])]:.3g}) at step "
+                           f"{int(np.flatnonzero(ok)[np.flatnonzero(bad)[np.argmax(err[bad])]])}")
+    return float(err.max()) if err.size else 0.0
+
+
+def check_divergence(la_oracle, logu, scale, la_gpu=None, label="", rel=LOGALPHA_REL):
+    """The two sides decided differently at a step: legitimate only if the oracle's decision was closer than the fp32 error of
+    log alpha, and (when the kernel's own log alpha is known) log u lies between the two values."""
+    gap = abs(la_oracle - logu)
+    assert np.isnan(gap) or gap <= logalpha_slack(scale, rel), f"{label}decision flipped with |log alpha - log u| = {gap:.3g} > {logalpha_slack(scale, rel):.3g}"
+    if la_gpu is not None and np.isfinite(la_gpu) and np.isfinite(la_oracle):
+        lo, hi = min(la_oracle, la_gpu), max(la_oracle, la_gpu)
+        assert lo - LOGALPHA_ABS <= logu <= hi + LOGALPHA_ABS, f"{label}log u = {logu} not between the two log alphas {la_oracle}, {la_gpu}"
 
 
 def datasets():
@@ -71,6 +145,8 @@ class OracleRun:
         self.pt = pt
         self.logalpha = np.full((pt.R, pt.S), np.nan)
         self.logu = np.full((pt.R, pt.S), np.nan)
+        self.scale = np.full((pt.R, pt.S), np.nan)
+        self.stale = np.zeros((pt.R, pt.S), dtype=bool)
 
     def run(self):
         pt = self.pt
@@ -79,12 +155,83 @@ class OracleRun:
                 rep.step(i)
                 self.logalpha[r, i] = rep.last_logalpha
                 self.logu[r, i] = np.log(rep.last_u)
+                self.scale[r, i] = rep.last_scale
+                self.stale[r, i] = rep.last_stale
             if orc.swap_trigger(pt.task, i, pt.si):
                 pt.swap_round()
         rounds = int(pt.S / pt.si) if pt.si > 0 else 0
         if pt.swap_rule == 0 and rounds > pt.rounds_done:
             pt.swap_round(L=[rep.likelihood for rep in pt.replicas], apply=False)
         return self
+
+
+def handoff_step(task, k, si):
+    """MH step after which swap round k (0-based) runs: REG i = (k+1) si (REG:427), CLS i = (k+1) si - 1 (CLS:438)."""
+    return (k + 1) * si - (0 if task == orc.TASK_REG else 1)
+
+
+def check_swap_divergence(pt, k, src_gpu, label=""):
+    """Round k of the cascade came out differently on the device: legitimate only if the first pair decided differently was
+    closer than the fp32 error of the two posted scalars it compares (REG:674: u < 0.5 exp(min(709, L2 - L1)))."""
+    L = pt.L_log[k]
+    u = pt.tape.swap_uniforms(k, pt.R - 1)
+    src_o = pt.src_log[k]
+    c = 0
+    for j in range(pt.R - 1):
+        if src_gpu[j] != src_o[j]:
+            d = min(709.0, L[j + 1] - L[c])
+            margin = abs(np.log(u[j]) - (np.log(0.5) + d))
+            bound = SWAP_L_REL * (abs(L[j + 1]) + abs(L[c])) + LOGALPHA_ABS
+            assert margin <= bound, f"{label}swap round {k} pair {j}: decision flipped with margin {margin:.3g} > {bound:.3g}"
+            return j
+        if src_o[j] != j + 1:
+            c = j + 1
+    raise AssertionError(f"{label}swap round {k}: permutations differ only in the last slot?")
+
+
+def check_run_against_oracle(s, tr, o, label="", limit=None):
+    """A whole ladder (swap rounds included) against the oracle run `o` (OracleRun) on the same tape.  The replicas are coupled
+    through the swaps, so only the EARLIEST difference is attributable: either an MH decision or a cascade decision.  Up to it
+    every trace row agrees within the fp32 tolerances and the kernel's log alpha is within the measured fp32 bound of the
+    oracle's on every step; the difference itself must be a decision inside that bound.  Returns the list of first differing
+    accept_list indices per replica (None = none) within the compared range."""
+    pt = o.pt
+    log = s.swap_log()
+    swap_div = next((k for k in range(min(len(log), len(pt.src_log))) if list(log[k]) != list(pt.src_log[k])), None)
+    if swap_div is not None and pt.swap_rule == 0:
+        rows = handoff_step(pt.task, swap_div, pt.si) + 2     # rows [0, rows) were written before that round moved anything
+        limit = rows if limit is None else min(int(limit), rows)
+    # earliest differing MH decision of ANY replica: from there on a swap can carry the difference into every other slot, so
+    # all replicas are compared on the rows written before it only
+    S_cmp = pt.S if limit is None else min(pt.S, int(limit))
+
+    def first_diff(r):
+        d = np.nonzero(tr["accept"][r].astype(np.int64)[:S_cmp] != pt.replicas[r].accept_list.astype(np.int64)[:S_cmp])[0]
+        return int(d[0]) if d.size else None
+    fd = [first_diff(r) for r in range(pt.R)]
+    early = [f for f in fd if f is not None]
+    if early:
+        limit = max(min(early) - 1, 2)                       # rows [0, first - 1) of the earliest diverging replica
+    firsts = [compare_replica_trace(tr, r, pt.replicas[r], f"{label}r{r} ", limit=limit) for r in range(pt.R)]
+    if early:                                               # compare_replica_trace saw rows below the divergence only: put it back
+        firsts[fd.index(min(early))] = min(early)
+    lag = s.log_alpha()
+    div = [f for f in firsts if f is not None]
+    upto = (pt.S - 1) if not div else min(div) - 2           # steps [0, upto) had identical inputs in every replica
+    if limit is not None:
+        upto = max(min(upto, int(limit) - 1), 0)
+    coupled = pt.rounds_done > 0 and pt.swap_rule == 0
+    for r in range(pt.R):
+        rel = np.where(o.stale[r, :upto], LOGALPHA_REL_STALE, LOGALPHA_REL_COUPLED if coupled else LOGALPHA_REL)
+        check_logalpha_error(lag[r, :upto], o.logalpha[r, :upto], o.scale[r, :upto], f"{label}r{r} ", rel=rel)
+    if div:
+        r = firsts.index(min(div))
+        i = min(div) - 2
+        rel = LOGALPHA_REL_STALE if o.stale[r, i] else (LOGALPHA_REL_COUPLED if coupled else LOGALPHA_REL)
+        check_divergence(o.logalpha[r, i], o.logu[r, i], o.scale[r, i], lag[r, i], f"{label}r{r} step {i}: ", rel=rel)
+    elif swap_div is not None and pt.swap_rule == 0:
+        check_swap_divergence(pt, swap_div, list(log[swap_div]), label)
+    return firsts
 
 
 def run_smoke_check():
@@ -103,14 +250,9 @@ def run_smoke_check():
     s.run(-1)
     s.sync()
     tr = s.traces()
-    firsts = [compare_replica_trace(tr, r, pt.replicas[r], f"smoke r{r} ") for r in range(R)]
+    firsts = check_run_against_oracle(s, tr, o, "smoke ")
     nsw, tot, rounds = s.swap_stats()
     assert tot == pt.total_swap_proposals and rounds == pt.rounds_done, (tot, rounds)
-    for r, f in enumerate(firsts):
-        if f is not None:
-            i = f - 2
-            gap = abs(o.logalpha[r, i] - o.logu[r, i])
-            assert gap < LOGALPHA_SLACK or np.isnan(gap), f"replica {r} diverged at step {i} with |log a - log u| = {gap}"
     s.close()
     return firsts
 
@@ -126,3 +268,63 @@ def synthetic_regression(n_rows, n_train, n_in, n_hidden, seed):
     y = np.clip(orc.forward(X, w_t, topo)[1][:, 0] + rng.normal(0, 0.02, n_rows), 0, 1)
     data = np.hstack([X, y[:, None]])
     return data[:n_train], data[n_train:]
+
+
+def posterior_parity(ref_runs, dev_runs, task, check_variance=True):
+    """Statistical parity of whole runs.  ref_runs: the reference's own runs from one start (fixture); dev_runs:
+    device runs from the same start; each a dict with w_mean / w_var [R, P] after burn-in, accept_pct [R], swap_perc, rmse / acc
+    means.  MCSE of a difference of means = sqrt(s_ref^2 / K_ref + s_dev^2 / K_dev) from the seed-to-seed spread on each side.
+
+      posterior mean   |mean_dev - mean_ref| <= 0.1 sd_post + 3 MCSE per weight and chain, sd_post^2 = the within-chain
+                       posterior variance (mean over both sides' runs).  The chains are short and far from mixed, so s_ref from
+                       five runs is itself noisy (t with 4 degrees of freedom: 4 % of exact draws exceed 3 MCSE): at least 90 %
+                       of the (chain, weight) pairs must be inside, and the median |z| must be below 1 (a shifted posterior
+                       moves every pair, not a tail of them).
+      posterior var    per chain, ratio of the geometric means (over the chain's weights, mean over runs of log var) in
+                       [0.8, 1.25] widened by 3 MCSE of that log ratio (seed-to-seed spread of the per-run chain values).
+      MH acceptance    per temperature, |acc_dev - acc_ref| <= 3 points + 3 MCSE
+      swap percentage  |swap_dev - swap_ref| <= 5 points + 3 MCSE
+      RMSE, accuracy   |x_dev - x_ref| <= 3 MCSE + 5 % of the reference value
+    """
+    def arr(runs, k):
+        return np.array([np.asarray(r[k], dtype=np.float64) for r in runs])
+
+    def mcse(a, b):
+        return np.sqrt(a.var(axis=0, ddof=1) / a.shape[0] + b.var(axis=0, ddof=1) / b.shape[0])
+    rep = {}
+    mr, md = arr(ref_runs, "w_mean"), arr(dev_runs, "w_mean")
+    vr, vd = arr(ref_runs, "w_var"), arr(dev_runs, "w_var")
+    sd_post = np.sqrt(0.5 * (vr.mean(axis=0) + vd.mean(axis=0)))
+    diff = np.abs(md.mean(axis=0) - mr.mean(axis=0))
+    se = mcse(mr, md)
+    inside = diff <= 0.1 * sd_post + 3.0 * se
+    z = diff / np.maximum(se, 1e-300)
+    rep["mean_frac_inside"] = float(inside.mean())
+    rep["mean_median_abs_z"] = float(np.median(z))
+    ok = rep["mean_frac_inside"] >= 0.90 and rep["mean_median_abs_z"] < 1.0
+    # variance ratio per chain, in the log domain: ratio of the geometric means over the chain's weights.  A chain that receives
+    # a state from another mode through a swap multiplies the variance of ALL its weights at once, so the Monte Carlo error of
+    # the ratio is taken from the seed-to-seed spread of the per-run chain values, not from the number of weights.
+    # (a hot chain that accepts nothing after burn-in has variance 0 in that run: floored at (1e-6)^2, far below a single step)
+    lr_, ld_ = np.log(np.maximum(vr, 1e-12)).mean(axis=2), np.log(np.maximum(vd, 1e-12)).mean(axis=2)       # [K, R]
+    g = ld_.mean(axis=0) - lr_.mean(axis=0)
+    gse = mcse(lr_, ld_)
+    rep["var_ratio_per_chain"] = [float(v) for v in np.exp(g)]
+    rep["var_ratio_mcse"] = [float(v) for v in gse]
+    if check_variance:
+        ok = ok and bool(np.all(np.abs(g) <= np.log(1.25) + 3.0 * gse))
+    ar, ad = arr(ref_runs, "accept_pct"), arr(dev_runs, "accept_pct")
+    dacc = np.abs(ad.mean(axis=0) - ar.mean(axis=0))
+    rep["accept_pct_ref"] = [float(v) for v in ar.mean(axis=0)]
+    rep["accept_pct_dev"] = [float(v) for v in ad.mean(axis=0)]
+    ok = ok and bool(np.all(dacc <= 3.0 + 3.0 * mcse(ar, ad)))
+    sr, sdv = arr(ref_runs, "swap_perc"), arr(dev_runs, "swap_perc")
+    rep["swap_perc_ref"], rep["swap_perc_dev"] = float(sr.mean()), float(sdv.mean())
+    ok = ok and abs(sdv.mean() - sr.mean()) <= 5.0 + 3.0 * float(mcse(sr, sdv))
+    keys = ["rmse_train_mean", "rmse_test_mean"] + (["acc_train_mean", "acc_test_mean"] if task == orc.TASK_CLS else [])
+    for k in keys:
+        a, b = arr(ref_runs, k), arr(dev_runs, k)
+        rep[k] = [float(a.mean()), float(b.mean())]
+        ok = ok and abs(b.mean() - a.mean()) <= 3.0 * float(mcse(a, b)) + 0.05 * abs(a.mean())
+    rep["ok"] = bool(ok)
+    return rep

@@ -131,10 +131,10 @@ def test_single_replica_trajectory(key, schedule, waves):
     tape = orc.PhiloxTape(seed)
     rep = orc.Replica(task, topo, train, test, w0.astype(np.float64), float(g["T"]), S, bool(g["use_lg"]), 0.5,
                       float(g["lr"]), tape, gid)
-    la, lu = np.zeros(S), np.zeros(S)
+    la, lu, sc = np.zeros(S), np.zeros(S), np.zeros(S)
     for i in range(S - 1):
         rep.step(i)
-        la[i], lu[i] = rep.last_logalpha, np.log(rep.last_u)
+        la[i], lu[i], sc[i] = rep.last_logalpha, np.log(rep.last_u), rep.last_scale
     s = parity.make_sampler(task, topo, train, test, R_local=1, R_global=8, first=gid, S=S, si=10 * S,
                             use_lg=bool(g["use_lg"]), lr=float(g["lr"]), seed=seed, waves=waves, schedule=schedule)
     s.set_state(w0[None, :], np.array([float(g["T"])], dtype=np.float32))
@@ -143,10 +143,13 @@ def test_single_replica_trajectory(key, schedule, waves):
     s.sync()
     tr = s.traces()
     first = parity.compare_replica_trace(tr, 0, rep, key + " ")
+    lag = s.log_alpha()[0]
+    upto = (S - 1) if first is None else first - 2          # steps [0, upto) had identical inputs on both sides
+    parity.check_logalpha_error(lag[:upto], la[:upto], sc[:upto], key + " ")
     if first is not None:
         i = first - 2
-        assert i >= 20, f"diverged at step {i}"
-        assert abs(la[i] - lu[i]) < parity.LOGALPHA_SLACK, f"decision flipped at step {i} with margin {abs(la[i] - lu[i])}"
+        assert i >= min(parity.MIN_IDENTICAL_STEPS, S - 2), f"diverged at step {i}"
+        parity.check_divergence(la[i], lu[i], sc[i], lag[i], f"{key} step {i}: ")
     else:
         st = s.state()
         assert int(st["num_accepted"][0]) == rep.num_accepted
@@ -194,18 +197,14 @@ def test_full_pt_run_with_swaps(key, schedule):
     assert log.shape == (rounds, R)
     for row in log:
         assert sorted(row.tolist()) == list(range(R))
-    firsts = [parity.compare_replica_trace(tr, r, pt.replicas[r], f"{key} r{r} ") for r in range(R)]
+    # every step before the earliest divergence: log alpha within the measured fp32 bound; the earliest divergence (if any)
+    # must be a decision inside it (replicas are coupled through swaps: only that one is attributable)
+    firsts = parity.check_run_against_oracle(s, tr, o, f"{key} ")
     diverged = [f for f in firsts if f is not None]
     if not diverged and all((log[k] == np.array(pt.src_log[k])).all() for k in range(rounds)):
         assert nsw == pt.num_swap == int(g["num_swap"])
     else:
-        # a decision flipped somewhere: it must have been a coin toss inside the fp32 noise
-        for r, f in enumerate(firsts):
-            if f is not None:
-                i = f - 2
-                # replicas are coupled through swaps: only the EARLIEST divergence is attributable
-                if f == min(diverged):
-                    assert abs(o.logalpha[r, i] - o.logu[r, i]) < parity.LOGALPHA_SLACK
+        assert not diverged or min(diverged) - 2 >= min(parity.MIN_IDENTICAL_STEPS, S - 2)
     s.close()
 
 
@@ -372,51 +371,54 @@ def test_smoke_entry():
 
 
 STATS = {"sunspot_rw_r8": (0, (4, 5, 1), "sunspot", False, 0.1, 2), "sunspot_lg_r8": (0, (4, 5, 1), "sunspot", True, 0.1, 2),
-         "iris_rw_r8": (1, (4, 12, 3), "iris", False, 0.01, 10)}
+         "iris_rw_r8": (1, (4, 12, 3), "iris", False, 0.01, 10), "mackey_lg_r8": (0, (4, 10, 1), "mackey", True, 0.1, 2),
+         "ions_rw_r8": (1, (34, 50, 2), "ions", False, 0.01, 10)}
+N_STAT_SEEDS = 10
 
 
+@pytest.mark.parametrize("shared_noise", [1, 0])
 @pytest.mark.parametrize("key", list(STATS))
-def test_statistics_match_long_reference_runs(key):
-    """F9: whole-run statistics against fixtures from long runs of the reference with its OWN random numbers (3 seeds,
-    tests/golden/stats_*.json).  The chains are short and multi-modal (the reference's seed-to-seed spread is large), so
-    the bands are wide; they catch a wrong temperature, prior, likelihood scale or swap rule, not fp32 noise.
-    Tolerances: mean MH acceptance within a factor 1.6 of the reference mean, acceptance of the coldest chain above that
-    of the hottest, swap percentage within 12 points of the reference's range, burn-in-discarded RMSE / accuracy inside
-    the reference's range widened by 60 %."""
+def test_statistics_match_long_reference_runs(key, shared_noise):
+    """F9, statistical parity (north_star: posterior weight means / variances and swap-acceptance rates must match the CPU
+    multiprocessing reference): fixtures hold five whole runs of the REFERENCE ITSELF per configuration (its own numpy /
+    random generators, tests/golden/make_fixtures.py --stats), all from the same initial weights and differing in the noise
+    only, so their spread is the reference's own Monte Carlo error for that start.  The device runs N_STAT_SEEDS chains from
+    the same initial weights with its Philox tape.  Bounds (parity.posterior_parity states how each is applied):
+    per-weight posterior mean within 0.1 posterior sd + 3 MCSE, posterior variance ratio 0.8 .. 1.25, MH acceptance per
+    temperature within 3 points + 3 MCSE, swap percentage within 5 points + 3 MCSE, RMSE / accuracy within 3 MCSE + 5 %.
+    shared_noise = 1 is the reference's actual behaviour (Q14: its forked chains all inherit one RNG state, REG:709-712) and
+    must pass every bound.  The default (independent Philox streams per replica, the statistically sound choice SURVEY 8a
+    sanctions) is held to the same bounds except the within-slot variance: chains that share one noise tape drift in parallel,
+    so the states a slot receives through swaps lie closer to the one it had -- with independent noise the within-slot variance
+    of the high-acceptance classification chains comes out 1.4-1.8 x the reference's (measured with the float64 oracle, which is
+    pinned to the reference bit for bit, under both settings)."""
     task, topo, name, lg, lr, maxtemp = STATS[key]
     f = json.load(open(os.path.join(parity.GOLDEN, f"stats_{key}.json")))
     R, S, si = f["R"], f["S"], f["swap_interval"]
     d = ds()
-    P = orc.num_param(topo)
-    acc, swap, rm, at = [], [], [], []
-    for seed in range(11, 19):
+    arrays = np.load(os.path.join(parity.GOLDEN, f["arrays"]))
+    w0 = arrays["w0"]
+    for k, run in enumerate(f["runs"]):
+        run["w_mean"], run["w_var"] = arrays["w_mean"][k], arrays["w_var"][k]
+    T = np.array(orc.temperature_ladder(R, maxtemp), dtype=np.float32)
+    runs = []
+    for seed in range(11, 11 + N_STAT_SEEDS):
         s = parity.make_sampler(task, topo, d[name + "_train"], d[name + "_test"], R_local=R, R_global=R, first=0, S=S, si=si,
-                                use_lg=lg, lr=lr, seed=seed)
-        tape = orc.PhiloxTape(seed)
-        w0 = np.stack([tape.w_init(r, P) for r in range(R)]).astype(np.float32)
-        s.set_state(w0, np.array(orc.temperature_ladder(R, maxtemp), dtype=np.float32))
+                                use_lg=lg, lr=lr, seed=seed, shared_noise=shared_noise)
+        s.set_state(w0.astype(np.float32), T)
         s.run(-1)
         s.sync()
-        tr = s.traces(pos_w=False)
+        tr = s.traces()
         nsw, tot, _ = s.swap_stats()
-        acc.append(100.0 * s.state()["num_accepted"] / S)
-        swap.append(100.0 * nsw / tot)
-        rm.append(tr["rmse_train"][:, S // 2:].mean())
-        at.append(tr["acc_train"][:, S // 2:].mean())
+        b = int(S * 0.5)
+        runs.append(dict(w_mean=tr["pos_w"][:, b:].mean(axis=1, dtype=np.float64), w_var=tr["pos_w"][:, b:].var(axis=1, dtype=np.float64),
+                         accept_pct=100.0 * s.state()["num_accepted"] / S, swap_perc=100.0 * nsw / tot,
+                         rmse_train_mean=float(tr["rmse_train"][:, b:].mean()), rmse_test_mean=float(tr["rmse_test"][:, b:].mean()),
+                         acc_train_mean=float(tr["acc_train"][:, b:].mean()), acc_test_mean=float(tr["acc_test"][:, b:].mean())))
         s.close()
-    acc = np.array(acc)
-    ref_acc = np.array([r["accept_pct"] for r in f["runs"]])
-    ref_swap = [r["swap_perc"] for r in f["runs"]]
-    ref_rm = [r["rmse_train_mean"] for r in f["runs"]]
-    assert ref_acc.mean() / 1.6 < acc.mean() < ref_acc.mean() * 1.6, (acc.mean(), ref_acc.mean())
-    if task == 0:
-        assert acc[:, 0].mean() > acc[:, -1].mean() and ref_acc[:, 0].mean() > ref_acc[:, -1].mean()
-    assert min(ref_swap) - 12 < np.mean(swap) < max(ref_swap) + 12, (np.mean(swap), ref_swap)
-    lo, hi = min(ref_rm), max(ref_rm)
-    assert lo / 1.6 < np.mean(rm) < hi * 1.6, (np.mean(rm), ref_rm)
-    if task == 1:
-        ref_at = [r["acc_train_mean"] for r in f["runs"]]
-        assert min(ref_at) - 15 < np.mean(at) < max(ref_at) + 15, (np.mean(at), ref_at)
+    report = parity.posterior_parity(f["runs"], runs, task, check_variance=bool(shared_noise))
+    print(key, "shared_noise", shared_noise, json.dumps(report))
+    assert report["ok"], report
 
 
 def test_config5_shape_against_oracle():
@@ -437,11 +439,7 @@ def test_config5_shape_against_oracle():
     tr = s.traces()
     nsw, tot, rounds = s.swap_stats()
     assert rounds == pt.rounds_done and tot == pt.total_swap_proposals
-    for r in range(R):
-        first = parity.compare_replica_trace(tr, r, pt.replicas[r], f"config5 r{r} ")
-        if first is not None:
-            i = first - 2
-            assert abs(o.logalpha[r, i] - o.logu[r, i]) < 0.05, (r, i, o.logalpha[r, i], o.logu[r, i])
+    parity.check_run_against_oracle(s, tr, o, "config5 ")
     # the SGD epoch on its own at this size: 1024 dependent rows, 512 x 33 weights
     w = w0[0]
     np.testing.assert_allclose(s.langevin_gradient(w)[0], orc.langevin_gradient(train, w.astype(np.float64), topo, 0.1, 0),
@@ -597,7 +595,7 @@ def test_even_odd_swap_rule_option(task):
         if div:
             r = firsts.index(min(div))
             i = min(div) - 2
-            assert abs(o.logalpha[r, i] - o.logu[r, i]) < parity.LOGALPHA_SLACK
+            parity.check_divergence(o.logalpha[r, i], o.logu[r, i], o.scale[r, i], s.log_alpha()[r, i], f"even/odd r{r} step {i}: ")
 
 
 
@@ -645,11 +643,7 @@ def test_classification_shapes_of_the_problem_table(topo):
         tr = s.traces()
         nsw, tot, rounds = s.swap_stats()
         assert rounds == pt.rounds_done and tot == pt.total_swap_proposals
-        for r in range(R):
-            first = parity.compare_replica_trace(tr, r, pt.replicas[r], f"{topo} waves={waves} r{r} ")
-            if first is not None:
-                i = first - 2
-                assert abs(o.logalpha[r, i] - o.logu[r, i]) < 0.05, (topo, waves, r, i, o.logalpha[r, i], o.logu[r, i])
+        parity.check_run_against_oracle(s, tr, o, f"{topo} waves={waves} ")
         s.close()
 
 
@@ -678,11 +672,7 @@ def test_shared_noise_option_matches_oracle(schedule):
     s.sync()
     tr = s.traces()
     assert s.swap_stats()[2] == pt.rounds_done and s.swap_stats()[1] == pt.total_swap_proposals
-    for r in range(R):
-        first = parity.compare_replica_trace(tr, r, pt.replicas[r], f"shared noise r{r} ")
-        if first is not None:
-            i = first - 2
-            assert abs(o.logalpha[r, i] - o.logu[r, i]) < 0.05, (r, i, o.logalpha[r, i], o.logu[r, i])
+    parity.check_run_against_oracle(s, tr, o, "shared noise ")
     s.close()
 
 
@@ -837,3 +827,44 @@ def test_multi_group_schedule_is_refused_when_not_resident():
     with pytest.raises(_lib.PtnnError, match="cannot all be resident"):
         parity.make_sampler(0, (4, 10, 1), d["mackey_train"], d["mackey_test"], R_local=too_many, R_global=too_many, first=0,
                             S=20, si=5, use_lg=True, lr=0.1, seed=1, schedule=2, groups=4)
+
+
+BASELINE_COUNTS = {
+    # name: task, topology, data set, replicas, Langevin, lr, maxtemp, S, swap interval  (BASELINE.json configs 2-4 at their full
+    # replica counts and default schedules; S short enough for the float64 oracle to finish in seconds)
+    "iris16": (1, (4, 12, 3), "iris", 16, False, 0.01, 10, 120, 20),
+    "mackey64": (0, (4, 10, 1), "mackey", 64, True, 0.1, 2, 60, 10),
+    "ionosphere256": (1, (34, 50, 2), "ions", 256, False, 0.01, 10, 30, 10),
+    "sunspot64": (0, (4, 5, 1), "sunspot", 64, True, 0.1, 2, 60, 10),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(BASELINE_COUNTS))
+def test_baseline_replica_counts_against_oracle(name):
+    """The whole ladder at the replica count BASELINE.json quotes (Iris 16, Mackey-Glass 64, Ionosphere 256, Sunspot 64) under
+    the schedule the library picks for it, against the float64 oracle on the same tape: traces, swap log, counters, and the
+    kernel's log alpha inside the measured fp32 bound on every step (tests/parity.py)."""
+    task, topo, dname, R, lg, lr, maxtemp, S, si = BASELINE_COUNTS[name]
+    d = ds()
+    train, test = d[dname + "_train"], d[dname + "_test"]
+    seed = 600 + R
+    pt = orc.PTOracle(task, topo, train, test, R, maxtemp, R * S, si, use_lg=lg, l_prob=0.5, lr=lr, seed=seed)
+    w0 = np.stack([rep.w for rep in pt.replicas]).astype(np.float32)
+    for rep, w in zip(pt.replicas, w0):
+        rep.__init__(task, topo, pt.train, pt.test, w.astype(np.float64), rep.T, S, lg, 0.5, lr, pt.tape, rep.gid)
+    o = parity.OracleRun(pt).run()
+    s = parity.make_sampler(task, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=lg, lr=lr, seed=seed)
+    s.set_state(w0, np.array(pt.temperatures, dtype=np.float32))
+    s.run(-1)
+    s.sync()
+    tr = s.traces()
+    nsw, tot, rounds = s.swap_stats()
+    assert rounds == pt.rounds_done and tot == pt.total_swap_proposals == rounds * (R - 1)
+    firsts = parity.check_run_against_oracle(s, tr, o, f"{name} ")
+    log = s.swap_log()
+    if all(f is None for f in firsts) and all((log[k] == np.array(pt.src_log[k])).all() for k in range(rounds)):
+        assert nsw == pt.num_swap
+    # else: among R x S decisions one landed inside the fp32 bound of log alpha -- check_run_against_oracle has verified that it
+    # is such a decision (log u between the two log alphas) and that everything before it agrees
+    s.close()
