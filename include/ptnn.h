@@ -64,6 +64,13 @@ typedef struct ptnn_config {
                                    * step tape of replica 0 (proposal noise, Langevin coin, MH uniform, eta noise): what the
                                    * reference's forked chains do, which all inherit one numpy / random state (REG:709-712,
                                    * SURVEY Q14).  Initial weights and swap uniforms are not shared (the parent draws them). */
+    int32_t label_swap;           /* 0 = a swap round moves (w, eta) between the temperature slots, as the reference does (default);
+                                   * 1 = label swapping (not in the reference): the chains stay in place and the
+                                   * TEMPERATURES move -- a round only rewrites the slot <-> temperature maps, so nothing but the R
+                                   * posted scalars crosses a GPU boundary (zero payload).  A chain keeps its own likelihood (re-tempered
+                                   * for its new temperature) and prior: no stale values (Q12 does not apply).  Works with both swap
+                                   * rules; needs ptnn_set_ladder.  Trace rows are recorded per chain slot: ptnn_get_labels / the swap log
+                                   * say which temperature a slot held when (the Python host stitches the per-temperature files). */
     float l_prob;                 /* langevin_prob (REG:174); CLS fixes 0.5 (CLS:192) */
     float learn_rate;             /* SGD step of langevin_gradient (REG:33) */
     float step_w;                 /* 0.025 (REG:258) */
@@ -208,6 +215,10 @@ int ptnn_get_swap_log(ptnn_handle *h, int32_t *src, int max_rounds);
  * (of those, accepted; speculative schedule only); any pointer may be NULL */
 int ptnn_get_state(ptnn_handle *h, float *w, float *eta, float *likelihood, float *prior, int32_t *num_accepted,
                    int32_t *langevin_count, int32_t *langevin_accepted);
+
+/* label_swap = 1: label[R_global] = the temperature index every chain slot of the whole ladder holds after the rounds queued so
+ * far (identity without label swapping) */
+int ptnn_get_labels(ptnn_handle *h, int32_t *label);
 
 /* ---- checkpoint / resume (the reference has none) ----
  * The RNG is counter based, so the state of the chains is small: (w, eta), cached gradient, recorded row, likelihood / prior /

@@ -394,8 +394,14 @@ class PTOracle:
     """
 
     def __init__(self, task, topo, train, test, num_chains, maxtemp, NumSample, swap_interval,
-                 use_lg=False, l_prob=0.5, lr=0.1, seed=1, w0=None, faithful=False, swap_rule=0, shared_noise=False):
+                 use_lg=False, l_prob=0.5, lr=0.1, seed=1, w0=None, faithful=False, swap_rule=0, shared_noise=False,
+                 label_swap=False):
         self.swap_rule = swap_rule          # 0 = the reference's cascade; 1 = even/odd Metropolis (NOT in the reference)
+        # label swapping (NOT in the reference; parity unpinned): a round permutes which CHAIN holds which
+        # temperature instead of moving (w, eta) between temperature slots.  self.replicas stays ordered by temperature index;
+        # a chain keeps everything it owns (likelihood, prior, counters, its noise stream) and its likelihood is re-tempered.
+        self.label_swap = bool(label_swap)
+        self.holder_hist = []               # [(first trace row written under this assignment, [chain objects by temperature])]
         self.task, self.topo = task, tuple(topo)
         self.train = np.asarray(train, dtype=np.float64)
         self.test = np.asarray(test, dtype=np.float64)
@@ -417,6 +423,8 @@ class PTOracle:
         self.total_swap_proposals = 0
         self.rounds_done = 0
         self.src_log = []
+        self.holder_hist.append((0, list(self.replicas)))
+        self._steps_done = 0
         self.L_log = []                                     # the scalars every round decided on (swap_rule 0)
 
     def swap_round_even_odd(self):
@@ -441,6 +449,9 @@ class PTOracle:
         self.total_swap_proposals += (R - par) // 2
         self.rounds_done += 1
         self.src_log.append(list(src))
+        if self.label_swap:
+            self._apply_labels(src)
+            return src
         old = [(rep.w, rep.eta, raw[i], rep.prior_current) for i, rep in enumerate(self.replicas)]
         for k, rep in enumerate(self.replicas):
             if src[k] != k:
@@ -448,6 +459,34 @@ class PTOracle:
                 rep.w, rep.eta, rep.prior_current = w, eta, pri
                 rep.likelihood = lraw / rep.adapttemp
         return src
+
+    def _apply_labels(self, src):
+        """Temperature t is handed to the chain that held temperature src[t]."""
+        T = self.temperatures
+        new = [self.replicas[src[t]] for t in range(self.R)]
+        for t, rep in enumerate(new):
+            if rep.T != T[t]:
+                if rep.init_count == 0:                     # still tempered: the chain's likelihood follows its new temperature
+                    rep.likelihood *= rep.T / T[t]
+                rep.T = float(T[t])
+        self.replicas = new
+        self.holder_hist.append((self._steps_done + 1, list(new)))
+
+    def traces_by_temperature(self):
+        """Label swapping: what the per-temperature files hold -- for every temperature the rows recorded by the chain that
+        held it at the time.  -> dict of arrays [R, S, ...]."""
+        out = dict(pos_w=np.zeros((self.R, self.S, self.P)), likeh=np.zeros((self.R, self.S)), accept=np.zeros((self.R, self.S)),
+                   rmse_train=np.zeros((self.R, self.S)), rmse_test=np.zeros((self.R, self.S)),
+                   acc_train=np.zeros((self.R, self.S)), acc_test=np.zeros((self.R, self.S)))
+        bounds = [h[0] for h in self.holder_hist] + [self.S]
+        for (row0, chains), row1 in zip(self.holder_hist, bounds[1:]):
+            for t, rep in enumerate(chains):
+                out["pos_w"][t, row0:row1] = rep.pos_w[row0:row1]
+                out["likeh"][t, row0:row1] = rep.likeh[row0:row1, 0]
+                out["accept"][t, row0:row1] = rep.accept_list[row0:row1]
+                for k in ("rmse_train", "rmse_test", "acc_train", "acc_test"):
+                    out[k][t, row0:row1] = getattr(rep, k)[row0:row1]
+        return out
 
     def swap_round(self, L=None, apply=True):
         if self.swap_rule == 1:
@@ -462,7 +501,9 @@ class PTOracle:
         self.rounds_done += 1
         self.src_log.append(list(src))
         self.L_log.append([float(v) for v in L])
-        if apply:                                           # R11/Q12: only (w, eta) move; likelihood/prior stay stale
+        if apply and self.label_swap:
+            self._apply_labels(src)
+        elif apply:                                         # R11/Q12: only (w, eta) move; likelihood/prior stay stale
             ws = [rep.w for rep in self.replicas]
             etas = [rep.eta for rep in self.replicas]
             for k, rep in enumerate(self.replicas):
@@ -477,6 +518,7 @@ class PTOracle:
         for i in range(S - 1):
             for rep in self.replicas:
                 rep.step(i)
+            self._steps_done = i + 1
             if swap_trigger(self.task, i, si):
                 self.swap_round()
         # Q13 phantom round: the parent loops int(S/si) rounds; extra ones consume the end-of-chain

@@ -19,7 +19,7 @@ class Config(C.Structure):
         ("n_in", C.c_int32), ("n_hidden", C.c_int32), ("n_out", C.c_int32),
         ("n_replicas_local", C.c_int32), ("n_replicas_global", C.c_int32), ("first_global_replica", C.c_int32),
         ("n_samples", C.c_int32), ("swap_interval", C.c_int32), ("pt_switch_step", C.c_int32),
-        ("use_langevin", C.c_int32), ("waves_per_replica", C.c_int32), ("schedule", C.c_int32), ("groups_per_replica", C.c_int32), ("trace_capacity", C.c_int32), ("forward_bf16", C.c_int32), ("swap_rule", C.c_int32), ("shared_noise", C.c_int32),
+        ("use_langevin", C.c_int32), ("waves_per_replica", C.c_int32), ("schedule", C.c_int32), ("groups_per_replica", C.c_int32), ("trace_capacity", C.c_int32), ("forward_bf16", C.c_int32), ("swap_rule", C.c_int32), ("shared_noise", C.c_int32), ("label_swap", C.c_int32),
         ("l_prob", C.c_float), ("learn_rate", C.c_float), ("step_w", C.c_float), ("step_eta", C.c_float),
         ("sigma_squared", C.c_float), ("nu_1", C.c_float), ("nu_2", C.c_float),
         ("seed", C.c_uint64),
@@ -78,6 +78,7 @@ SYMBOLS = {
     "ptnn_get_swap_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _ip]),
     "ptnn_get_swap_log": (C.c_int, [C.c_void_p, _ip, C.c_int]),
     "ptnn_get_state": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp, _ip, _ip, _ip]),
+    "ptnn_get_labels": (C.c_int, [C.c_void_p, _ip]),
     "ptnn_checkpoint_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "ptnn_checkpoint_save": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "ptnn_checkpoint_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
@@ -327,6 +328,11 @@ class Sampler:
         buf = np.empty((cap, Rg), np.int32)
         n = self._check(self.lib.ptnn_get_swap_log(self.h, _ptr(buf, _ip), cap))
         return buf[:n]
+
+    def labels(self):
+        lab = np.empty(self.cfg.n_replicas_global, np.int32)
+        self._check(self.lib.ptnn_get_labels(self.h, _ptr(lab, _ip)))
+        return lab
 
     def state(self):
         w = np.empty((self.R, self.P), np.float32)

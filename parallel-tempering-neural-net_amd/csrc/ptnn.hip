@@ -104,6 +104,8 @@ struct ptnn_handle {
     float *d_L_handoff = nullptr, *d_L_final = nullptr;
     float *d_L_raw = nullptr, *d_prior_post = nullptr, *d_temps_global = nullptr;   // swap_rule 1
     bool have_ladder = false;
+    int *d_label[2] = {nullptr, nullptr}, *d_slot_of[2] = {nullptr, nullptr};   // label_swap: slot <-> temperature maps, ping-pong
+    int lflip = 0;
     float *d_pos_w = nullptr;       // [Rl][cap][PW]
     float *d_scal = nullptr;        // [Rl][cap][TR_COUNT] scalar trace rows
     int *d_src = nullptr, *d_src_log = nullptr;
@@ -220,6 +222,10 @@ int launch_swap(ptnn_handle* h, bool phantom, int mode, bool want_src) {
     sp.st_f = h->d_st_f;
     sp.canonical = (h->cfg.pt_switch_step >= 0 && h->cur - 1 >= h->cfg.pt_switch_step) ? 1 : 0;
     sp.xchg = h->d_xchg; sp.XS = xchg_row_floats(h->PS); sp.L_stride = 1;
+    sp.label_mode = h->cfg.label_swap ? 1 : 0;
+    sp.label_cur = h->d_label[h->lflip]; sp.slot_cur = h->d_slot_of[h->lflip];
+    sp.label_next = h->d_label[h->lflip ^ 1]; sp.slot_next = h->d_slot_of[h->lflip ^ 1];
+    sp.temps_local = h->d_temps;
     if (mode == -1) {
         hipLaunchKernelGGL(xchg_pack_kernel, dim3(sp.Rl), dim3(64), 0, h->stream, sp);
         HIP_TRY(hipGetLastError());
@@ -294,6 +300,10 @@ int create_buffers(ptnn_handle* h, const ptnn_config* cfg, const Shape* sh, cons
     HIP_TRY(hipMalloc(&h->d_pos_w, Rl * S * h->PW * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_scal, Rl * S * TR_COUNT * sizeof(float)));
     HIP_TRY(hipMalloc(&h->d_src, R * sizeof(int)));
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY(hipMalloc(&h->d_label[b], R * sizeof(int)));
+        HIP_TRY(hipMalloc(&h->d_slot_of[b], R * sizeof(int)));
+    }
     HIP_TRY(hipHostMalloc(&h->h_src, R * sizeof(int), hipHostMallocDefault));
     HIP_TRY(hipMalloc(&h->d_xchg, (size_t)R * xchg_row_floats(h->PS) * sizeof(float)));
     HIP_TRY(hipMemsetAsync(h->d_xchg, 0, (size_t)R * xchg_row_floats(h->PS) * sizeof(float), h->stream));
@@ -340,6 +350,7 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
     if (cfg->n_samples < 2) return fail(-1, "n_samples must be >= 2");
     if (cfg->swap_interval < 1) return fail(-1, "swap_interval must be >= 1 (the reference divides by it, REG:427)");
     if (cfg->swap_rule != 0 && cfg->swap_rule != 1) return fail(-1, "swap_rule must be 0 (reference cascade) or 1 (even/odd Metropolis)");
+    if (cfg->label_swap != 0 && cfg->label_swap != 1) return fail(-1, "label_swap must be 0 or 1");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(-2, "device %d not present (%d devices)", cfg->device_id, ndev);
@@ -368,7 +379,7 @@ int ptnn_destroy(ptnn_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->comm.release();
     void* ptrs[] = {h->d_data, h->d_state[0], h->d_state[1], h->d_rec_w, h->d_gd_w[0], h->d_gd_w[1], h->d_gd_valid[0], h->d_gd_valid[1], h->d_st_f, h->d_st_i, h->d_temps,
-                    h->d_L_handoff, h->d_L_final, h->d_L_raw, h->d_prior_post, h->d_temps_global, h->d_pos_w, h->d_scal, h->d_src, h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_xverdict, h->d_stamps, h->d_wide_scratch, h->d_xt};
+                    h->d_L_handoff, h->d_L_final, h->d_L_raw, h->d_prior_post, h->d_temps_global, h->d_pos_w, h->d_scal, h->d_src, h->d_label[0], h->d_label[1], h->d_slot_of[0], h->d_slot_of[1], h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_xverdict, h->d_stamps, h->d_wide_scratch, h->d_xt};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_src) (void)hipHostFree(h->h_src);
@@ -580,6 +591,15 @@ int ptnn_set_state(ptnn_handle* h, const float* w0, const float* temperatures) {
                         hipMemcpyHostToDevice));
     h->flip = 0; h->cur = 0; h->rounds_done = 0; h->finalized = false; h->drained = 0; h->first_row = 0;
     HIP_TRY(hipMemset(h->d_counters, 0, 2 * sizeof(long long)));
+    {
+        std::vector<int> ident(h->cfg.n_replicas_global);
+        for (size_t k = 0; k < ident.size(); ++k) ident[k] = (int)k;
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(hipMemcpy(h->d_label[b], ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(h->d_slot_of[b], ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+        h->lflip = 0;
+    }
     h->have_state = true;
     return 0;
 }
@@ -602,10 +622,28 @@ static int resolved_xchg_mode(const ptnn_handle* h) {
     return gathered <= (size_t)4 << 20 ? PTNN_XCHG_GATHER : PTNN_XCHG_BOUNDARY;
 }
 
+// bookkeeping after the kernels of a round are queued: which buffers are current now
+static void round_queued(ptnn_handle* h, bool phantom) {
+    if (!phantom) {
+        if (h->cfg.label_swap) h->lflip ^= 1;                // the maps changed, the chains stayed where they are
+        else h->flip ^= 1;
+    }
+    h->rounds_done += 1;
+}
+
 // One swap round of a sharded ladder (the handle owns a block of it), everything queued on the handle's stream.
 static int comm_swap_round(ptnn_handle* h, bool phantom) {
     Comm& c = h->comm;
     const int Rl = h->cfg.n_replicas_local, R = h->cfg.n_replicas_global;
+    if (h->cfg.label_swap) {
+        // zero payload: only the posted scalars travel (4 R bytes; the untempered ones too under swap_rule 1)
+        if (!c.all_gather(phantom ? h->d_L_final : h->d_L_handoff, (size_t)Rl * sizeof(float), h->stream)) return fail(-7, "%s", c.err.c_str());
+        if (h->cfg.swap_rule == 1 && !c.all_gather(h->d_L_raw, (size_t)Rl * sizeof(float), h->stream)) return fail(-7, "%s", c.err.c_str());
+        if (int rc = launch_swap(h, phantom, phantom ? 2 : 3, false)) return rc;
+        round_queued(h, phantom);
+        c.rounds += 1;
+        return 0;
+    }
     if (resolved_xchg_mode(h) == PTNN_XCHG_GATHER) {
         if (int rc = launch_swap(h, phantom, -1, false)) return rc;                     // exchange rows of the local replicas
         if (!c.all_gather(h->d_xchg, (size_t)Rl * xchg_row_floats(h->PS) * sizeof(float), h->stream)) return fail(-7, "%s", c.err.c_str());
@@ -629,8 +667,7 @@ static int comm_swap_round(ptnn_handle* h, bool phantom) {
             if (int rc = launch_swap(h, false, 3, false)) return rc;                    // local moves (arrived rows stay), count, log
         }
     }
-    if (!phantom) h->flip ^= 1;
-    h->rounds_done += 1;
+    round_queued(h, phantom);
     c.rounds += 1;
     return 0;
 }
@@ -643,7 +680,8 @@ int ptnn_run(ptnn_handle* h, int n_steps) {
         return fail(-1, "this handle owns replicas %d..%d of %d: attach a communicator first (ptnn_comm_init / ptnn_comm_init_host), "
                         "or drive the pieces yourself with ptnn_run_segment + ptnn_swap_*", h->cfg.first_global_replica,
                     h->cfg.first_global_replica + h->cfg.n_replicas_local - 1, h->cfg.n_replicas_global);
-    if (h->cfg.swap_rule == 1 && !h->have_ladder) return fail(-1, "swap_rule 1 needs ptnn_set_ladder (all temperatures)");
+    if ((h->cfg.swap_rule == 1 || h->cfg.label_swap) && !h->have_ladder)
+        return fail(-1, "swap_rule 1 and label_swap need ptnn_set_ladder (all temperatures)");
     const int S = h->cfg.n_samples;
     const int last = S - 1;                                  // steps are i = 0 .. S-2
     int end = (n_steps < 0) ? last : std::min(last, h->cur + n_steps);
@@ -662,8 +700,7 @@ int ptnn_run(ptnn_handle* h, int n_steps) {
                 if (int rc = comm_swap_round(h, false)) return rc;
             } else {
                 if (int rc = launch_swap(h, false, 3, false)) return rc;
-                h->flip ^= 1;
-                h->rounds_done += 1;
+                round_queued(h, false);
             }
         }
     }
@@ -852,6 +889,7 @@ int ptnn_swap_row_ptr(ptnn_handle* h, int local_replica, void** cur_row, void** 
 
 int ptnn_swap_apply(ptnn_handle* h, const int32_t* src_host, int phantom) {
     if (int rc = check_ready(h)) return rc;
+    if (h->cfg.label_swap) return fail(-3, "label swapping moves no rows: drive it with ptnn_run");
     (void)src_host;   // the device recomputes the identical cascade; the host copy only routed the remote rows
     if (int rc = launch_swap(h, phantom != 0, phantom ? 2 : 3, false)) return rc;
     if (!phantom) h->flip ^= 1;
@@ -868,12 +906,14 @@ int ptnn_xchg_ptr(ptnn_handle* h, void** base, int* row_floats) {
 
 int ptnn_swap_pack(ptnn_handle* h, int phantom) {
     if (int rc = check_ready(h)) return rc;
+    if (h->cfg.label_swap) return fail(-3, "label swapping moves no rows: drive it with ptnn_run");
     if (h->cfg.swap_rule == 1 && !h->have_ladder) return fail(-1, "swap_rule 1 needs ptnn_set_ladder (all temperatures)");
     return launch_swap(h, phantom != 0, -1, false);
 }
 
 int ptnn_swap_apply_gathered(ptnn_handle* h, int phantom) {
     if (int rc = check_ready(h)) return rc;
+    if (h->cfg.label_swap) return fail(-3, "label swapping moves no rows: drive it with ptnn_run");
     if (int rc = launch_swap(h, phantom != 0, phantom ? (2 | 4) : (3 | 4), false)) return rc;
     if (!phantom) h->flip ^= 1;
     h->rounds_done += 1;
@@ -978,6 +1018,14 @@ int ptnn_get_swap_stats(ptnn_handle* h, int64_t* num_swap, int64_t* total_propos
     return 0;
 }
 
+int ptnn_get_labels(ptnn_handle* h, int32_t* label) {
+    if (!h || !label) return fail(-1, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(label, h->d_label[h->lflip], (size_t)h->cfg.n_replicas_global * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int ptnn_get_swap_log(ptnn_handle* h, int32_t* src, int max_rounds) {
     if (!h || !src) return fail(-1, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
@@ -1024,7 +1072,7 @@ constexpr uint32_t CK_MAGIC = 0x4b435450u;      // "PTCK"
 size_t ck_bytes(const ptnn_handle* h) {
     const size_t Rl = h->cfg.n_replicas_local, R = h->cfg.n_replicas_global, PS = h->PS;
     const size_t logr = (size_t)std::min(h->rounds_done, h->max_rounds);
-    return sizeof(CkHeader) + sizeof(float) * (3 * Rl * PS + Rl * SF_COUNT + Rl + 5 * R) + sizeof(int) * (Rl + Rl * SI_COUNT + logr * R);
+    return sizeof(CkHeader) + sizeof(float) * (3 * Rl * PS + Rl * SF_COUNT + Rl + 5 * R) + sizeof(int) * (Rl + Rl * SI_COUNT + logr * R + 2 * R);
 }
 
 bool same_chain(const ptnn_config& a, const ptnn_config& b) {
@@ -1032,7 +1080,7 @@ bool same_chain(const ptnn_config& a, const ptnn_config& b) {
            a.n_replicas_local == b.n_replicas_local && a.n_replicas_global == b.n_replicas_global &&
            a.first_global_replica == b.first_global_replica && a.n_samples == b.n_samples && a.swap_interval == b.swap_interval &&
            a.pt_switch_step == b.pt_switch_step && a.use_langevin == b.use_langevin && a.swap_rule == b.swap_rule &&
-           a.shared_noise == b.shared_noise && a.forward_bf16 == b.forward_bf16 && a.l_prob == b.l_prob &&
+           a.shared_noise == b.shared_noise && a.label_swap == b.label_swap && a.forward_bf16 == b.forward_bf16 && a.l_prob == b.l_prob &&
            a.learn_rate == b.learn_rate && a.step_w == b.step_w && a.step_eta == b.step_eta && a.sigma_squared == b.sigma_squared &&
            a.nu_1 == b.nu_1 && a.nu_2 == b.nu_2 && a.seed == b.seed;
 }
@@ -1052,7 +1100,7 @@ int ptnn_checkpoint_save(ptnn_handle* h, void* buf, int64_t bytes) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t Rl = h->cfg.n_replicas_local, R = h->cfg.n_replicas_global, PS = h->PS;
     CkHeader hd{};
-    hd.magic = CK_MAGIC; hd.version = 1; hd.cfg = h->cfg; hd.P = h->P; hd.PS = h->PS; hd.cur = h->cur;
+    hd.magic = CK_MAGIC; hd.version = 2; hd.cfg = h->cfg; hd.P = h->P; hd.PS = h->PS; hd.cur = h->cur;
     hd.rounds_done = h->rounds_done; hd.finalized = h->finalized ? 1 : 0; hd.have_ladder = h->have_ladder ? 1 : 0;
     hd.log_rounds = std::min(h->rounds_done, h->max_rounds);
     HIP_TRY(hipMemcpy(hd.counters, h->d_counters, sizeof(hd.counters), hipMemcpyDeviceToHost));
@@ -1076,6 +1124,8 @@ int ptnn_checkpoint_save(ptnn_handle* h, void* buf, int64_t bytes) {
     if (int rc = get(h->d_gd_valid[h->flip], sizeof(int) * Rl)) return rc;
     if (int rc = get(h->d_st_i, sizeof(int) * Rl * SI_COUNT)) return rc;
     if (int rc = get(h->d_src_log, sizeof(int) * (size_t)hd.log_rounds * R)) return rc;
+    if (int rc = get(h->d_label[h->lflip], sizeof(int) * R)) return rc;          // slot <-> temperature maps (identity unless label_swap)
+    if (int rc = get(h->d_slot_of[h->lflip], sizeof(int) * R)) return rc;
     return 0;
 }
 
@@ -1085,14 +1135,14 @@ int ptnn_checkpoint_load(ptnn_handle* h, const void* buf, int64_t bytes) {
     if (bytes < (int64_t)sizeof(CkHeader)) return fail(-1, "not a checkpoint (too short)");
     CkHeader hd;
     std::memcpy(&hd, buf, sizeof(hd));
-    if (hd.magic != CK_MAGIC || hd.version != 1) return fail(-1, "not a libptnn checkpoint (magic %08x version %u)", hd.magic, hd.version);
+    if (hd.magic != CK_MAGIC || hd.version != 2) return fail(-1, "not a libptnn checkpoint (magic %08x version %u)", hd.magic, hd.version);
     if (!same_chain(hd.cfg, h->cfg) || hd.P != h->P || hd.PS != h->PS)
         return fail(-1, "the checkpoint was written by chains with a different configuration (topology, replicas, samples, seed ...)");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     HIP_TRY(hipStreamSynchronize(h->stream));
     const size_t Rl = h->cfg.n_replicas_local, R = h->cfg.n_replicas_global, PS = h->PS;
     const size_t need = sizeof(CkHeader) + sizeof(float) * (3 * Rl * PS + Rl * SF_COUNT + Rl + 5 * R) +
-                        sizeof(int) * (Rl + Rl * SI_COUNT + (size_t)hd.log_rounds * R);
+                        sizeof(int) * (Rl + Rl * SI_COUNT + (size_t)hd.log_rounds * R + 2 * R);
     if ((size_t)bytes < need) return fail(-1, "truncated checkpoint: %lld < %zu bytes", (long long)bytes, need);
     if (hd.log_rounds > h->max_rounds) return fail(-1, "checkpoint holds more swap rounds than this handle can log");
     const char* q = static_cast<const char*>(buf) + sizeof(CkHeader);
@@ -1115,6 +1165,9 @@ int ptnn_checkpoint_load(ptnn_handle* h, const void* buf, int64_t bytes) {
     if (int rc = put(h->d_gd_valid[0], sizeof(int) * Rl)) return rc;
     if (int rc = put(h->d_st_i, sizeof(int) * Rl * SI_COUNT)) return rc;
     if (int rc = put(h->d_src_log, sizeof(int) * (size_t)hd.log_rounds * R)) return rc;
+    h->lflip = 0;
+    if (int rc = put(h->d_label[0], sizeof(int) * R)) return rc;
+    if (int rc = put(h->d_slot_of[0], sizeof(int) * R)) return rc;
     HIP_TRY(hipMemcpy(h->d_state[1], h->d_state[0], sizeof(float) * Rl * PS, hipMemcpyDeviceToDevice));
     HIP_TRY(hipMemcpy(h->d_counters, hd.counters, sizeof(hd.counters), hipMemcpyHostToDevice));
     h->cur = hd.cur; h->rounds_done = hd.rounds_done; h->finalized = hd.finalized != 0; h->have_ladder = hd.have_ladder != 0;
@@ -1194,7 +1247,7 @@ int ptnn_describe(ptnn_handle* h, char* buf, int nbytes) {
                                 h->wide ? "cooperative-wide" : (h->packed ? "packed-speculative" : (h->speculative ? "speculative" : "cooperative")),
                                 grid, h->nthreads, h->seg_lds, h->groups, slots, h->num_cus, per_cu, fa.numRegs, (size_t)fa.localSizeBytes,
                                 (h->fw_mfma || (h->wide && h->cfg.n_hidden % 32 == 0)) ? 1 : 0,
-                                h->comm.kind == COMM_NONE ? "none" : (resolved_xchg_mode(h) == PTNN_XCHG_GATHER ? "gather" : "boundary"));
+                                h->comm.kind == COMM_NONE ? "none" : (h->cfg.label_swap ? "labels" : (resolved_xchg_mode(h) == PTNN_XCHG_GATHER ? "gather" : "boundary")));
     if (n < 0 || n >= nbytes) return fail(-1, "buffer of %d bytes is too small for the description", nbytes);
     return n;
 }

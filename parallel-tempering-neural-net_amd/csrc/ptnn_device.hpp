@@ -1542,12 +1542,16 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
                 for (int e = lane; e < 2 * PS; e += WAVE) granule_store(xo + e, epoch, mine[e]);   // my_prop ++ my_pgd
             }
         }
-        // Every slot, every round: ONE 8-byte verdict granule {tag, accepted?} -- the verdicts of a replica's round are one
-        // contiguous row, which is all a foreign group polls (everything else it needs of a rejected foreign slot -- the
-        // Langevin coin, eta_pro -- follows from the tape and the shared chain state; rocprofv3: 22 MB per launch of granule
-        // traffic when every slot published and every group polled 16 granules per slot).  A wave without a step this round
-        // (k < K: the last rounds of an interval, or before the temperature switch) publishes too: every group waits for
-        // EVERY slot's tag below, which keeps the groups within one round of each other (two-deep buffers suffice).
+        // Every slot, every round: ONE 8-byte verdict granule {tag, accepted?}, published the moment the slot is decided; the
+        // verdicts of a replica's round are one contiguous row, which is all a foreign group polls.  Everything else it needs of a
+        // rejected foreign slot -- the Langevin coin, eta_pro -- follows from the tape and the shared chain state; records and
+        // proposals are published by accepted slots only and read at commit.  rocprofv3, Mackey-Glass 64 replicas x 4 groups, HBM
+        // bytes per launch: 4.2 MB (1.8 MB of it trace rows); 7.6 MB when every slot published a 16-granule record every round
+        // and every group polled all of them.  (One granule per GROUP, carrying the accept bits of its slots and published after
+        // the group's barrier, moves 6 % fewer bytes and was 4 % slower: the other groups see a decision later.)
+        // A wave without a step this round (k < K: the last rounds of an interval, or before the temperature switch) publishes
+        // too: every group waits for EVERY slot's tag below, which keeps the groups within one round of each other, so two-deep
+        // buffers suffice.
         if (G > 1 && lane == 0) granule_store(xv + (size_t)par * MAX_SLOTS + sidx, epoch, (active && acc_mine) ? 1.0f : 0.0f);
         STAMP(5);                                         // publish
         __syncthreads();
@@ -2005,38 +2009,90 @@ __host__ __device__ inline size_t wide_img_floats(int H, int FWS, int PS) {
 // R5 for H > 64: thread h owns hidden unit h; the output pre-activation is a two-level sum (DPP inside the wave, then the
 // per-wave partials through LDS, summed in a fixed order by every thread); ONE work-group barrier per data row (the
 // partial buffers alternate between rows).
+//
+// A row costs what its dependent chain costs: z -> sigmoid -> hid W2 -> wave sum -> LDS -> barrier -> sum of the partials ->
+// sigmoid -> deltas -> lhd.  The 2 I multiply-adds of a row (the W1 update and the next row's x . W1) are kept OFF that chain,
+// the way the narrow sweep does it (deferred update): the update of row n-1 is applied during row n, and the pre-activation
+// of row n+1 starts from the weights of row n-1,
+//     z[n+1] = (x[n+1] . W1[n-1] - B1[n-1]) + lhd[n] (1 + x[n+1] . x[n]),
+// the last factor being column I+1 of the data image.  Both run as packed v_pk_fma_f32 on input PAIRS while the wave waits
+// for the reduction and the barrier of row n.  The rows are wave-uniform and come through the scalar cache (s_load from the
+// constant address space, a row ahead), so the data values are SGPR operands of the multiply-adds: no vector loads, no
+// register copies (the plain chain spent 136 issue slots per row: 32 dependent v_fmac, 16 v_pk_fma, 16 v_mov_b64 of row
+// buffers, 10 flat loads).  Called out of line: inlined twice into the segment kernel next to the two MFMA forward variants
+// it pushed 312 VGPRs of the kernel into scratch (1236 B per lane for the 32-H-1 shape).
 template <int TASK, int I, int O>
-__device__ __forceinline__ void sgd_sweep_wide(const float* __restrict__ w_in, float* __restrict__ w_out,
-                                               const float* __restrict__ data, int IPY, int Ntr, int H, float lr,
-                                               float* __restrict__ part) {
+__device__ __attribute__((noinline)) void sgd_sweep_wide(const float* __restrict__ w_in, float* __restrict__ w_out,
+                                                         const float* __restrict__ data, int IPY, int Ntr, int H, float lr,
+                                                         float* __restrict__ part) {
     constexpr float C = -LOG2E, IC = -LN2;
     constexpr int OP = (O + 3) & ~3;
+    constexpr int IP = (I + 1) / 2;                                   // input pairs (an odd I is padded with a zero weight)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const bool act = t < H;
     const int hl = act ? t : 0;
     const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
     const float clr = C * lr;
-    float w1[I], w2[O], cl[O];
+    f32x2 w1[IP];
+    float w2[O], cl[O];
 #pragma unroll
-    for (int i = 0; i < I; ++i) w1[i] = act ? C * w_in[i * H + hl] : 0.0f;
+    for (int i = 0; i < IP; ++i) {
+        w1[i][0] = act ? C * w_in[(2 * i) * H + hl] : 0.0f;
+        w1[i][1] = (act && 2 * i + 1 < I) ? C * w_in[(2 * i + 1) * H + hl] : 0.0f;
+    }
 #pragma unroll
     for (int o = 0; o < O; ++o) w2[o] = act ? C * w_in[oW2 + hl * O + o] : 0.0f;
-    float b1 = act ? C * w_in[oB1 + hl] : -1.0e30f;
+    float nb1 = act ? -C * w_in[oB1 + hl] : 1.0e30f;                  // -B1'; inactive threads: exponent +1e30 -> hid == 0 exactly
 #pragma unroll
     for (int o = 0; o < O; ++o) cl[o] = -C * w_in[oB2 + o];          // replicated in every thread, updated identically
     int par = 0;
     static_assert(MAX_WAVES == 8, "the partial sums are read as two float4");
     for (int e = t; e < 2 * MAX_WAVES * OP; e += blockDim.x) part[e] = 0.0f;
     __syncthreads();
-    // the rows come from L2 (wave-uniform addresses): keep two rows in flight so that their latency hides behind the row
-    // being computed.  The data image carries two padding rows, so the look-ahead never leaves it.
-    auto row_step = [&](const float (&x)[I + 1]) {
-        float z = fmaf(x[0], w1[0], -b1);
+    // rows through the scalar cache: the address is wave-uniform and the image is never written while a kernel runs
+    // (a device function receives its arguments in VGPRs: the address is made scalar by hand, or the loads would be vector loads)
+    const unsigned long long da = (unsigned long long)(uintptr_t)data;
+    const cfloat* cdata = (const cfloat*)(uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(da >> 32)) << 32) |
+                                                     (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)da));
+    const int ipy = __builtin_amdgcn_readfirstlane(IPY);
+    const int ntr = __builtin_amdgcn_readfirstlane(Ntr);
+    typedef __attribute__((address_space(3))) float lfloat;
+    lfloat* lpart = (lfloat*)part;                                    // the partial sums live in LDS: ds_ instead of flat_ accesses
+    auto xpair = [&](int n, int i) {                                  // inputs (2i, 2i+1) of row n; the pad column of an odd I is 0-weighted
+        const cfloat* row = cdata + (size_t)n * ipy;
+        f32x2 v;
+        v[0] = row[2 * i];
+        v[1] = row[2 * i + 1];
+        return v;
+    };
+    auto zpart = [&](int n) {                                         // x[n] . W1 - B1 with the weights as they are now
+        f32x2 a0 = {nb1, 0.0f}, a1 = {0.0f, 0.0f};
 #pragma unroll
-        for (int i = 1; i < I; ++i) z = fmaf(x[i], w1[i], z);
-        const float hid = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
+        for (int i = 0; i < IP; i += 2) {
+            a0 = __builtin_elementwise_fma(xpair(n, i), w1[i], a0);
+            if (i + 1 < IP) a1 = __builtin_elementwise_fma(xpair(n, i + 1), w1[i + 1], a1);
+        }
+        const f32x2 s_ = a0 + a1;
+        return s_[0] + s_[1];
+    };
+    float lhd_p = 0.0f;                                               // lhd of the previous row: its update is still pending
+    float zp = zpart(0);
+    for (int n = 0; n < ntr; ++n) {
+        const cfloat* row = cdata + (size_t)n * ipy;
+        const float z = fmaf(lhd_p, row[I + 1], zp);                  // + lhd[n-1] (1 + x[n] . x[n-1])   (row 0: lhd_p == 0)
+        const float e = __builtin_amdgcn_exp2f(z);
+        // off the chain: apply the update of row n-1, then start row n+1 from the updated weights (two zero rows follow the image)
+        if (n > 0) {
+            const f32x2 l2 = {lhd_p, lhd_p};
+#pragma unroll
+            for (int i = 0; i < IP; ++i) w1[i] = __builtin_elementwise_fma(l2, xpair(n - 1, i), w1[i]);
+            if constexpr (I & 1) w1[IP - 1][1] = 0.0f;                // the pad weight of an odd input count stays zero
+            nb1 += lhd_p;
+        }
+        zp = zpart(n + 1);
+        const float hid = __builtin_amdgcn_rcpf(1.0f + e);
         const float ldh = lr * fmaf(-hid, hid, hid);
-        float* mypart = part + (size_t)par * MAX_WAVES * OP;          // [o][wave]: the partials of one output are contiguous
+        lfloat* mypart = lpart + par * MAX_WAVES * OP;          // [o][wave]: the partials of one output are contiguous
 #pragma unroll
         for (int o = 0; o < O; ++o) {
             const float s_ = wave_allsum(hid * w2[o]);
@@ -2048,50 +2104,38 @@ __device__ __forceinline__ void sgd_sweep_wide(const float* __restrict__ w_in, f
 #pragma unroll
         for (int o = 0; o < O; ++o) {
             // all MAX_WAVES partials with two 16-byte reads (entries of absent waves are zero), summed in a fixed order
-            const float4 pa = *reinterpret_cast<const float4*>(mypart + o * MAX_WAVES);
-            const float4 pb = *reinterpret_cast<const float4*>(mypart + o * MAX_WAVES + 4);
+            const lfloat* pp = mypart + o * MAX_WAVES;
+            const float4 pa = make_float4(pp[0], pp[1], pp[2], pp[3]);
+            const float4 pb = make_float4(pp[4], pp[5], pp[6], pp[7]);
             const float zo = cl[o] + (((pa.x + pa.y) + (pa.z + pa.w)) + ((pb.x + pb.y) + (pb.z + pb.w)));
             const float out = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zo));
             float tt;
-            if (TASK == TASK_CLS) tt = ((int)x[I] == o) ? 1.0f : 0.0f;
-            else tt = x[I];
+            if (TASK == TASK_CLS) tt = ((int)row[I] == o) ? 1.0f : 0.0f;
+            else tt = row[I];
             const float od = (tt - out) * fmaf(-out, out, out);
-            g = fmaf(od, w2[o], g);
+            g = fmaf(od, w2[o], g);                                   // pre-update W2 (Q4)
             lod[o] = clr * od;
         }
-        const float lhd = g * ldh;
+        lhd_p = g * ldh;
 #pragma unroll
         for (int o = 0; o < O; ++o) {
             w2[o] = fmaf(lod[o], hid, w2[o]);
             cl[o] += lod[o];
         }
-#pragma unroll
-        for (int i = 0; i < I; ++i) w1[i] = fmaf(lhd, x[i], w1[i]);
-        b1 -= lhd;
         par ^= 1;
-    };
-    auto load_row = [&](int n, float (&x)[I + 1]) {
-        const float* __restrict__ row = data + (size_t)n * IPY;
-#pragma unroll
-        for (int i = 0; i <= I; ++i) x[i] = row[i];
-    };
-    float xa[I + 1], xb[I + 1];
-    load_row(0, xa);
-    load_row(1, xb);
-    int n = 0;
-    for (; n + 1 < Ntr; n += 2) {
-        row_step(xa);
-        load_row(n + 2, xa);
-        row_step(xb);
-        load_row(n + 3, xb);
     }
-    if (n < Ntr) row_step(xa);
+    if (ntr > 0) {                                                    // the update of the last row is still pending
+        const f32x2 l2 = {lhd_p, lhd_p};
+#pragma unroll
+        for (int i = 0; i < IP; ++i) w1[i] = __builtin_elementwise_fma(l2, xpair(ntr - 1, i), w1[i]);
+        nb1 += lhd_p;
+    }
     if (act) {
 #pragma unroll
-        for (int i = 0; i < I; ++i) w_out[i * H + t] = IC * w1[i];
+        for (int i = 0; i < I; ++i) w_out[i * H + t] = IC * w1[i >> 1][i & 1];
 #pragma unroll
         for (int o = 0; o < O; ++o) w_out[oW2 + t * O + o] = IC * w2[o];
-        w_out[oB1 + t] = IC * b1;
+        w_out[oB1 + t] = -IC * nb1;
     }
     if (t == 0) {
 #pragma unroll
@@ -2451,6 +2495,16 @@ struct SwapParams {
     float* xchg;               // null: single-GPU / point-to-point modes
     int XS;
     int L_stride;              // 1, or XS when L (and, swap_rule 1, L_raw / prior_post) are read from the exchange rows
+    // label swapping (not in the reference): the chains stay where they are and the TEMPERATURES move.  label[slot] =
+    // temperature index the chain in that slot holds, slot_of[temperature] = its inverse, both over the whole ladder and replicated
+    // on every rank; the cascade runs over temperature indices, the round only rewrites the maps, the temperature of the local
+    // slots and (before the temperature switch) the tempering of their likelihoods.  Nothing but L crosses a GPU boundary.
+    int label_mode;
+    const int* label_cur;      // [R]
+    const int* slot_cur;       // [R]
+    int* label_next;           // [R]
+    int* slot_next;            // [R]
+    float* temps_local;        // [Rl] temperature of the local slots (what the segment kernels read)
 };
 __host__ __device__ inline int xchg_row_floats(int PS) { return (2 * PS + 4 + 3) & ~3; }
 
@@ -2458,7 +2512,7 @@ __host__ __device__ inline int xchg_row_floats(int PS) { return (2 * PS + 4 + 3)
 __device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, float* sL, float* sU, int* sSrc) {
     const int R = sp.R;
     for (int k = threadIdx.x; k < R; k += blockDim.x) {
-        sL[k] = sp.L[(size_t)k * sp.L_stride];
+        sL[k] = sp.L[(size_t)(sp.label_mode ? sp.slot_cur[k] : k) * sp.L_stride];    // k is a temperature index
         if (k < R - 1) {
             uint32_t x[4];
             philox4x32_10((uint32_t)k, (uint32_t)round, 0u, STREAM_SWAP, sp.seed_lo, sp.seed_hi, x);
@@ -2472,8 +2526,9 @@ __device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, floa
         if (threadIdx.x == 0) sSrc[R] = 0;
         __syncthreads();
         for (int k = (round & 1) + 2 * threadIdx.x; k < R - 1; k += 2 * blockDim.x) {
+            const int s0 = sp.label_mode ? sp.slot_cur[k] : k, s1 = sp.label_mode ? sp.slot_cur[k + 1] : k + 1;
             const float d = (1.0f / sp.temps_global[k] - 1.0f / sp.temps_global[k + 1]) *
-                            (sp.L_raw[(size_t)(k + 1) * sp.L_stride] - sp.L_raw[(size_t)k * sp.L_stride]);
+                            (sp.L_raw[(size_t)s1 * sp.L_stride] - sp.L_raw[(size_t)s0 * sp.L_stride]);
             const float pr = (d != d) ? 1.0f : fminf(1.0f, expf_fast(fminf(d, 80.0f)));
             if (sU[k] < pr) { sSrc[k] = k + 1; sSrc[k + 1] = k; atomicAdd(&sSrc[R], 1); }
         }
@@ -2527,7 +2582,30 @@ __global__ void swap_kernel(const SwapParams sp, const int round, const int mode
     int* sSrc = reinterpret_cast<int*>(smem + 2 * sp.R);
     const int nsw = cascade_lds(sp, round, sL, sU, sSrc);
     const int b = blockIdx.x;
-    if (mode & 1) {
+    if (sp.label_mode) {
+        // temperature t is handed to the chain that held temperature src[t]: only the maps change
+        if (mode & 1) {
+            const int g = sp.first_global + b;
+            const int t_old = sp.label_cur[g];
+            int t_new = t_old;
+            for (int t = threadIdx.x; t < sp.R; t += blockDim.x)
+                if (sSrc[t] == t_old) sL[0] = __int_as_float(t);           // exactly one t has src[t] == t_old (a permutation)
+            __syncthreads();
+            t_new = __float_as_int(sL[0]);
+            if (threadIdx.x == 0 && t_new != t_old) {
+                const float To = sp.temps_global[t_old], Tn = sp.temps_global[t_new];
+                sp.temps_local[b] = Tn;
+                // the chain keeps its own likelihood; while the chains are tempered it is re-tempered for the new temperature
+                if (!sp.canonical) sp.st_f[(size_t)b * SF_COUNT + SF_LIK] *= To / Tn;
+            }
+            if (b == 0)
+                for (int t = threadIdx.x; t < sp.R; t += blockDim.x) {
+                    const int slot = sp.slot_cur[sSrc[t]];
+                    sp.slot_next[t] = slot;
+                    sp.label_next[slot] = t;
+                }
+        }
+    } else if (mode & 1) {
         const int k = sp.first_global + b;
         const int s = sSrc[k];
         const int sl = s - sp.first_global;

@@ -26,134 +26,129 @@ CLS_PROBLEMS = {"winequality-red": (1, 11, 50, 10), "winequality-white": (2, 11,
 
 
 def _next_run_dir(folder, name):
-    run_nb = 0
-    while os.path.exists(folder + name + '_%s' % (run_nb)):
-        run_nb += 1
-    os.makedirs(folder + name + '_%s' % (run_nb))
-    return folder + name + '_%s' % (run_nb), run_nb
+    """`<folder><name>_<n>` with the first n that does not exist yet (REG:964-975)."""
+    n = 0
+    while os.path.exists(f"{folder}{name}_{n}"):
+        n += 1
+    os.makedirs(f"{folder}{name}_{n}")
+    return f"{folder}{name}_{n}", n
 
 
-def _append_row(path, allres, fmt, xv=None):
-    with open(path, 'a+') as f:
-        np.savetxt(f, allres, fmt=fmt, newline=' ')
-        if xv is not None:
-            np.savetxt(f, [xv], fmt="%s", newline=' \n')
+def _scatter_pair(plt, first, second, targets, fname, title=None, xlabel=None, ylabel=None):
+    """Two point clouds over the sample index, saved once per target directory.  The reference labels the TRAIN series 'Test'
+    and the TEST series 'Train' (REG:1079-1080, CLS:1152-1153); the files are compared by eye with its own, so that is kept."""
+    for target in targets:
+        plt.plot(first, '.', label='Test')
+        plt.plot(second, '.', label='Train')
+        plt.legend(loc='upper right')
+        if title:
+            plt.title(title)
+        if xlabel:
+            plt.xlabel(xlabel, fontsize=12)
+            plt.ylabel(ylabel, fontsize=12)
+        plt.savefig(os.path.join(target, fname))
+        plt.clf()
 
 
-def _plots(task, path, path_db, rmse_train, rmse_test, acc_train, acc_test, likelihood_rep, accept_vec, num_chains):
+def _lines(plt, curves, targets, fname, ylabel):
+    for target in targets:
+        plt.plot(curves)
+        plt.xlabel('Samples', fontsize=12)
+        plt.ylabel(ylabel, fontsize=12)
+        plt.savefig(os.path.join(target, fname))
+        plt.clf()
+
+
+def _plots(kind, path, path_db, res, num_chains):
+    """The figures of a run (REG:1077-1131, CLS:1150-1199): metric over samples, proposed log-likelihood per chain, accepted
+    proposals per chain.  Skipped when matplotlib is not importable."""
     try:
         import matplotlib
         matplotlib.use('agg')
         import matplotlib.pyplot as plt
-    except Exception:
+    except Exception:                                        # noqa: BLE001
         return False
-    if task == "reg":                                     # REG:1077-1097 (labels are swapped in the reference, kept)
-        for p in (path_db, path):
-            plt.plot(rmse_train, '.', label='Test')
-            plt.plot(rmse_test, '.', label='Train')
-            plt.legend(loc='upper right')
-            plt.xlabel('Samples', fontsize=12)
-            plt.ylabel('RMSE', fontsize=12)
-            plt.savefig(p + '/rmse_samples.pdf')
-            plt.clf()
-        ext = 'pdf'
-    else:                                                 # CLS:1150-1170
-        x = np.linspace(0, acc_train.shape[0], num=acc_train.shape[0])
-        for p in (path, path_db):
-            plt.plot(x, acc_train, '.', label='Test')
-            plt.plot(x, acc_test, '.', label='Train')
-            plt.legend(loc='upper right')
-            plt.title("Plot of Classification Acc. over time")
-            plt.savefig(p + '/acc_samples.png')
-            plt.clf()
-        ext = 'png'
-    likelihood = np.asarray(np.split(likelihood_rep[:, 0], num_chains))      # proposed likelihood per chain
-    for p in (path, path_db):
-        plt.plot(likelihood.T)
-        plt.xlabel('Samples', fontsize=12)
-        plt.ylabel(' Log-Likelihood', fontsize=12)
-        plt.savefig(p + '/likelihood.' + ext)
-        plt.clf()
-    plt.plot(accept_vec.T)
-    plt.xlabel('Samples', fontsize=12)
-    plt.ylabel(' Number accepted proposals', fontsize=12)
-    plt.savefig(path_db + '/accept.png')
-    plt.clf()
+    if kind == "reg":
+        _scatter_pair(plt, res["rmse_train"], res["rmse_test"], (path_db, path), 'rmse_samples.pdf', xlabel='Samples', ylabel='RMSE')
+    else:
+        _scatter_pair(plt, res["acc_train"], res["acc_test"], (path, path_db), 'acc_samples.png',
+                      title="Plot of Classification Acc. over time")
+    per_chain = res["likelihood"][:, 0].reshape(num_chains, -1)
+    _lines(plt, per_chain.T, (path, path_db), 'likelihood.' + ('pdf' if kind == "reg" else 'png'), ' Log-Likelihood')
+    _lines(plt, res["accept_vec"].T, (path_db,), 'accept.png', ' Number accepted proposals')
     return True
+
+
+_RESULT_NAMES = ("pos_w", "fx_train", "fx_test", "rmse_train", "rmse_test", "acc_train", "acc_test", "likelihood", "swap_perc",
+                 "accept_vec", "accept")
+# what differs between the two main() functions: result format, the metric that is summarised and which extreme is "best"
+_KINDS = {"reg": dict(fmt='%1.4f', metric="rmse", best=np.amin), "cls": dict(fmt='%1.2f', metric="acc", best=np.amax)}
+
+
+def _experiment(kind, pt_class, pt_args, name, problem, col5, NumSample, maxtemp, swap_interval, learn_rate, num_chains, burn_in,
+                problemfolder, problemfolder_db, plots):
+    """Run one experiment and leave what the reference's main() leaves: the run directories, result.txt and the master file in
+    both trees (15 numbers + run name: problem, NumSample, maxtemp, swap interval, Langevin probability | flag, learning rate,
+    train mean / std / best, test mean / std / best, swap %, accept %, minutes; REG:1052 / CLS:1138) and the figures."""
+    spec = _KINDS[kind]
+    path, run_nb = _next_run_dir(problemfolder, name)
+    path_db, _ = _next_run_dir(problemfolder_db, name)
+    t0 = time.time()
+    pt = pt_class(*pt_args(path))
+    for d in SUBDIRS:
+        pt.make_directory(path + d)
+    pt.initialize_chains(burn_in)
+    res = dict(zip(_RESULT_NAMES, pt.run_chains()))
+    minutes = (time.time() - t0) / 60
+    S = res["accept_vec"].shape[1]
+    accept_per = 100.0 * float(np.mean(res["accept_vec"][:, -1] / S))                # last cumulative count over samples (REG:1013-1016)
+    stats = [f(res[f"{spec['metric']}_{part}"]) for part in ("train", "test") for f in (np.mean, np.std, spec["best"])]
+    row = np.asarray([problem, NumSample, maxtemp, swap_interval, col5, learn_rate, *stats, res["swap_perc"], accept_per, minutes])
+    run_name = f"{name}_{run_nb}"
+    for run_dir, master_dir in ((path_db, problemfolder_db), (path, problemfolder)):
+        with open(run_dir + '/result.txt', 'a+') as f:
+            np.savetxt(f, row, fmt=spec["fmt"], newline=' ')
+        with open(master_dir + '/master_result_file.txt', 'a+') as f:
+            np.savetxt(f, row, fmt=spec["fmt"], newline=' ')
+            np.savetxt(f, [run_name], fmt="%s", newline=' \n')
+    if plots:
+        _plots(kind, path, path_db, res, num_chains)
+    return dict(allres=row, path=path, path_db=path_db, run_name=run_name, pt=pt)
 
 
 def run_regression(name, traindata, testdata, *, problem=None, hidden=10, ip=4, output=1, NumSample=100000, maxtemp=2,
                    swap_ratio=0.01, num_chains=10, burn_in=0.5, learn_rate=0.1, use_langevin_gradients=True,
                    langevin_prob=0.5, problemfolder='Res_PT/', problemfolder_db='Res_PT_db/', plots=True, **pt_kwargs):
-    """One pass of the loop body of REG main() (REG:881-1150).  Returns the 15-number summary row and the run paths."""
+    """One pass of the loop body of REG main() (REG:881-1150): defaults are its literals.  Returns the summary row and paths."""
     from .pt_timeseries_regression import ParallelTempering
-    problem = REG_PROBLEMS.get(name, 0) if problem is None else problem
-    topology = [ip, hidden, output]
     swap_interval = int(swap_ratio * NumSample / num_chains)                 # REG:949
-    path, run_nb = _next_run_dir(problemfolder, name)
-    path_db, _ = _next_run_dir(problemfolder_db, name)
-    timer = time.time()
-    pt = ParallelTempering(use_langevin_gradients, learn_rate, traindata, testdata, topology, num_chains, maxtemp, NumSample,
-                           swap_interval, langevin_prob, path, **pt_kwargs)
-    for d in SUBDIRS:
-        pt.make_directory(path + d)
-    pt.initialize_chains(burn_in)
-    (pos_w, fx_train, fx_test, rmse_train, rmse_test, acc_train, acc_test, likelihood_rep, swap_perc, accept_vec,
-     accept) = pt.run_chains()
-    list_end = accept_vec.shape[1]
-    accept_ratio = accept_vec[:, list_end - 1:list_end] / list_end
-    accept_per = np.mean(accept_ratio) * 100
-    timetotal = (time.time() - timer) / 60
-    rmse_tr, rmsetr_std, rmsetr_max = np.mean(rmse_train[:]), np.std(rmse_train[:]), np.amin(rmse_train[:])
-    rmse_tes, rmsetest_std, rmsetes_max = np.mean(rmse_test[:]), np.std(rmse_test[:]), np.amin(rmse_test[:])
-    xv = name + '_' + str(run_nb)
-    allres = np.asarray([problem, NumSample, maxtemp, swap_interval, langevin_prob, learn_rate, rmse_tr, rmsetr_std, rmsetr_max,
-                         rmse_tes, rmsetest_std, rmsetes_max, swap_perc, accept_per, timetotal])
-    for p_run, p_master in ((path_db, problemfolder_db), (path, problemfolder)):
-        _append_row(p_run + '/result.txt', allres, '%1.4f')
-        _append_row(p_master + '/master_result_file.txt', allres, '%1.4f', xv)
-    if plots:
-        _plots("reg", path, path_db, rmse_train, rmse_test, acc_train, acc_test, likelihood_rep, accept_vec, num_chains)
-    return dict(allres=allres, path=path, path_db=path_db, run_name=xv, pt=pt)
+    topology = [ip, hidden, output]
+
+    def pt_args(path):
+        return (use_langevin_gradients, learn_rate, traindata, testdata, topology, num_chains, maxtemp, NumSample, swap_interval,
+                langevin_prob, path)
+    pt_class = (lambda *a: ParallelTempering(*a, **pt_kwargs))
+    return _experiment("reg", pt_class, pt_args, name, REG_PROBLEMS.get(name, 0) if problem is None else problem, langevin_prob,
+                       NumSample, maxtemp, swap_interval, learn_rate, num_chains, burn_in, problemfolder, problemfolder_db, plots)
 
 
 def run_classification(name, traindata, testdata, *, problem=None, hidden=None, ip=None, output=None, NumSample=50000,
                        maxtemp=10, swap_ratio=0.02, num_chains=10, burn_in=0.5, learn_rate=0.01, use_langevin_gradients=False,
                        problemfolder='PT_Eval/', problemfolder_db='PT_Eval_db/', plots=True, **pt_kwargs):
-    """One pass of the loop body of CLS main() (CLS:903-1199)."""
+    """One pass of the loop body of CLS main() (CLS:903-1199); the topology of a known problem comes from its table."""
     from .pt_classification import ParallelTempering
     if name in CLS_PROBLEMS:
         pnum, pip, phid, pout = CLS_PROBLEMS[name]
         problem = pnum if problem is None else problem
         ip, hidden, output = ip or pip, hidden or phid, output or pout
-    topology = [ip, hidden, output]
     swap_interval = int(swap_ratio * NumSample / num_chains)                 # CLS:1040
-    path, run_nb = _next_run_dir(problemfolder, name)
-    path_db, _ = _next_run_dir(problemfolder_db, name)
-    timer = time.time()
-    pt = ParallelTempering(use_langevin_gradients, learn_rate, traindata, testdata, topology, num_chains, maxtemp, NumSample,
-                           swap_interval, path, **pt_kwargs)
-    for d in SUBDIRS:
-        pt.make_directory(path + d)
-    pt.initialize_chains(burn_in)
-    (pos_w, fx_train, fx_test, rmse_train, rmse_test, acc_train, acc_test, likelihood_rep, swap_perc, accept_vec,
-     accept) = pt.run_chains()
-    timer2 = time.time()
-    list_end = accept_vec.shape[1]
-    accept_ratio = accept_vec[:, list_end - 1:list_end] / list_end
-    accept_per = np.mean(accept_ratio) * 100
-    timetotal = (timer2 - timer) / 60
-    acc_tr, acctr_std, acctr_max = np.mean(acc_train[:]), np.std(acc_train[:]), np.amax(acc_train[:])
-    acc_tes, acctest_std, acctes_max = np.mean(acc_test[:]), np.std(acc_test[:]), np.amax(acc_test[:])
-    xv = name + '_' + str(run_nb)
-    allres = np.asarray([problem or 0, NumSample, maxtemp, swap_interval, use_langevin_gradients, learn_rate, acc_tr, acctr_std,
-                         acctr_max, acc_tes, acctest_std, acctes_max, swap_perc, accept_per, timetotal])
-    for p_run, p_master in ((path_db, problemfolder_db), (path, problemfolder)):
-        _append_row(p_run + '/result.txt', allres, '%1.2f')
-        _append_row(p_master + '/master_result_file.txt', allres, '%1.2f', xv)
-    if plots:
-        _plots("cls", path, path_db, rmse_train, rmse_test, acc_train, acc_test, likelihood_rep, accept_vec, num_chains)
-    return dict(allres=allres, path=path, path_db=path_db, run_name=xv, pt=pt)
+    topology = [ip, hidden, output]
+
+    def pt_args(path):
+        return (use_langevin_gradients, learn_rate, traindata, testdata, topology, num_chains, maxtemp, NumSample, swap_interval, path)
+    pt_class = (lambda *a: ParallelTempering(*a, **pt_kwargs))
+    return _experiment("cls", pt_class, pt_args, name, problem or 0, use_langevin_gradients, NumSample, maxtemp, swap_interval,
+                       learn_rate, num_chains, burn_in, problemfolder, problemfolder_db, plots)
 
 
 def split_and_normalise(features, classes, ip, train_ratio=0.7, rng=None):

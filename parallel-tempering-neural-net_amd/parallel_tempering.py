@@ -27,6 +27,26 @@ def _text_round(a, fmt, threads=8):
     return _lib.text_round(a, fmt, threads)
 
 
+def stitch_by_temperature(tr, swap_log, handoff_steps, S):
+    """Label swapping: the device records trace rows per chain slot and a slot's temperature changes at the swap rounds.  Row
+    i + 1 is written by MH step i, so the rows up to the hand-off step + 1 belong to the assignment before the round; round k
+    hands temperature t to the chain that held temperature swap_log[k][t].  -> (traces keyed by temperature, final holder[t])."""
+    R = next(v for v in tr.values() if v is not None).shape[0]
+    holder = np.arange(R)                                    # holder[t] = slot whose chain holds temperature t
+    out = {k: (None if v is None else np.empty_like(v)) for k, v in tr.items()}
+    row0 = 0
+    for k, i_k in enumerate(list(handoff_steps) + [None]):
+        row1 = S if i_k is None else i_k + 2
+        for key, v in tr.items():
+            if v is not None:
+                out[key][:, row0:row1] = v[holder, row0:row1]
+        if i_k is None:
+            break
+        holder = holder[np.asarray(swap_log[k])]
+        row0 = row1
+    return out, holder
+
+
 class ParallelTemperingBase:
     task = None                       # set by the two drop-in subclasses
     rmse_fmt = None                   # REG '%1.8f' (REG:462-464), CLS '%1.2f' (CLS:473-475)
@@ -34,7 +54,7 @@ class ParallelTemperingBase:
     def __init__(self, use_langevin_gradients, learn_rate, traindata, testdata, topology, num_chains, maxtemp,
                  NumSample, swap_interval, langevin_prob, path, *, seed=None, device=None, devices=None, exchange="auto",
                  transport=None, waves_per_replica=0, schedule=0, groups_per_replica=0, trace_capacity=0, swap_rule=0,
-                 shared_noise=False, write_files=True, io_threads=None):
+                 label_swap=False, shared_noise=False, write_files=True, io_threads=None):
         # FNN chain variables (REG:491-494)
         self.traindata = traindata
         self.testdata = testdata
@@ -76,6 +96,10 @@ class ParallelTemperingBase:
         self.groups_per_replica = int(groups_per_replica)
         self.swap_rule = int(swap_rule)          # 0 = the reference's cascade; 1 = even/odd Metropolis exchange (not in the reference)
         self.shared_noise = bool(shared_noise)   # True: all chains read one noise tape, as the reference's forked chains do (Q14)
+        # True: swap rounds permute which chain holds which temperature instead of moving (w, eta) between the temperature slots
+        # (zero payload between GPUs; not in the reference).  The files stay keyed by temperature: the rows a
+        # temperature's files hold are those of the chain that held it at the time (_stitch_by_temperature).
+        self.label_swap = bool(label_swap)
         self.trace_capacity = int(trace_capacity)   # rows per replica kept in HBM (0 = all); smaller = streamed to the host
         self.write_files = bool(write_files)
         self.io_threads = io_threads or min(16, os.cpu_count() or 1)
@@ -144,7 +168,7 @@ class ParallelTemperingBase:
             n_samples=S, swap_interval=int(self.swap_interval), pt_switch_step=self._pt_switch_step(),
             use_langevin=1 if self.use_langevin_gradients is True else 0, waves_per_replica=self.waves_per_replica,
             schedule=self.schedule, groups_per_replica=self.groups_per_replica, trace_capacity=self.trace_capacity,
-            swap_rule=self.swap_rule, shared_noise=int(self.shared_noise),
+            swap_rule=self.swap_rule, shared_noise=int(self.shared_noise), label_swap=int(self.label_swap),
             l_prob=float(self.langevin_prob), learn_rate=float(self.learn_rate), step_w=0.025, step_eta=0.2,
             sigma_squared=25.0, nu_1=0.0, nu_2=0.0, seed=self.seed)
         if self.devices is not None and len(self.devices) > 1:
@@ -155,7 +179,7 @@ class ParallelTemperingBase:
             self._sampler = _lib.Sampler(device_id=dev, n_replicas_local=self.num_chains, first_global_replica=0, **config)
         self._sampler.set_data(train, test)
         self._sampler.set_state(self._w0, self.temperatures)
-        if self.swap_rule == 1:
+        if self.swap_rule == 1 or self.label_swap:
             self._sampler.set_ladder(self.temperatures)
 
     # ------------------------------------------------------------------ run_chains (REG:694-771)
@@ -220,6 +244,8 @@ class ParallelTemperingBase:
             self.num_swap, self.total_swap_proposals, self.rounds = self._sampler.swap_stats()
             tr = self._sampler.traces()
             t2 = time.perf_counter()
+        if self.label_swap:
+            tr = self._stitch_by_temperature(tr)
         if self.write_files:
             self._write_chain_files(tr)
         t3 = time.perf_counter()
@@ -233,6 +259,18 @@ class ParallelTemperingBase:
         swap_perc = self.num_swap * 100 / self.total_swap_proposals            # ZeroDivisionError when no round ran (REG:769)
         return (pos_w, fx_train, fx_test, rmse_train, rmse_test, acc_train, acc_test, likelihood_vec, swap_perc,
                 accept_vec, accept)
+
+    # ------------------------------------------------------------------ label swapping: rows per chain slot -> rows per temperature
+    def _handoff_steps(self):
+        """MH steps after which a swap round moved something: REG i % si == 0, i != 0 (REG:427); CLS (i + 1) % si == 0 (CLS:438)."""
+        si, S = int(self.swap_interval), self.NumSamples
+        if self.task == TASK_REG:
+            return [i for i in range(1, S - 1) if i % si == 0]
+        return [i for i in range(S - 1) if (i + 1) % si == 0]
+
+    def _stitch_by_temperature(self, tr):
+        out, self._final_holder = stitch_by_temperature(tr, self._sampler.swap_log(), self._handoff_steps(), self.NumSamples)
+        return out
 
     # ------------------------------------------------------------------ per-chain files (REG:454-481)
     def _chain_file_jobs(self, tr):
@@ -259,6 +297,8 @@ class ParallelTemperingBase:
     def _write_chain_files(self, tr):
         # accept_list[i+1] holds the count BEFORE step i (REG:380); the percentage file uses the final count
         self._final_accepted = self._sampler.state()["num_accepted"]
+        if self.label_swap:                                  # per temperature: the count of the chain that holds it at the end
+            self._final_accepted = self._final_accepted[self._final_holder]
         jobs = self._chain_file_jobs(tr)
         with ThreadPoolExecutor(max_workers=self.io_threads) as ex:
             list(ex.map(lambda j: _lib.savetxt(*j), jobs))
@@ -270,6 +310,8 @@ class ParallelTemperingBase:
     def show_results(self, tr=None):
         if tr is None:
             tr = self._sampler.traces()
+            if self.label_swap:
+                tr = self._stitch_by_temperature(tr)
         S, R, P = self.NumSamples, self.num_chains, self.num_param
         burnin = int(S * self.burn_in)
         # the reference re-reads the per-chain text files, so every value below has been through their format

@@ -103,14 +103,14 @@ def golden(name):
 
 
 def make_sampler(task, topo, train, test, *, R_local, R_global, first, S, si, use_lg, lr, seed, l_prob=0.5, waves=0,
-                 schedule=0, groups=0, trace_capacity=0, forward_bf16=0, swap_rule=0, shared_noise=0):
+                 schedule=0, groups=0, trace_capacity=0, forward_bf16=0, swap_rule=0, shared_noise=0, label_swap=0):
     import ptnn_amd
     from ptnn_amd import _lib
     pt = S * 0.6
     s = _lib.Sampler(device_id=0, task=task, n_in=topo[0], n_hidden=topo[1], n_out=topo[2], n_replicas_local=R_local,
                      n_replicas_global=R_global, first_global_replica=first, n_samples=S, swap_interval=si,
                      pt_switch_step=int(pt) if pt == int(pt) else -1, use_langevin=int(bool(use_lg)),
-                     waves_per_replica=waves, schedule=schedule, groups_per_replica=groups, trace_capacity=trace_capacity, forward_bf16=forward_bf16, swap_rule=swap_rule, shared_noise=int(shared_noise), l_prob=l_prob, learn_rate=lr, step_w=0.025, step_eta=0.2,
+                     waves_per_replica=waves, schedule=schedule, groups_per_replica=groups, trace_capacity=trace_capacity, forward_bf16=forward_bf16, swap_rule=swap_rule, shared_noise=int(shared_noise), label_swap=int(label_swap), l_prob=l_prob, learn_rate=lr, step_w=0.025, step_eta=0.2,
                      sigma_squared=25.0, nu_1=0.0, nu_2=0.0, seed=seed)
     s.set_data(train, test)
     return s
@@ -157,6 +157,7 @@ class OracleRun:
                 self.logu[r, i] = np.log(rep.last_u)
                 self.scale[r, i] = rep.last_scale
                 self.stale[r, i] = rep.last_stale
+            pt._steps_done = i + 1
             if orc.swap_trigger(pt.task, i, pt.si):
                 pt.swap_round()
         rounds = int(pt.S / pt.si) if pt.si > 0 else 0

@@ -868,3 +868,90 @@ def test_baseline_replica_counts_against_oracle(name):
     # else: among R x S decisions one landed inside the fp32 bound of log alpha -- check_run_against_oracle has verified that it
     # is such a decision (log u between the two log alphas) and that everything before it agrees
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["reg_cascade", "cls_cascade", "reg_evenodd"])
+def test_label_swapping_option(case):
+    """SURVEY 8f-4, second half (`label_swap=1`, default off): the chains stay in place and the temperatures move, so a swap
+    round copies nothing.  PARITY UNPINNED by nature -- the reference has no such mode; checked against the oracle's restatement
+    (PTOracle(label_swap=True): a chain keeps its own likelihood, re-tempered, its prior, counters and noise stream), with the
+    per-slot device traces stitched into per-temperature rows the way the drop-in class does for the result files."""
+    import ptnn_amd  # noqa: F401
+    from ptnn_amd.parallel_tempering import stitch_by_temperature
+    d = ds()
+    if case.startswith("reg"):
+        task, topo, name, lg, lr, mt, R, S, si = 0, (4, 5, 1), "sunspot", True, 0.1, 2, 6, 63, 7
+    else:
+        task, topo, name, lg, lr, mt, R, S, si = 1, (4, 12, 3), "iris", False, 0.01, 10, 6, 60, 6
+    rule = 1 if case.endswith("evenodd") else 0
+    seed = 321
+    train, test = d[name + "_train"], d[name + "_test"]
+    pt = orc.PTOracle(task, topo, train, test, R, mt, R * S, si, use_lg=lg, l_prob=0.5, lr=lr, seed=seed, swap_rule=rule, label_swap=True)
+    w0 = np.stack([rep.w for rep in pt.replicas]).astype(np.float32)
+    for rep, w in zip(pt.replicas, w0):
+        rep.__init__(task, topo, pt.train, pt.test, w.astype(np.float64), rep.T, S, lg, 0.5, lr, pt.tape, rep.gid)
+    pt.holder_hist = [(0, list(pt.replicas))]
+    pt.run()
+    want = pt.traces_by_temperature()
+    s = parity.make_sampler(task, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=lg, lr=lr, seed=seed,
+                            swap_rule=rule, label_swap=1)
+    s.set_state(w0, np.array(pt.temperatures, dtype=np.float32))
+    with pytest.raises(Exception, match="ptnn_set_ladder"):
+        s.run(-1)
+    s.set_ladder(pt.temperatures)
+    s.run(-1)
+    s.sync()
+    nsw, tot, rounds = s.swap_stats()
+    assert rounds == pt.rounds_done and tot == pt.total_swap_proposals
+    log = s.swap_log()
+    steps = [i for i in range(S - 1) if orc.swap_trigger(task, i, si)]
+    got, holder = stitch_by_temperature(s.traces(), log, steps, S)
+    same_rounds = all(list(log[k]) == list(pt.src_log[k]) for k in range(rounds))
+    first_diff = np.nonzero((got["accept"].astype(np.int64) != want["accept"].astype(np.int64)).any(axis=0))[0]
+    upto = S if not first_diff.size else int(first_diff[0]) - 1
+    if not same_rounds:
+        k = next(k for k in range(rounds) if list(log[k]) != list(pt.src_log[k]))
+        upto = min(upto, steps[k] + 2 if k < len(steps) else S)
+    assert upto > 3 * si, f"chains parted after {upto} rows"          # several rounds of label moves were compared
+    np.testing.assert_allclose(got["pos_w"][:, :upto], want["pos_w"][:, :upto], rtol=parity.RTOL, atol=2e-5)
+    np.testing.assert_allclose(got["likeh"][:, :upto], want["likeh"][:, :upto], rtol=5e-5, atol=5e-3)
+    np.testing.assert_allclose(got["rmse_train"][:, :upto], want["rmse_train"][:, :upto], rtol=1e-4, atol=1e-6)
+    assert (got["accept"][:, :upto] == want["accept"][:, :upto]).all()
+    if upto == S and same_rounds:
+        assert nsw == pt.num_swap and nsw > 0
+        # the final slot <-> temperature map: chain c (its noise stream id) holds temperature label[c]
+        lab = s.labels()
+        assert sorted(lab.tolist()) == list(range(R))
+        assert [pt.replicas[t].gid for t in range(R)] == [int(np.nonzero(lab == t)[0][0]) for t in range(R)]
+        assert (holder == np.array([rep.gid for rep in pt.replicas])).all()
+    s.close()
+
+
+@pytest.mark.gpu
+def test_label_swapping_drop_in_and_sharded(tmp_path):
+    """`ParallelTempering(..., label_swap=True)` end to end, on one device and on a ladder cut into two blocks (where nothing but
+    the posted scalars crosses the boundary): same 11-tuple, same files."""
+    import ptnn_amd  # noqa: F401
+    from ptnn_amd.pt_timeseries_regression import ParallelTempering
+    d = ds()
+    res = []
+    for sub, kw in (("a", {}), ("b", dict(devices=[0, 0]))):
+        path = str(tmp_path / sub)
+        os.makedirs(path)
+        pt = ParallelTempering(True, 0.1, d["sunspot_train"], d["sunspot_test"], [4, 5, 1], 8, 2, 8 * 60, 6, 0.5, path, seed=5,
+                               label_swap=True, **kw)
+        for sdir in ("predictions", "posterior", "posterior/pos_w", "posterior/pos_likelihood", "posterior/accept_list"):
+            pt.make_directory(os.path.join(path, sdir))
+        pt.initialize_chains(0.5)
+        res.append((pt.run_chains(), pt))
+    for x, y in zip(res[0][0], res[1][0]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    assert res[0][1].num_swap == res[1][1].num_swap > 0
+    stats = res[1][1]._sampler.comm_stats()
+    # zero payload: per round each rank contributes its 4 posted scalars (4 x 4 bytes) and nothing else
+    assert all(st["bytes_sent"] == st["rounds"] * 4 * 4 for st in stats), stats
+    for root, _, files in os.walk(tmp_path / "a"):
+        for f in files:
+            pa = os.path.join(root, f)
+            assert open(pa, "rb").read() == open(pa.replace(str(tmp_path / "a"), str(tmp_path / "b")), "rb").read(), f
