@@ -240,6 +240,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10, help="untimed whole runs before them")
     ap.add_argument("--workload", default="sunspot64", choices=list(WORKLOADS))
     ap.add_argument("--rw", action="store_true", help="random-walk proposals only (extra data point)")
+    ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU instead of the workload's own count (extra data point)")
     ap.add_argument("--bf16", action="store_true", help="synthetic512: forward GEMM operands in bf16 (tolerance study mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra legs (kept-half split run, dependent-chain "
@@ -262,6 +263,9 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         N = world
     wl = dict(WORKLOADS[a.workload])
+    if a.replicas:
+        wl["desc"] = wl["desc"].replace(f"{wl['R']} replicas", f"{a.replicas} replicas")
+        wl["R"] = a.replicas
     if a.rw:
         wl["lg"] = False
         wl["desc"] = wl["desc"].replace("Langevin p=0.5 lr=0.1", "random-walk").replace("Langevin p=0.5", "random-walk")
@@ -346,7 +350,7 @@ def main():
         # 4 (P + 7) bytes (pos_w row + likeh + 2 rmse + 2 acc + accept count); a swap round adds 4 (P + 2) per replica
         bytes_per_launch = R * steps_per_launch * 4 * (P + 7) + R * 4 * (P + 2)
         flops_per_launch = R * steps_per_launch * flops_per_step(wl["topo"], train.shape[0], test.shape[0], 0.5 if wl["lg"] else 0.0)
-        traffic, traffic_tag = pmc_traffic(a.workload, info["kernel"]) if (a.schedule, a.waves, a.groups, a.rw, a.bf16) == (0, 0, 0, False, False) and N == 1 else (None, None)
+        traffic, traffic_tag = pmc_traffic(a.workload, info["kernel"]) if (a.schedule, a.waves, a.groups, a.rw, a.bf16, a.replicas) == (0, 0, 0, False, False, 0) and N == 1 else (None, None)
         roof = {"bound": "hbm", "achieved": bytes_per_launch / avg_launch_s / 1e9 if launches else 0.0, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "traffic": traffic, "kernel": info["kernel"], "avg_launch_ms": avg_launch_s * 1e3,
                 "launches": launches, "mh_steps_per_launch": steps_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
