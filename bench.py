@@ -250,6 +250,9 @@ def main():
     ap.add_argument("--groups", type=int, default=0, help="work-groups (CUs) per replica, speculative schedule (0 = auto)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "gather", "boundary"],
                     help="N > 1: what a swap round moves between GPUs (ptnn_comm_set_mode)")
+    ap.add_argument("--force-comm", action="store_true", help="N = 1: attach a one-rank communicator anyway, so that the whole N > 1 code "
+                    "path (torch.distributed rendezvous next to RCCL inside libptnn, swap rounds through the communicator) runs on a "
+                    "one-GPU box")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
                     help="N > 1: rccl = RCCL over xGMI inside libptnn; host = host-staged through gloo (rehearsal of the N > 1 code "
                          "path with every rank on GPU 0 of a one-GPU box; what it prints is not a measurement)")
@@ -277,7 +280,12 @@ def main():
         cpu = cpu_baseline(wl, train, test)      # before the first HIP call: the pool forks
 
     dist = None
-    if N > 1:
+    sharded = N > 1 or a.force_comm
+    if sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -288,7 +296,7 @@ def main():
         device = local_rank
     lad = Ladder(wl, a, train, test, rank, N, device)
     s = lad.s
-    if N > 1:
+    if sharded:
         from ptnn_amd import _lib
         if a.transport == "rccl":
             uid = [_lib.comm_unique_id() if rank == 0 else None]
@@ -381,7 +389,7 @@ def main():
                        "proposals": "langevin p=0.5" if wl["lg"] else "random-walk", "schedule": info["schedule"],
                        "slots_per_round": info["slots_per_round"], "groups_per_replica": info["groups_per_replica"],
                        "block_threads": info["block_threads"], "lds_bytes": info["lds_bytes"], "exchange": info.get("exchange", "none"),
-                       "transport": a.transport if N > 1 else "none"},
+                       "transport": a.transport if sharded else "none"},
             "swap_accept_pct": 100.0 * nsw / max(tot, 1), "swap_rounds_per_run": rounds,
             "mh_accept_pct": float(100.0 * np.mean(st["num_accepted"]) / max(S - 1, 1)),
             "roofline": roof,

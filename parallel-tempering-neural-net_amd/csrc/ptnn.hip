@@ -235,8 +235,9 @@ int launch_swap(ptnn_handle* h, bool phantom, int mode, bool want_src) {
         sp.L = h->d_xchg + 2 * h->PS + 1; sp.L_stride = sp.XS;
         sp.L_raw = h->d_xchg + 2 * h->PS + 2; sp.prior_post = h->d_xchg + 2 * h->PS + 3;
     }
-    const size_t lds = (size_t)(3 * sp.R + 1) * sizeof(float);
-    hipLaunchKernelGGL(swap_kernel, dim3(sp.Rl), dim3(64), lds, h->stream, sp, h->rounds_done, mode);
+    const size_t lds = (size_t)(3 * sp.R + 1) * sizeof(float);        // L, ln 2u, src (+ count)
+    const int swap_threads = (sp.R <= 512 && sp.PS <= 256) ? 64 : 256;     // more threads for long ladders and long rows
+    hipLaunchKernelGGL(swap_kernel, dim3(sp.Rl), dim3(swap_threads), lds, h->stream, sp, h->rounds_done, mode);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -2516,7 +2516,9 @@ __device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, floa
         if (k < R - 1) {
             uint32_t x[4];
             philox4x32_10((uint32_t)k, (uint32_t)round, 0u, STREAM_SWAP, sp.seed_lo, sp.seed_hi, x);
-            sU[k] = u23(x[0]);
+            // rule 0 compares in the log domain (below): ln(2 u) is computed here, by all threads at once, instead of an exp inside
+            // the sequential chain
+            sU[k] = (sp.rule == 1) ? u23(x[0]) : logf_fast(2.0f * u23(x[0]));
         }
     }
     __syncthreads();
@@ -2535,22 +2537,45 @@ __device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, floa
         __syncthreads();
         return sSrc[R];
     }
-    if (threadIdx.x == 0) {
-        // the carried state's L stays in a register: the only LDS reads of a step (L[k+1], u[k]) have addresses that do not
-        // depend on the decisions, so they run ahead of the chain
+    // REG:674-679: swap iff u < min(1, 0.5 exp(min(709, L[k+1] - L[c]))).  u < 1 always, so the outer min never binds, and with
+    // u > 0 the test is ln(2 u) < min(709, L[k+1] - L[c]) -- subtract, clamp, compare, no transcendental.
+    //
+    // The bubble pass is sequential only through WHICH state is being carried: while the carried state is c, the tests of the
+    // pairs ahead are all against the same L[c], i.e. independent.  Wave 0 takes the pairs 64 at a time (lane = pair), tests
+    // all of them against the current carried L with one compare, and a ballot finds the first pair where it fails: the
+    // carried state is dropped there (src[k] = c), the next state is picked up (its L comes from that lane's register) and
+    // the lanes behind it are re-tested -- one iteration per DROP, not per pair, plus one per 64 pairs.  Wave-uniform control
+    // throughout.  (Round 1 walked the pairs one by one in thread 0 of every block, with an exp, a branch and an LDS store per
+    // pair: 95 ns per pair -- 6.1 us per round at R = 64, 40 us at 256, 72 us at 1024; independent forward scans from every
+    // start + pointer doubling were tried and are worse, because the reference's rule accepts 60 - 98 % of the swaps and the runs
+    // are long.)
+    if (threadIdx.x < WAVE) {
+        const int lane = threadIdx.x;
         int c = 0, nsw = 0;
         float Lc = sL[0];
-#pragma unroll 4
-        for (int k = 0; k < R - 1; ++k) {
-            const float Ln = sL[k + 1];
-            float d = Ln - Lc;
-            d = (d < 709.0f) ? d : 709.0f;                  // python min(709, nan) == 709
-            const float pr = fminf(1.0f, 0.5f * expf_fast(d));
-            if (sU[k] < pr) { sSrc[k] = k + 1; nsw++; }
-            else { sSrc[k] = c; c = k + 1; Lc = Ln; }
+        for (int k0 = 0; k0 < R - 1; k0 += WAVE) {
+            const int k = k0 + lane;
+            const bool valid = k < R - 1;
+            const float Ln = valid ? sL[k + 1] : 0.0f;
+            const float tk = valid ? sU[k] : 0.0f;
+            unsigned long long todo = __ballot(valid);
+            unsigned long long swapped = 0ull;
+            while (todo) {
+                float d = Ln - Lc;
+                d = (d < 709.0f) ? d : 709.0f;              // python min(709, nan) == 709
+                const unsigned long long fail = __ballot(!(tk < d)) & todo;
+                if (!fail) { swapped |= todo; break; }       // the carried state passes every remaining pair of this window
+                const int j = __ffsll((long long)fail) - 1;  // first pair where it is dropped
+                swapped |= todo & ((1ull << j) - 1ull);
+                if (lane == j) sSrc[k] = c;                  // slot k0 + j receives the carried state ...
+                c = k0 + j + 1;                              // ... and the state of the next slot is picked up
+                Lc = __shfl(Ln, j);
+                todo &= (j == 63) ? 0ull : ~((2ull << j) - 1ull);
+            }
+            if (valid && ((swapped >> lane) & 1ull)) sSrc[k] = k + 1;
+            nsw += __popcll(swapped);
         }
-        sSrc[R - 1] = c;
-        sSrc[R] = nsw;
+        if (lane == 0) { sSrc[R - 1] = c; sSrc[R] = nsw; }
     }
     __syncthreads();
     return sSrc[R];
@@ -2616,14 +2641,21 @@ __global__ void swap_kernel(const SwapParams sp, const int round, const int mode
             const float* from = sp.xchg + (size_t)s * sp.XS;
             float* to = sp.next + (size_t)b * sp.PS;
             float* gto = sp.gd_next + (size_t)b * sp.PS;
-            for (int j = threadIdx.x; j < sp.PS; j += blockDim.x) { to[j] = from[j]; gto[j] = from[sp.PS + j]; }
+            // rows are multiples of 4 floats and 16-byte aligned (PS = round4(P + 1), XS = round4(2 PS + 4))
+            for (int j = threadIdx.x; j < sp.PS / 4; j += blockDim.x) {
+                reinterpret_cast<float4*>(to)[j] = reinterpret_cast<const float4*>(from)[j];
+                reinterpret_cast<float4*>(gto)[j] = reinterpret_cast<const float4*>(from + sp.PS)[j];
+            }
             valid = (from[2 * sp.PS] != 0.0f) ? 1 : 0;
         } else if (sl >= 0 && sl < sp.Rl) {
             const float* from = sp.cur + (size_t)sl * sp.PS;
             float* to = sp.next + (size_t)b * sp.PS;
             const float* gfrom = sp.gd_cur + (size_t)sl * sp.PS;
             float* gto = sp.gd_next + (size_t)b * sp.PS;
-            for (int j = threadIdx.x; j < sp.PS; j += blockDim.x) { to[j] = from[j]; gto[j] = gfrom[j]; }
+            for (int j = threadIdx.x; j < sp.PS / 4; j += blockDim.x) {
+                reinterpret_cast<float4*>(to)[j] = reinterpret_cast<const float4*>(from)[j];
+                reinterpret_cast<float4*>(gto)[j] = reinterpret_cast<const float4*>(gfrom)[j];
+            }
             valid = sp.gd_valid_cur[sl];
         }
         if (threadIdx.x == 0) sp.gd_valid_next[b] = valid;
