@@ -478,7 +478,11 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
             (h->cfg.schedule == PTNN_SCHED_AUTO && sched == PTNN_SCHED_SPECULATIVE && fits && pays && h->cfg.use_langevin &&
              h->cfg.waves_per_replica == 0 && h->cfg.groups_per_replica == 0)) {
             h->packed = true; h->speculative = true; h->groups = 1;
-            h->nthreads = PK_WAVES * WAVE;
+            // eight waves (forward passes two to a SIMD) while every replica has a CU to itself, four beyond that; an explicit
+            // waves_per_replica of 4 or 8 decides otherwise
+            const int pkw = (h->cfg.waves_per_replica == 4 || h->cfg.waves_per_replica == 8) ? h->cfg.waves_per_replica
+                            : (h->cfg.n_replicas_local <= h->num_cus ? PK_WAVES : 4);
+            h->nthreads = pkw * WAVE;
             h->seg_lds = pk;
             sched = PTNN_SCHED_PACKED;
         }

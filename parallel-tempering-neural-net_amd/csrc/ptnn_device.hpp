@@ -323,10 +323,23 @@ typedef __attribute__((address_space(4))) float cfloat;    // constant address s
 // in file order, each row is a dependent chain; the next row's inputs are fetched while this one computes.
 // Lanes >= H carry B1 = +1e30 so their hidden activation is exactly 0 and they never contribute or update.
 // ------------------------------------------------------------------------------------------------
-template <int TASK, int I, int O, int NRED>
+// Where the lane groups of a packed sweep find their input vectors when these are PROPOSALS that nobody has written out yet:
+// group g sweeps from  base + step_w * noise  with the noise row of ring slot (pos0 + g) mod ring and base = w_gd when the
+// step's Langevin coin (first scalar of the same ring slot) came up, else w_cur -- the same fmaf the proposal is written with.
+struct SweepProposals {
+    const float* noise;      // ring[ring][nstride]
+    const float* scal;       // ring[ring][4]: {lx, u, n_eta, -}
+    const float* w_cur;
+    const float* w_gd;
+    int pos0, ring, nstride;
+    float step_w, l_prob;
+    int use_lg;
+};
+
+template <int TASK, int I, int O, int NRED, bool PROP = false>
 __device__ __forceinline__ void sgd_sweep(const float* __restrict__ w_in, float* __restrict__ w_out,
                                           const float* __restrict__ xy, const float* __restrict__ gdata, int Ntr, int H,
-                                          float lr, int ngroups = 1, int gstride = 0) {
+                                          float lr, int ngroups = 1, int gstride = 0, const SweepProposals* pp = nullptr) {
     // All weights are kept pre-multiplied by c = -log2(e): the pre-activation then IS the exponent of
     // sigmoid(z) = 1 / (1 + 2^(c z)), and every update rule keeps its shape with lr folded into two constants:
     //   W1' += lr (g' dh) x,  B1' -= lr g' dh      with g' = sum_o od W2'[.,o]  (= c g)
@@ -342,19 +355,33 @@ __device__ __forceinline__ void sgd_sweep(const float* __restrict__ w_in, float*
     const bool gact = grp < ngroups;
     const bool act = gact && (lane < H);
     const int hl = act ? lane : 0;
-    w_in += (size_t)(gact ? grp : 0) * gstride;
+    if constexpr (!PROP) w_in += (size_t)(gact ? grp : 0) * gstride;
     w_out += (size_t)(gact ? grp : 0) * gstride;
     const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
     const float clr = C * lr;
     const float m0 = (lane == 0) ? 1.0f : 0.0f;
     float w1[I], w2[O], cl[O];
+    const float* pnz = nullptr;
+    const float* pbase = nullptr;
+    float pstep = 0.0f;
+    if constexpr (PROP) {
+        int slot = pp->pos0 + (gact ? grp : 0);
+        if (slot >= pp->ring) slot -= pp->ring;
+        pnz = pp->noise + (size_t)slot * pp->nstride;
+        pbase = (pp->use_lg && pp->scal[slot * 4] < pp->l_prob) ? pp->w_gd : pp->w_cur;
+        pstep = pp->step_w;
+    }
+    auto win = [&](int e) -> float {
+        if constexpr (PROP) return fmaf(pstep, pnz[e], pbase[e]);
+        else return w_in[e];
+    };
 #pragma unroll
-    for (int i = 0; i < I; ++i) w1[i] = act ? C * w_in[i * H + hl] : 0.0f;
+    for (int i = 0; i < I; ++i) w1[i] = act ? C * win(i * H + hl) : 0.0f;
 #pragma unroll
-    for (int o = 0; o < O; ++o) w2[o] = act ? C * w_in[oW2 + hl * O + o] : 0.0f;
-    float b1 = act ? C * w_in[oB1 + hl] : -1.0e30f;          // inactive lanes: exponent +1e30 -> hid == 0 exactly
+    for (int o = 0; o < O; ++o) w2[o] = act ? C * win(oW2 + hl * O + o) : 0.0f;
+    float b1 = act ? C * win(oB1 + hl) : -1.0e30f;           // inactive lanes: exponent +1e30 -> hid == 0 exactly
 #pragma unroll
-    for (int o = 0; o < O; ++o) cl[o] = (lane == 0) ? -C * w_in[oB2 + o] : 0.0f;
+    for (int o = 0; o < O; ++o) cl[o] = (lane == 0) ? -C * win(oB2 + o) : 0.0f;
 
     // A lone wave issues one instruction (of any kind) per 4 cycles, so the epoch costs (instructions per row) x 4 cycles
     // and every hazard slot (VALU -> DPP needs two, transcendental -> use one) that holds no useful instruction is lost.
@@ -1324,7 +1351,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
 // by (1 - (1-a)^k) / a for acceptance rate a and k waves.  Each wave runs its whole step alone (wave-local LDS
 // scratch, no work-group barrier inside a step), so the result does not depend on the number of waves.
 // ------------------------------------------------------------------------------------------------
-enum { SL_ACCEPT = 0, SL_LIKPROP, SL_PRIORPROP, SL_ETAPRO, SL_RM_TR, SL_RM_TE, SL_AC_TR, SL_AC_TE, SL_LG, SL_ADAPT, SL_LOGALPHA, SL_COUNT = 16 };
+enum { SL_ACCEPT = 0, SL_LIKPROP, SL_PRIORPROP, SL_ETAPRO, SL_RM_TR, SL_RM_TE, SL_AC_TR, SL_AC_TE, SL_LG, SL_ADAPT, SL_LOGALPHA, SL_D2, SL_COUNT = 16 };
 constexpr int MAX_SLOTS = 64;          // speculative steps per round: work-groups per replica x waves per work-group
 constexpr unsigned SPIN_LIMIT = 1u << 22;   // x (s_sleep 2 + one L2 round trip) = a few seconds, then the launch gives up
 
@@ -1690,14 +1717,20 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
 // no cross-CU exchange on the critical path.  Per-slot arithmetic is the same code as in segment_spec_kernel, so the
 // committed chain is bit-identical to it (tested).
 // ------------------------------------------------------------------------------------------------
-constexpr int PK_WAVES = 4, PK_SWEEP_WAVES = 2;
+// Eight waves, two per SIMD (waves w and w + 4 share one): waves 0,1 run the SGD epochs and have their SIMDs to themselves
+// (waves 4,5 only take part in the phases between the barriers), waves 2,3,6,7 run the forward passes two to a SIMD -- forward
+// passes are full of transcendental and LDS latency, and two waves on a SIMD get 1.2 x the work done per cycle.  With four
+// waves the 16 forward passes took as long as the 16 epochs once the tape and the proposals had moved into them.
+constexpr int PK_WAVES = 8, PK_SWEEP_WAVES = 2, PK_FWD_WAVES = 4;
 // lane groups of 2^nred hidden units: 8 (n_hidden <= 8: 16 slots per round) or 16 (n_hidden <= 16: 8 slots per round)
 __host__ __device__ constexpr int pack_slots(int nred) { return PK_SWEEP_WAVES * (WAVE >> nred); }
 
-__host__ __device__ inline size_t pack_slot_floats(int PS) { return 3 * (size_t)PS + 8; }
+__host__ __device__ inline size_t pack_slot_floats(int PS) { return 2 * (size_t)PS; }      // proposal, its SGD epoch
+// the random tape lives in a ring of 2 x nslots steps: {noise[PS], lx, u, n_eta, -} per step
+__host__ __device__ inline size_t pack_ring_floats(int PS, int nslots) { return (size_t)2 * nslots * ((size_t)PS + 4); }
 __host__ __device__ inline size_t pack_lds_floats(int Nall, int IPY, int PS, int H, int FWS, int nslots) {
     return (size_t)(Nall + 2) * IPY + 3 * (size_t)PS + MAX_WAVES * 8 + (size_t)nslots * SL_COUNT +
-           (size_t)nslots * pack_slot_floats(PS) + (size_t)PK_WAVES * fw_floats(H, FWS);
+           (size_t)nslots * pack_slot_floats(PS) + pack_ring_floats(PS, nslots) + (size_t)PK_WAVES * fw_floats(H, FWS);
 }
 
 template <int TASK, int I, int O, int PK_NRED>
@@ -1717,13 +1750,18 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
     float* rec_w = q; q += PS;
     float* red = q; q += MAX_WAVES * 8;
     float* slots = q; q += PK_SLOTS * SL_COUNT;
-    const size_t SLF = pack_slot_floats(PS);                // per slot: proposal, its SGD epoch, noise, 8 scalars
+    const size_t SLF = pack_slot_floats(PS);                // per slot: proposal, its SGD epoch
     float* sl0 = q; q += PK_SLOTS * SLF;
+    // The random tape of a step depends on (seed, replica, step) only, so it is generated AHEAD of the rounds into a ring of
+    // RING = 2 PK_SLOTS steps (step j lives in entry j mod RING): at the start of a round the ring holds steps [i, i + RING)
+    // minus what the previous round committed, and the forward-pass waves refill it while the sweep waves are still sweeping.
+    // The tape is never on the critical path of a round.
+    constexpr int RING = 2 * PK_SLOTS;
+    float* ring_n = q; q += (size_t)RING * PS;
+    float* ring_s = q; q += (size_t)RING * 4;
     float* my_fw = q + (size_t)wave * fw_floats(H, p.FWS);
     auto s_prop = [&](int s_) { return sl0 + (size_t)s_ * SLF; };
     auto s_pgd = [&](int s_) { return sl0 + (size_t)s_ * SLF + PS; };
-    auto s_noise = [&](int s_) { return sl0 + (size_t)s_ * SLF + 2 * PS; };
-    auto s_scal = [&](int s_) { return sl0 + (size_t)s_ * SLF + 3 * PS; };
 
     {
         const float4* src = reinterpret_cast<const float4*>(p.data);
@@ -1774,11 +1812,43 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
     const size_t trow = (size_t)r * p.trace_cap;
     const int end = step_begin + n_steps;
     const bool sweeping = p.use_lg != 0;
-    // forward passes: waves 2,3 while waves 0,1 sweep; all four waves when there is nothing to sweep
-    const int ev_first = sweeping ? PK_SWEEP_WAVES : 0, ev_n = PK_WAVES - ev_first;
+    // forward passes: waves 2,3(,6,7) while waves 0,1 sweep; all waves when there is nothing to sweep.  The host launches eight
+    // waves while every replica has a CU to itself and four beyond that (with 232 VGPRs two waves fit on a SIMD: an eight-wave
+    // work-group has the CU to itself, of four-wave ones two are resident -- 1024 replicas on one GPU: 105 M vs 91 M samples/s)
+    const int nwaves = nthr >> 6;
+    const int ev_n = sweeping ? (nwaves == PK_WAVES ? PK_FWD_WAVES : 2) : nwaves;
+    const int ev_i = !sweeping ? wave : ((wave & 3) >= 2 ? (wave & 1) + ((wave >> 2) << 1) : -1);   // my index among them, or -1
     int i = step_begin;
     int tpos0 = (step_begin + 1) % p.trace_cap;            // ring position of the trace row of step i
-    const float inv_P = 1.0f / (float)P, inv_PW = 1.0f / (float)p.PW;
+    const float inv_PW = 1.0f / (float)p.PW;
+    // tape of steps [lo, hi) into the ring, by the waves [w0, w0 + nw): one Philox counter quad per lane, a wave covers
+    // 64 / (quads per step) steps in one pass
+    const int nq1 = ((P + 3) >> 2) + 1;                     // noise quads + the scalar quad
+    auto fill_ring = [&](int lo, int hi, int wi, int nw) {    // this wave is number wi of the nw waves that share the job
+        if (nq1 <= WAVE) {
+            const int per_pass = WAVE / nq1, ls = lane / nq1, q_ = lane - ls * nq1;
+            for (int sb = lo + wi * per_pass; sb < hi; sb += nw * per_pass) {
+                const int j = sb + ls;
+                if (ls < per_pass && j < hi) {
+                    const int slot = j % RING;
+                    const bool sc = (q_ == nq1 - 1);
+                    uint32_t x[4];
+                    philox4x32_10(sc ? 0u : (uint32_t)q_, (uint32_t)j, p.noise_shared ? 0u : (uint32_t)gid, sc ? STREAM_STEP : STREAM_WNOISE,
+                                  p.seed_lo, p.seed_hi, x);
+                    float n0, n1, n2, n3;
+                    box_muller(x[0], x[1], n0, n1);
+                    box_muller(x[2], x[3], n2, n3);
+                    if (sc) { float* sc_ = ring_s + slot * 4; sc_[0] = u23(x[0]); sc_[1] = u23(x[1]); sc_[2] = n2; }
+                    else *reinterpret_cast<float4*>(ring_n + (size_t)slot * PS + 4 * q_) = make_float4(n0, n1, n2, n3);
+                }
+            }
+        } else {
+            for (int j = lo + wi; j < hi; j += nw) tape_step<true>(p, gid, j, ring_n + (size_t)(j % RING) * PS, ring_s + (j % RING) * 4);
+        }
+    };
+    fill_ring(step_begin, step_begin + RING, wave, nwaves);
+    int ring_hi = step_begin + RING;                        // first step whose tape is not in the ring yet
+    __syncthreads();
     while (i < end) {
         if (i == p.switch_step) {
             if (wave == 0) {
@@ -1804,56 +1874,44 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
             gd_valid = 1;
             __syncthreads();
         }
-        // phase 1: random tape and proposal of every slot (slot s = step i + s).  One Philox counter quad per lane:
-        // a wave covers 64 / (quads per step) slots in one pass
-        {
-            const int nq1 = ((P + 3) >> 2) + 1;                 // noise quads + the scalar quad
-            if (nq1 <= WAVE) {
-                const int per_pass = WAVE / nq1, ls = lane / nq1, q_ = lane - ls * nq1;
-                for (int sb = wave * per_pass; sb < k; sb += PK_WAVES * per_pass) {
-                    const int s_ = sb + ls;
-                    if (ls < per_pass && s_ < k) {
-                        const bool sc = (q_ == nq1 - 1);
-                        uint32_t x[4];
-                        philox4x32_10(sc ? 0u : (uint32_t)q_, (uint32_t)(i + s_), p.noise_shared ? 0u : (uint32_t)gid, sc ? STREAM_STEP : STREAM_WNOISE,
-                                      p.seed_lo, p.seed_hi, x);
-                        float n0, n1, n2, n3;
-                        box_muller(x[0], x[1], n0, n1);
-                        box_muller(x[2], x[3], n2, n3);
-                        if (sc) { float* sc_ = s_scal(s_); sc_[0] = u23(x[0]); sc_[1] = u23(x[1]); sc_[2] = n2; }
-                        else *reinterpret_cast<float4*>(s_noise(s_) + 4 * q_) = make_float4(n0, n1, n2, n3);
-                    }
-                }
-            } else {
-                for (int s_ = wave; s_ < k; s_ += PK_WAVES) tape_step<true>(p, gid, i + s_, s_noise(s_), s_scal(s_));
-            }
-        }
-        __syncthreads();
-        STAMP(1);                                           // tape
-        for (int item = tid; item < k * P; item += nthr) {  // all (slot, element) pairs at once
-            const int s_ = (int)(((float)item + 0.5f) * inv_P), e = item - s_ * P;
-            const bool lg = sweeping && (s_scal(s_)[0] < p.l_prob);
-            s_prop(s_)[e] = fmaf(p.step_w, s_noise(s_)[e], (lg ? w_gd : w_cur)[e]);
-            if (e == 0) slots[s_ * SL_COUNT + SL_LG] = lg ? 1.0f : 0.0f;
-        }
-        __syncthreads();
-        STAMP(2);                                           // proposal
-        // phase 2: SGD epochs of all slots in lane groups || forward passes
+        const int rpos0 = i % RING;                         // ring entry of slot 0 (= step i)
+        auto s_noise = [&](int s_) { int e_ = rpos0 + s_; if (e_ >= RING) e_ -= RING; return ring_n + (size_t)e_ * PS; };
+        auto s_scal = [&](int s_) { int e_ = rpos0 + s_; if (e_ >= RING) e_ -= RING; return ring_s + e_ * 4; };
+        STAMP(1);
+        STAMP(2);
+        // SGD epochs of all slots in lane groups (waves 0,1) || forward passes (the other waves).  Nobody waits for a proposal
+        // phase: a proposal is base + step_w * noise with base = w_gd or w_cur by the step's Langevin coin, and each consumer
+        // forms the elements it needs -- the sweep lanes their own weights, the forward wave of a slot the whole vector, which
+        // it also writes out (the commit and an accepted step need it).
         if (sweeping && wave < PK_SWEEP_WAVES) {
             const int ng = min(PK_NG, k - wave * PK_NG);
-            if (ng > 0)
-                sgd_sweep<TASK, I, O, PK_NRED>(s_prop(wave * PK_NG), s_pgd(wave * PK_NG), xy, p.data, p.Ntr, H, p.lr, ng, (int)SLF);
+            if (ng > 0) {
+                SweepProposals pp;
+                pp.noise = ring_n; pp.scal = ring_s; pp.w_cur = w_cur; pp.w_gd = w_gd;
+                pp.pos0 = rpos0 + wave * PK_NG; if (pp.pos0 >= RING) pp.pos0 -= RING;
+                pp.ring = RING; pp.nstride = PS; pp.step_w = p.step_w; pp.l_prob = p.l_prob; pp.use_lg = 1;
+                sgd_sweep<TASK, I, O, PK_NRED, true>(nullptr, s_pgd(wave * PK_NG), xy, p.data, p.Ntr, H, p.lr, ng, (int)SLF, &pp);
+            }
         }
         STAMP(3);                                           // sweep
 #ifdef PTNN_STAMPS
         const unsigned long long ev_t0 = __builtin_amdgcn_s_memtime();
 #endif
-        if (wave >= ev_first) {
-            for (int s_ = wave - ev_first; s_ < k; s_ += ev_n) {
+        if (ev_i >= 0) {
+            for (int s_ = ev_i; s_ < k; s_ += ev_n) {
                 const int j = i + s_;
                 const float adapttemp = (p.switch_step >= 0 && j >= p.switch_step) ? 1.0f : T;
+                const float* sc_ = s_scal(s_);
+                const bool lg = sweeping && (sc_[0] < p.l_prob);
                 float eta_pro = eta;
-                if (TASK == TASK_REG) eta_pro = fmaf(p.step_eta, s_scal(s_)[2], eta);
+                if (TASK == TASK_REG) eta_pro = fmaf(p.step_eta, sc_[2], eta);
+                {
+                    const float* nz = s_noise(s_);
+                    const float* base = lg ? w_gd : w_cur;
+                    float* pr = s_prop(s_);
+                    for (int e = lane; e < P; e += WAVE) pr[e] = fmaf(p.step_w, nz[e], base[e]);
+                }
+                gsync<true>();
                 build_fw<I, O, true>(s_prop(s_), my_fw, H, p.FWS);
                 gsync<true>();
                 const EvalSums es = eval_rows<TASK, I, O, true>(my_fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, nullptr);
@@ -1861,46 +1919,50 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
                 finish_eval<TASK>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
                 const float ssq = block_sumsq<true>(s_prop(s_), P, nullptr);
                 const float prior_prop = prior_value<TASK>(p, ssq, eta_pro);
+                // |noise|^2 of the Langevin ratio does not wait for the epoch: taken here, off the critical path (same
+                // association order as the one-wave-per-slot schedule's block_sumsq)
+                const float d2 = lg ? block_sumsq<true>(s_noise(s_), P, nullptr) : 0.0f;
                 if (lane == 0) {
                     float* sl = slots + s_ * SL_COUNT;
                     sl[SL_LIKPROP] = ll / adapttemp; sl[SL_PRIORPROP] = prior_prop; sl[SL_ETAPRO] = eta_pro;
                     sl[SL_RM_TR] = rm_tr; sl[SL_RM_TE] = rm_te; sl[SL_AC_TR] = ac_tr; sl[SL_AC_TE] = ac_te;
-                    sl[SL_ADAPT] = adapttemp;
+                    sl[SL_ADAPT] = adapttemp; sl[SL_LG] = lg ? 1.0f : 0.0f; sl[SL_D2] = d2;
                 }
                 gsync<true>();
             }
+            // tape of the steps the next round may reach and the ring does not hold yet: at most as many as the previous round
+            // committed.  They overwrite entries of steps below i.
+            fill_ring(ring_hi, i + RING, ev_i, ev_n);
         }
+        ring_hi = i + RING;
 #ifdef PTNN_STAMPS
-        if (wave == ev_first) stamp_eval += __builtin_amdgcn_s_memtime() - ev_t0;
+        if (ev_i == 0) stamp_eval += __builtin_amdgcn_s_memtime() - ev_t0;
 #endif
         __syncthreads();
         STAMP(4);                                           // waiting for the forward passes
         // phase 3: Metropolis-Hastings ratio of every slot
-        // one 16-lane row per slot, all 16 slots at once.  The two sums of squares are taken in the association order of
-        // block_sumsq<true> (element j in lane j of a wave: rows of 16, then (row0 + row1) + (row2 + row3)), so the
+        // one 16-lane row per slot, all 16 slots at once (waves 0-3).  |w - epoch(proposal)|^2 is taken in the association order
+        // of block_sumsq_diff<true> (element j in lane j of a wave: rows of 16, then (row0 + row1) + (row2 + row3)), so the
         // decision is bit-identical to the one-wave-per-slot schedule.
         {
             const int s_ = wave * (WAVE / 16) + (lane >> 4), l16 = lane & 15;
             const bool on = s_ < k;
             float* sl = slots + (on ? s_ : 0) * SL_COUNT;
             float diff_prop = 0.0f;
-            if (sweeping) {
+            if (sweeping && wave < 4) {
                 const float* pg = s_pgd(on ? s_ : 0);
-                const float* nz = s_noise(on ? s_ : 0);
-                float r1[4], r2[4];
+                float r1[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {                 // row c of the wave layout: elements 16 c + l16 (+ 64 t)
-                    float a1 = 0.0f, a2 = 0.0f;
+                    float a1 = 0.0f;
                     for (int e = 16 * c + l16; e < P; e += WAVE) {
-                        const float d = w_cur[e] - pg[e], z = nz[e];
+                        const float d = w_cur[e] - pg[e];
                         a1 = fmaf(d, d, a1);
-                        a2 = fmaf(z, z, a2);
                     }
                     r1[c] = group_allsum<4>(a1);
-                    r2[c] = group_allsum<4>(a2);
                 }
-                const float d1 = (r1[0] + r1[1]) + (r1[2] + r1[3]), d2 = (r2[0] + r2[1]) + (r2[2] + r2[3]);
-                if (sl[SL_LG] != 0.0f) diff_prop = (-0.5f * d1 / (p.step_w * p.step_w) + 0.5f * d2) / sl[SL_ADAPT];
+                const float d1 = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+                if (sl[SL_LG] != 0.0f) diff_prop = (-0.5f * d1 / (p.step_w * p.step_w) + 0.5f * sl[SL_D2]) / sl[SL_ADAPT];
             }
             const float logalpha = (sl[SL_LIKPROP] - lik) + (sl[SL_PRIORPROP] - prior_cur) + diff_prop;
             const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
@@ -1960,7 +2022,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
         atomicAdd(p.stamps + 9, stamp_rounds);
         atomicAdd(p.stamps + 10, __builtin_amdgcn_s_memtime() - stamp_t0);
     }
-    if (blockIdx.x == 0 && wave == ev_first && lane == 0 && p.stamps) atomicAdd(p.stamps + 11, stamp_eval);
+    if (blockIdx.x == 0 && ev_i == 0 && lane == 0 && p.stamps) atomicAdd(p.stamps + 11, stamp_eval);
     if (tid == 0 && p.stamps && r < 64) {
         atomicAdd(p.stamps + 16 + 2 * r, __builtin_amdgcn_s_memtime() - stamp_t0);
         atomicAdd(p.stamps + 17 + 2 * r, stamp_rounds);
