@@ -1729,7 +1729,7 @@ __host__ __device__ inline size_t pack_slot_floats(int PS) { return 2 * (size_t)
 // the random tape lives in a ring of 2 x nslots steps: {noise[PS], lx, u, n_eta, -} per step
 __host__ __device__ inline size_t pack_ring_floats(int PS, int nslots) { return (size_t)2 * nslots * ((size_t)PS + 4); }
 __host__ __device__ inline size_t pack_lds_floats(int Nall, int IPY, int PS, int H, int FWS, int nslots) {
-    return (size_t)(Nall + 2) * IPY + 3 * (size_t)PS + MAX_WAVES * 8 + (size_t)nslots * SL_COUNT +
+    return (size_t)(Nall + 2) * IPY + 4 * (size_t)PS + MAX_WAVES * 8 + (size_t)nslots * SL_COUNT +
            (size_t)nslots * pack_slot_floats(PS) + pack_ring_floats(PS, nslots) + (size_t)PK_WAVES * fw_floats(H, FWS);
 }
 
@@ -1747,7 +1747,8 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
     float* xy = q; q += (Nall + 2) * p.IPY;
     float* w_cur = q; q += PS;
     float* w_gd = q; q += PS;
-    float* rec_w = q; q += PS;
+    float* rec_w = q; q += PS;                              // last recorded pos_w row ...
+    float* rec_alt = q; q += PS;                            // ... and where the next one goes: the two swap on every accepted step
     float* red = q; q += MAX_WAVES * 8;
     float* slots = q; q += PK_SLOTS * SL_COUNT;
     const size_t SLF = pack_slot_floats(PS);                // per slot: proposal, its SGD epoch
@@ -1959,7 +1960,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
                         const float d = w_cur[e] - pg[e];
                         a1 = fmaf(d, d, a1);
                     }
-                    r1[c] = group_allsum<4>(a1);
+                    r1[c] = (16 * c < P) ? group_allsum<4>(a1) : 0.0f;     // a row beyond P sums zeros: exactly 0 either way
                 }
                 const float d1 = (r1[0] + r1[1]) + (r1[2] + r1[3]);
                 if (sl[SL_LG] != 0.0f) diff_prop = (-0.5f * d1 / (p.step_w * p.step_w) + 0.5f * sl[SL_D2]) / sl[SL_ADAPT];
@@ -1995,8 +1996,8 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
         }
         lg_count += __popcll(bal_lg & ((1ull << ncommit) - 1ull));
         if (TASK == TASK_REG) tau_eta_last = slots[(ncommit - 1) * SL_COUNT + SL_ETAPRO];
-        __syncthreads();
         if (m < k) {
+            // no barrier between the trace rows above and this update: they read rec_w, the new recorded row goes to rec_alt
             const float* sm = slots + m * SL_COUNT;
             nacc += 1;
             lik = sm[SL_LIKPROP]; prior_cur = sm[SL_PRIORPROP]; eta = sm[SL_ETAPRO];
@@ -2006,9 +2007,10 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
             const float* wacc = s_prop(m);
             for (int e = tid; e < P; e += nthr) {
                 const float v = wacc[e];
-                w_cur[e] = v; rec_w[e] = v;
+                w_cur[e] = v; rec_alt[e] = v;
                 if (sweeping) w_gd[e] = wacc[PS + e];
             }
+            float* t_ = rec_w; rec_w = rec_alt; rec_alt = t_;
         }
         __syncthreads();
         i += ncommit;
