@@ -92,6 +92,10 @@ __device__ __forceinline__ float sigmoidf_fast(float z) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * z));
 }
 __device__ __forceinline__ float expf_fast(float x) { return __builtin_amdgcn_exp2f(LOG2E * x); }
+// a value every lane of the wave holds alike, moved to a scalar register (the chain state of a replica -- likelihood, prior,
+// counters -- is such a value; loaded from memory or LDS it would occupy a VGPR each for the whole launch)
+__device__ __forceinline__ float uni_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float logf_fast(float x) { return LN2 * __builtin_amdgcn_logf(x); }
 
 // ------------------------------------------------------------------------------------------------
@@ -1432,8 +1436,8 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
     }
     __syncthreads();
 
-    const float T = p.temps[r];
-    float eta = (TASK == TASK_REG) ? w_cur[P] : 0.0f;
+    const float T = uni_f(p.temps[r]);
+    float eta = (TASK == TASK_REG) ? uni_f(w_cur[P]) : 0.0f;
     float* sf = p.st_f + (size_t)r * SF_COUNT;
     int* si = p.st_i + (size_t)r * SI_COUNT;
     float lik, prior_cur, tau_eta_last, rec_rmse_tr, rec_rmse_te, rec_acc_tr, rec_acc_te;
@@ -1445,16 +1449,16 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
             if (lane == 0) { red[0] = eta; red[1] = lik; red[2] = prior_cur; }
         }
         __syncthreads();
-        eta = red[0]; lik = red[1]; prior_cur = red[2];
+        eta = uni_f(red[0]); lik = uni_f(red[1]); prior_cur = uni_f(red[2]);
         tau_eta_last = eta;
         rec_rmse_tr = rec_rmse_te = rec_acc_tr = rec_acc_te = 0.f;
         nacc = 0; gd_valid = 0; lg_count = 0;
         __syncthreads();
     } else {
-        lik = sf[SF_LIK]; prior_cur = sf[SF_PRIOR]; tau_eta_last = sf[SF_TAU_LAST];
-        rec_rmse_tr = sf[SF_REC_RMSE_TR]; rec_rmse_te = sf[SF_REC_RMSE_TE];
-        rec_acc_tr = sf[SF_REC_ACC_TR]; rec_acc_te = sf[SF_REC_ACC_TE];
-        nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT]; lg_acc = si[SI_LG_ACC];
+        lik = uni_f(sf[SF_LIK]); prior_cur = uni_f(sf[SF_PRIOR]); tau_eta_last = uni_f(sf[SF_TAU_LAST]);
+        rec_rmse_tr = uni_f(sf[SF_REC_RMSE_TR]); rec_rmse_te = uni_f(sf[SF_REC_RMSE_TE]);
+        rec_acc_tr = uni_f(sf[SF_REC_ACC_TR]); rec_acc_te = uni_f(sf[SF_REC_ACC_TE]);
+        nacc = uni_i(si[SI_NACC]); gd_valid = uni_i(p.gd_valid[r]); lg_count = uni_i(si[SI_LG_COUNT]); lg_acc = uni_i(si[SI_LG_ACC]);
     }
 
 #ifdef PTNN_STAMPS
@@ -1490,7 +1494,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
                 if (lane == 0) red[0] = l2;
             }
             __syncthreads();
-            lik = red[0];
+            lik = uni_f(red[0]);
             __syncthreads();
         }
         int k = min(K, end - i);
@@ -1624,7 +1628,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
             }
         }
         lg_count += __popcll(bal_lg & ((ncommit >= 64) ? ~0ull : ((1ull << ncommit) - 1ull)));
-        if (TASK == TASK_REG) tau_eta_last = slots[(ncommit - 1) * SL_COUNT + SL_ETAPRO];
+        if (TASK == TASK_REG) tau_eta_last = uni_f(slots[(ncommit - 1) * SL_COUNT + SL_ETAPRO]);
         __syncthreads();                                    // every reader of rec_w is done
         if (m < k) {
             const int owner = m / NW;
@@ -1639,8 +1643,9 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
             }
             const float* sm = slots + m * SL_COUNT;
             nacc += 1;
-            lik = sm[SL_LIKPROP]; prior_cur = sm[SL_PRIORPROP]; eta = sm[SL_ETAPRO];
-            rec_rmse_tr = sm[SL_RM_TR]; rec_rmse_te = sm[SL_RM_TE]; rec_acc_tr = sm[SL_AC_TR]; rec_acc_te = sm[SL_AC_TE];
+            lik = uni_f(sm[SL_LIKPROP]); prior_cur = uni_f(sm[SL_PRIORPROP]); eta = uni_f(sm[SL_ETAPRO]);
+            rec_rmse_tr = uni_f(sm[SL_RM_TR]); rec_rmse_te = uni_f(sm[SL_RM_TE]);
+            rec_acc_tr = uni_f(sm[SL_AC_TR]); rec_acc_te = uni_f(sm[SL_AC_TE]);
             gd_valid = p.use_lg ? 1 : 0;
             lg_acc += (sm[SL_LG] != 0.0f) ? 1 : 0;
             if (owner == grp) {
@@ -1777,8 +1782,8 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
     }
     __syncthreads();
 
-    const float T = p.temps[r];
-    float eta = (TASK == TASK_REG) ? w_cur[P] : 0.0f;
+    const float T = uni_f(p.temps[r]);
+    float eta = (TASK == TASK_REG) ? uni_f(w_cur[P]) : 0.0f;
     float* sf = p.st_f + (size_t)r * SF_COUNT;
     int* si = p.st_i + (size_t)r * SI_COUNT;
     float lik, prior_cur, tau_eta_last, rec_rmse_tr, rec_rmse_te, rec_acc_tr, rec_acc_te;
@@ -1790,16 +1795,16 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
             if (lane == 0) { red[0] = eta; red[1] = lik; red[2] = prior_cur; }
         }
         __syncthreads();
-        eta = red[0]; lik = red[1]; prior_cur = red[2];
+        eta = uni_f(red[0]); lik = uni_f(red[1]); prior_cur = uni_f(red[2]);
         tau_eta_last = eta;
         rec_rmse_tr = rec_rmse_te = rec_acc_tr = rec_acc_te = 0.f;
         nacc = 0; gd_valid = 0; lg_count = 0;
         __syncthreads();
     } else {
-        lik = sf[SF_LIK]; prior_cur = sf[SF_PRIOR]; tau_eta_last = sf[SF_TAU_LAST];
-        rec_rmse_tr = sf[SF_REC_RMSE_TR]; rec_rmse_te = sf[SF_REC_RMSE_TE];
-        rec_acc_tr = sf[SF_REC_ACC_TR]; rec_acc_te = sf[SF_REC_ACC_TE];
-        nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT]; lg_acc = si[SI_LG_ACC];
+        lik = uni_f(sf[SF_LIK]); prior_cur = uni_f(sf[SF_PRIOR]); tau_eta_last = uni_f(sf[SF_TAU_LAST]);
+        rec_rmse_tr = uni_f(sf[SF_REC_RMSE_TR]); rec_rmse_te = uni_f(sf[SF_REC_RMSE_TE]);
+        rec_acc_tr = uni_f(sf[SF_REC_ACC_TR]); rec_acc_te = uni_f(sf[SF_REC_ACC_TE]);
+        nacc = uni_i(si[SI_NACC]); gd_valid = uni_i(p.gd_valid[r]); lg_count = uni_i(si[SI_LG_COUNT]); lg_acc = uni_i(si[SI_LG_ACC]);
     }
 
 #ifdef PTNN_STAMPS
@@ -1861,7 +1866,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
                 if (lane == 0) red[0] = l2;
             }
             __syncthreads();
-            lik = red[0];
+            lik = uni_f(red[0]);
             __syncthreads();
         }
         int k = min(PK_SLOTS, end - i);
@@ -1995,13 +2000,14 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
                             acc_me ? sl[SL_AC_TR] : rec_acc_tr, acc_me ? sl[SL_AC_TE] : rec_acc_te, nacc, sl[SL_LOGALPHA]);
         }
         lg_count += __popcll(bal_lg & ((1ull << ncommit) - 1ull));
-        if (TASK == TASK_REG) tau_eta_last = slots[(ncommit - 1) * SL_COUNT + SL_ETAPRO];
+        if (TASK == TASK_REG) tau_eta_last = uni_f(slots[(ncommit - 1) * SL_COUNT + SL_ETAPRO]);
         if (m < k) {
             // no barrier between the trace rows above and this update: they read rec_w, the new recorded row goes to rec_alt
             const float* sm = slots + m * SL_COUNT;
             nacc += 1;
-            lik = sm[SL_LIKPROP]; prior_cur = sm[SL_PRIORPROP]; eta = sm[SL_ETAPRO];
-            rec_rmse_tr = sm[SL_RM_TR]; rec_rmse_te = sm[SL_RM_TE]; rec_acc_tr = sm[SL_AC_TR]; rec_acc_te = sm[SL_AC_TE];
+            lik = uni_f(sm[SL_LIKPROP]); prior_cur = uni_f(sm[SL_PRIORPROP]); eta = uni_f(sm[SL_ETAPRO]);
+            rec_rmse_tr = uni_f(sm[SL_RM_TR]); rec_rmse_te = uni_f(sm[SL_RM_TE]);
+            rec_acc_tr = uni_f(sm[SL_AC_TR]); rec_acc_te = uni_f(sm[SL_AC_TE]);
             lg_acc += (sm[SL_LG] != 0.0f) ? 1 : 0;
             gd_valid = sweeping ? 1 : 0;
             const float* wacc = s_prop(m);
