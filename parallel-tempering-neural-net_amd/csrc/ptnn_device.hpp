@@ -2128,60 +2128,79 @@ __device__ __attribute__((noinline)) void sgd_sweep_wide(const float* __restrict
     const int ntr = __builtin_amdgcn_readfirstlane(Ntr);
     typedef __attribute__((address_space(3))) float lfloat;
     lfloat* lpart = (lfloat*)part;                                    // the partial sums live in LDS: ds_ instead of flat_ accesses
-    auto xpair = [&](int n, int i) {                                  // inputs (2i, 2i+1) of row n; the pad column of an odd I is 0-weighted
+    // a whole row of input pairs into SGPRs (the pad column of an odd I meets a zero weight)
+    auto load_row = [&](int n, f32x2 (&x)[IP]) {
         const cfloat* row = cdata + (size_t)n * ipy;
-        f32x2 v;
-        v[0] = row[2 * i];
-        v[1] = row[2 * i + 1];
-        return v;
+#pragma unroll
+        for (int i = 0; i < IP; ++i) { x[i][0] = row[2 * i]; x[i][1] = row[2 * i + 1]; }
     };
-    auto zpart = [&](int n) {                                         // x[n] . W1 - B1 with the weights as they are now
+    auto zpart = [&](const f32x2 (&x)[IP]) {                          // x . W1 - B1 with the weights as they are now
         f32x2 a0 = {nb1, 0.0f}, a1 = {0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < IP; i += 2) {
-            a0 = __builtin_elementwise_fma(xpair(n, i), w1[i], a0);
-            if (i + 1 < IP) a1 = __builtin_elementwise_fma(xpair(n, i + 1), w1[i + 1], a1);
+            a0 = __builtin_elementwise_fma(x[i], w1[i], a0);
+            if (i + 1 < IP) a1 = __builtin_elementwise_fma(x[i + 1], w1[i + 1], a1);
         }
         const f32x2 s_ = a0 + a1;
         return s_[0] + s_[1];
     };
+    // Two rows live in scalar registers: xu = the row whose update is pending (row n-1 during iteration n), xz = the row whose
+    // pre-activation is started next (row n+1).  Both are consumed BEFORE the barrier of an iteration and reloaded right AFTER
+    // it (into the same registers: the old rows are dead by then), a whole iteration ahead of the next barrier -- the only place
+    // that has to wait for them, because the LDS traffic of the reduction shares the scalar loads' counter (lgkmcnt).
+    f32x2 xu[IP], xz[IP];
+    load_row(0, xz);
     float lhd_p = 0.0f;                                               // lhd of the previous row: its update is still pending
-    float zp = zpart(0);
+    float zp = zpart(xz);
+    load_row(0, xu);
+    load_row(1, xz);
     for (int n = 0; n < ntr; ++n) {
         const cfloat* row = cdata + (size_t)n * ipy;
-        const float z = fmaf(lhd_p, row[I + 1], zp);                  // + lhd[n-1] (1 + x[n] . x[n-1])   (row 0: lhd_p == 0)
+        const float yn = row[I], dn = row[I + 1];
+        const float z = fmaf(lhd_p, dn, zp);                          // + lhd[n-1] (1 + x[n] . x[n-1])   (row 0: lhd_p == 0)
         const float e = __builtin_amdgcn_exp2f(z);
-        // off the chain: apply the update of row n-1, then start row n+1 from the updated weights (two zero rows follow the image)
-        if (n > 0) {
+        // off the chain: apply the update of row n-1 (xu; a no-op for n = 0, where lhd_p = 0), then start row n+1 (xz) from the
+        // updated weights; two zero rows follow the image, so the look-ahead never leaves it
+        {
             const f32x2 l2 = {lhd_p, lhd_p};
 #pragma unroll
-            for (int i = 0; i < IP; ++i) w1[i] = __builtin_elementwise_fma(l2, xpair(n - 1, i), w1[i]);
+            for (int i = 0; i < IP; ++i) w1[i] = __builtin_elementwise_fma(l2, xu[i], w1[i]);
             if constexpr (I & 1) w1[IP - 1][1] = 0.0f;                // the pad weight of an odd input count stays zero
             nb1 += lhd_p;
         }
-        zp = zpart(n + 1);
+        zp = zpart(xz);
         const float hid = __builtin_amdgcn_rcpf(1.0f + e);
         const float ldh = lr * fmaf(-hid, hid, hid);
-        lfloat* mypart = lpart + par * MAX_WAVES * OP;          // [o][wave]: the partials of one output are contiguous
+        lfloat* mypart = lpart + par * MAX_WAVES * OP;                // [o][wave]: the partials of one output are contiguous
 #pragma unroll
         for (int o = 0; o < O; ++o) {
             const float s_ = wave_allsum(hid * w2[o]);
             if (lane == 0) mypart[o * MAX_WAVES + wave] = s_;
         }
         __syncthreads();
+        // the partials first, THEN the scalar loads: a wait for the LDS reads is a wait for everything on lgkmcnt
+        float4 pa[O], pb[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            const volatile lfloat* pq = mypart + o * MAX_WAVES;       // volatile: the reads stay above the wait below
+            pa[o] = make_float4(pq[0], pq[1], pq[2], pq[3]);
+            pb[o] = make_float4(pq[4], pq[5], pq[6], pq[7]);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0): the partials are here
+        __builtin_amdgcn_sched_barrier(0);
+        load_row(n, xu);                                              // pending update of the next iteration
+        load_row(n + 2, xz);                                          // pre-activation started in the next iteration
+        __builtin_amdgcn_sched_barrier(0);
         float g = 0.0f;
         float lod[O];
 #pragma unroll
         for (int o = 0; o < O; ++o) {
-            // all MAX_WAVES partials with two 16-byte reads (entries of absent waves are zero), summed in a fixed order
-            const lfloat* pp = mypart + o * MAX_WAVES;
-            const float4 pa = make_float4(pp[0], pp[1], pp[2], pp[3]);
-            const float4 pb = make_float4(pp[4], pp[5], pp[6], pp[7]);
-            const float zo = cl[o] + (((pa.x + pa.y) + (pa.z + pa.w)) + ((pb.x + pb.y) + (pb.z + pb.w)));
+            // all MAX_WAVES partials (entries of absent waves are zero), summed in a fixed order
+            const float zo = cl[o] + (((pa[o].x + pa[o].y) + (pa[o].z + pa[o].w)) + ((pb[o].x + pb[o].y) + (pb[o].z + pb[o].w)));
             const float out = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zo));
             float tt;
-            if (TASK == TASK_CLS) tt = ((int)row[I] == o) ? 1.0f : 0.0f;
-            else tt = row[I];
+            if (TASK == TASK_CLS) tt = ((int)yn == o) ? 1.0f : 0.0f;
+            else tt = yn;
             const float od = (tt - out) * fmaf(-out, out, out);
             g = fmaf(od, w2[o], g);                                   // pre-update W2 (Q4)
             lod[o] = clr * od;
@@ -2194,10 +2213,10 @@ __device__ __attribute__((noinline)) void sgd_sweep_wide(const float* __restrict
         }
         par ^= 1;
     }
-    if (ntr > 0) {                                                    // the update of the last row is still pending
+    if (ntr > 0) {                                                    // the update of the last row is still pending (xu = row ntr-1)
         const f32x2 l2 = {lhd_p, lhd_p};
 #pragma unroll
-        for (int i = 0; i < IP; ++i) w1[i] = __builtin_elementwise_fma(l2, xpair(ntr - 1, i), w1[i]);
+        for (int i = 0; i < IP; ++i) w1[i] = __builtin_elementwise_fma(l2, xu[i], w1[i]);
         nb1 += lhd_p;
     }
     if (act) {
