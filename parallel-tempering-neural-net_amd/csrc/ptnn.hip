@@ -549,12 +549,13 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
     if (sched == PTNN_SCHED_COOPERATIVE) {
         h->speculative = false;
         h->nthreads = (nw ? nw : coop_nw) * 64;
-        h->seg_lds = coop_lds;
+        const size_t seg_lds = lds_floats(Nall, IPY, h->PS, H, h->FWS, h->cfg.use_langevin != 0) * sizeof(float);
+        h->seg_lds = seg_lds;
         // a hidden layer that fills most of a 32-unit tile and at least three k-steps: forward pass on the matrix cores
         // (the VALU pass re-reads the weights from LDS with broadcast reads and is bound by the LDS pipe at this size)
         const size_t extra = mfma_coop_lds_floats(I, h->cfg.n_out, H, h->Npad) * sizeof(float);
-        h->fw_mfma = (H >= 24 && I >= 6 && coop_lds + extra <= LDS_MAX);
-        if (h->fw_mfma) h->seg_lds = coop_lds + extra;
+        h->fw_mfma = (H >= 24 && I >= 6 && seg_lds + extra <= LDS_MAX);
+        if (h->fw_mfma) h->seg_lds = seg_lds + extra;
     }
     h->Ntr = ntr; h->Nte = nte;
     if (h->d_data) { HIP_TRY(hipFree(h->d_data)); h->d_data = nullptr; }

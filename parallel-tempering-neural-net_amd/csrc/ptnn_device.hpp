@@ -646,6 +646,32 @@ __device__ __forceinline__ void build_fw(const float* __restrict__ w, float* __r
     }
 }
 
+// Random-walk proposal and its forward image in one pass: every weight appears in the image exactly once, so the thread that
+// places element e also forms w_prop[idx] = w[idx] + step * noise[idx] (the value build_fw would read back).
+template <int I, int O>
+__device__ __forceinline__ void propose_build_fw(const float* __restrict__ w, const float* __restrict__ noise, float step,
+                                                 float* __restrict__ w_prop, float* __restrict__ fw, int H, int FWS) {
+    const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
+    constexpr int K = I + 1 + O;
+    const bool pairs = FwLayout<I>::pairs(H);
+    const int HR = pairs ? 2 * fw_pairs(H) : H;
+    for (int e = threadIdx.x; e < HR * K; e += blockDim.x) {
+        const int h = e / K, c = e - h * K;
+        float v = 0.0f;
+        if (h < H) {
+            const int idx = (c < I) ? c * H + h : (c == I) ? oB1 + h : oW2 + h * O + (c - I - 1);
+            v = fmaf(step, noise[idx], w[idx]);
+            w_prop[idx] = v;
+        }
+        fw[pairs ? (h >> 1) * 2 * FWS + 2 * c + (h & 1) : h * FWS + c] = v;
+    }
+    if (threadIdx.x < O) {
+        const float v = fmaf(step, noise[oB2 + threadIdx.x], w[oB2 + threadIdx.x]);
+        w_prop[oB2 + threadIdx.x] = v;
+        fw[HR * FWS + threadIdx.x] = v;
+    }
+}
+
 // Ordering key of np.argmax over the reference's FLOAT64 sigmoid outputs, computed from the fp32 pre-activation z.
 // sigmoid is monotone, so below z = 30 the key is z itself (fp32 outputs saturating to 1.0f must not tie where float64
 // outputs still differ).  From z = 30 on, float64 itself quantises: 1 + e^-z is rounded to a multiple of 2^-52, outputs
@@ -670,11 +696,48 @@ struct EvalSums {
     float a_te, b_te, c_te;   // same for test rows
 };
 
+// Work-group sums of the per-lane row scores, returned in every thread: wave DPP reduction, then a fixed-order sum of the
+// per-wave partials through LDS.  LEAN (the cooperative kernel's step loop): the caller guarantees that nobody still reads
+// red[] (a barrier separates the previous readers from this call), and `extra` -- one more per-thread partial, the sum of
+// squares of the proposal for the prior -- rides along in the same rows, so a step has ONE reduction instead of three.
+template <int TASK, bool WL, bool LEAN>
+__device__ __forceinline__ EvalSums reduce_eval(float a_tr, float b_tr, float c_tr, float a_te, float b_te, float c_te,
+                                                float* __restrict__ red, float& extra) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    a_tr = wave_allsum(a_tr);
+    a_te = wave_allsum(a_te);
+    if (TASK == TASK_CLS) {
+        b_tr = wave_allsum(b_tr); c_tr = wave_allsum(c_tr);
+        b_te = wave_allsum(b_te); c_te = wave_allsum(c_te);
+    }
+    if (LEAN) extra = wave_allsum(extra);
+    EvalSums s;
+    if (WL || nw == 1) {
+        s.a_tr = a_tr; s.b_tr = b_tr; s.c_tr = c_tr; s.a_te = a_te; s.b_te = b_te; s.c_te = c_te;
+        return s;
+    }
+    if (!LEAN) __syncthreads();                            // red[] may still be read from the previous use
+    if (lane == 0) {
+        float* r = red + wave * 8;
+        *reinterpret_cast<float4*>(r) = make_float4(a_tr, b_tr, c_tr, a_te);
+        *reinterpret_cast<float4*>(r + 4) = make_float4(b_te, c_te, LEAN ? extra : 0.0f, 0.0f);
+    }
+    __syncthreads();
+    s.a_tr = s.b_tr = s.c_tr = s.a_te = s.b_te = s.c_te = 0.f;
+    float ex = 0.f;
+    for (int k = 0; k < nw; ++k) {
+        const float4 u = *reinterpret_cast<const float4*>(red + k * 8), v = *reinterpret_cast<const float4*>(red + k * 8 + 4);
+        s.a_tr += u.x; s.b_tr += u.y; s.c_tr += u.z; s.a_te += u.w; s.b_te += v.x; s.c_te += v.y; ex += v.z;
+    }
+    if (LEAN) extra = ex;
+    return s;
+}
+
 // R2/R3/R6: one lane per data row; the block's threads stride over train ++ test.  Returns block-wide sums in every
-// thread (wave DPP reduction, then a fixed-order sum of the per-wave partials through LDS).
-template <int TASK, int I, int O, bool WL = false>
+// thread (reduce_eval).
+template <int TASK, int I, int O, bool WL = false, bool LEAN = false>
 __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, const float* __restrict__ xy, int IPY,
-                                              int FWS, int H, int Ntr, int Nall, float* __restrict__ red) {
+                                              int FWS, int H, int Ntr, int Nall, float* __restrict__ red, float& extra) {
     float a_tr = 0.f, b_tr = 0.f, c_tr = 0.f, a_te = 0.f, b_te = 0.f, c_te = 0.f;
     constexpr int K = I + 1 + O;
     // RB data rows of one lane are kept in registers while the hidden units stream by: the packed weights of unit h are
@@ -689,6 +752,7 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
     // order whatever the blocking, so the sums do not depend on it.
     auto block = [&](auto rbk, int b0) {
         constexpr int RBK = decltype(rbk)::value;
+        constexpr int UNR = LEAN ? 2 : 1;
         const int n0 = gtid<WL>() + b0 * stride;
         const int nc = n0 < Nall ? n0 : 0;
         float x[RBK][I + 1];
@@ -706,6 +770,7 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
                 for (int o = 0; o < O; ++o) acc2[b][o] = f32x2{0.0f, 0.0f};
             const int HP = fw_pairs(H);
             constexpr int CH = 8, NF = I / CH, RQ = K - NF * CH;   // inputs in chunks of 8 pairs: bounded register footprint
+#pragma unroll UNR                                        // cooperative step loop: the next pair's weights arrive while this pair computes
             for (int hp = 0; hp < HP; ++hp) {
                 const float* row = fw + hp * 2 * FWS;      // wave-uniform address: broadcast reads
                 f32x2 z[RBK];
@@ -744,6 +809,7 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
             for (int b = 0; b < RBK; ++b)
 #pragma unroll
                 for (int o = 0; o < O; ++o) acc[b][o] = -b2[o];
+#pragma unroll UNR
             for (int h = 0; h < H; ++h) {
                 float f[K];
                 lds_load<K>(fw + h * FWS, f);              // wave-uniform address: broadcast reads
@@ -795,30 +861,14 @@ __device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, cons
     if (RB >= 8 && cnt - b0 >= 4) { block(std::integral_constant<int, 4>{}, b0); b0 += 4; }
     if (RB >= 4 && cnt - b0 >= 2) { block(std::integral_constant<int, 2>{}, b0); b0 += 2; }
     if (RB >= 2 && cnt - b0 >= 1) { block(std::integral_constant<int, 1>{}, b0); b0 += 1; }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    a_tr = wave_allsum(a_tr);
-    a_te = wave_allsum(a_te);
-    if (TASK == TASK_CLS) {
-        b_tr = wave_allsum(b_tr); c_tr = wave_allsum(c_tr);
-        b_te = wave_allsum(b_te); c_te = wave_allsum(c_te);
-    }
-    EvalSums s;
-    if (WL || nw == 1) {
-        s.a_tr = a_tr; s.b_tr = b_tr; s.c_tr = c_tr; s.a_te = a_te; s.b_te = b_te; s.c_te = c_te;
-        return s;
-    }
-    __syncthreads();                                       // red[] may still be read from the previous use
-    if (lane == 0) {
-        float* r = red + wave * 8;
-        r[0] = a_tr; r[1] = b_tr; r[2] = c_tr; r[3] = a_te; r[4] = b_te; r[5] = c_te;
-    }
-    __syncthreads();
-    s.a_tr = s.b_tr = s.c_tr = s.a_te = s.b_te = s.c_te = 0.f;
-    for (int k = 0; k < nw; ++k) {
-        const float* r = red + k * 8;
-        s.a_tr += r[0]; s.b_tr += r[1]; s.c_tr += r[2]; s.a_te += r[3]; s.b_te += r[4]; s.c_te += r[5];
-    }
-    return s;
+    return reduce_eval<TASK, WL, LEAN>(a_tr, b_tr, c_tr, a_te, b_te, c_te, red, extra);
+}
+
+template <int TASK, int I, int O, bool WL = false>
+__device__ __forceinline__ EvalSums eval_rows(const float* __restrict__ fw, const float* __restrict__ xy, int IPY,
+                                              int FWS, int H, int Ntr, int Nall, float* __restrict__ red) {
+    float none = 0.0f;
+    return eval_rows<TASK, I, O, WL, false>(fw, xy, IPY, FWS, H, Ntr, Nall, red, none);
 }
 
 // block-wide sum of one value per thread, returned in every thread
@@ -885,24 +935,44 @@ __device__ __forceinline__ float block_sumsq_diff(const float* __restrict__ a, c
     return block_sum<WL>(s, red);
 }
 
-// likelihood / rmse / accuracy from the sums (R6: REG:200-205, CLS:209-222, 200-207); untempered log-likelihood
+// likelihood / rmse / accuracy from the sums (R6: REG:200-205, CLS:209-222, 200-207); untempered log-likelihood.  In two
+// parts because only the likelihood feeds the MH test: the cooperative step loop forms the scores after the decision, and
+// only in the wave that writes them.
 template <int TASK>
-__device__ __forceinline__ void finish_eval(const EvalSums& s, int Ntr, int Nte, float eta, float& loglik,
-                                            float& rmse_tr, float& rmse_te, float& acc_tr, float& acc_te) {
+__device__ __forceinline__ float finish_loglik(const EvalSums& s, int Ntr, float eta) {
     if (TASK == TASK_REG) {
         // sum_n [-0.5 log(2 pi tau^2) - 0.5 (y-fx)^2 / tau^2], tau^2 = exp(eta)
-        loglik = -0.5f * (float)Ntr * (LOG_2PI + eta) - 0.5f * s.a_tr * expf_fast(-eta);
+        // explicit fused operation (as in prior_value): every kernel must form the same bits whatever surrounds the call
+        return fmaf(-0.5f * s.a_tr, expf_fast(-eta), -0.5f * (float)Ntr * (LOG_2PI + eta));
+    }
+    return s.a_tr;
+}
+template <int TASK>
+__device__ __forceinline__ void finish_scores(const EvalSums& s, int Ntr, int Nte, float& rmse_tr, float& rmse_te, float& acc_tr,
+                                              float& acc_te) {
+    if (TASK == TASK_REG) {
         rmse_tr = __builtin_amdgcn_sqrtf(s.a_tr / (float)Ntr);
         rmse_te = __builtin_amdgcn_sqrtf(s.a_te / (float)Nte);
         acc_tr = 0.f;
         acc_te = 0.f;
     } else {
-        loglik = s.a_tr;
         rmse_tr = __builtin_amdgcn_sqrtf(s.b_tr / (float)Ntr);
         rmse_te = __builtin_amdgcn_sqrtf(s.b_te / (float)Nte);
         acc_tr = 100.0f * (s.c_tr / (float)Ntr);
         acc_te = 100.0f * (s.c_te / (float)Nte);
     }
+}
+template <int TASK>
+__device__ __forceinline__ void finish_eval(const EvalSums& s, int Ntr, int Nte, float eta, float& loglik,
+                                            float& rmse_tr, float& rmse_te, float& acc_tr, float& acc_te) {
+    loglik = finish_loglik<TASK>(s, Ntr, eta);
+    finish_scores<TASK>(s, Ntr, Nte, rmse_tr, rmse_te, acc_tr, acc_te);
+}
+
+// Langevin proposal ratio (REG:336-347, Q6): [-0.5 d1 / step^2 + 0.5 d2] / adapttemp with d1 = |w - w_prop_gd|^2 and
+// d2 = |noise|^2; one explicit fused operation, the same bits in every kernel
+__device__ __forceinline__ float langevin_ratio(float d1, float d2, float step_w, float adapttemp) {
+    return fmaf(0.5f, d2, -0.5f * d1 / (step_w * step_w)) / adapttemp;
 }
 
 // R7 prior_likelihood (REG:215-221 / CLS:224-230); prior_c = part1, log tau^2 = eta
@@ -919,23 +989,22 @@ struct Lds {
     float* xy; float* w_cur; float* w_prop; float* w_gd; float* w_pgd; float* rec_w; float* noise; float* fw;
     float* red; float* scal;
 };
-__device__ __forceinline__ Lds carve(float* base, int Nall, int IPY, int PS, int H, int FWS) {
+// lg = false (a launch without Langevin proposals): the two cached SGD epochs are not carved at all
+__device__ __forceinline__ Lds carve(float* base, int Nall, int IPY, int PS, int H, int FWS, bool lg = true) {
     Lds l;
     float* q = base;
     l.xy = q; q += (Nall + 2) * IPY;
-    l.w_cur = q; q += PS;
-    l.w_prop = q; q += PS;
-    l.w_gd = q; q += PS;
-    l.w_pgd = q; q += PS;
+    l.w_cur = q; q += PS;                                  // w_cur, w_prop, rec_w, w_gd, w_pgd in this order: the cooperative
+    l.w_prop = q; q += PS;                                 // step loop rotates them by offset
     l.rec_w = q; q += PS;
-    l.noise = q; q += PS;
+    l.w_gd = q; l.w_pgd = q + (lg ? PS : 0); q += lg ? 2 * PS : 0;
+    l.noise = q; l.scal = q + PS; q += 2 * (PS + 8);        // two tapes {noise[PS], scal[8]}: a step draws the next one's
     l.fw = q; q += fw_floats(H, FWS);
     l.red = q; q += MAX_WAVES * 8;
-    l.scal = q; q += 8;
     return l;
 }
-__host__ __device__ inline size_t lds_floats(int Nall, int IPY, int PS, int H, int FWS) {
-    return (size_t)(Nall + 2) * IPY + 6 * (size_t)PS + fw_floats(H, FWS) + MAX_WAVES * 8 + 8;
+__host__ __device__ inline size_t lds_floats(int Nall, int IPY, int PS, int H, int FWS, bool lg = true) {
+    return (size_t)(Nall + 2) * IPY + (lg ? 7 : 5) * (size_t)PS + fw_floats(H, FWS) + MAX_WAVES * 8 + 16;
 }
 
 // random tape of one step: noise[0..P) and scal[0..2] = {lx, u, n_eta}
@@ -1021,37 +1090,40 @@ __host__ __device__ inline size_t mfma_coop_lds_floats(int I, int O, int H, int 
     return (size_t)I * Npad + (size_t)((H + 31) >> 5) * Npad * O;
 }
 
-template <int TASK, int I, int O>
+template <int TASK, int I, int O, bool LEAN = false>
 __device__ __forceinline__ EvalSums eval_rows_mfma_coop(const float* __restrict__ wl, const float* __restrict__ xt,
                                                         float* __restrict__ part, const float* __restrict__ xy, int IPY,
-                                                        int H, int Ntr, int Nall, int Npad, float* __restrict__ red) {
+                                                        int H, int Ntr, int Nall, int Npad, float* __restrict__ red, float& extra) {
     constexpr int IK = (I + 1) & ~1, KS = IK / 2;
     const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: the unit loops branch on the SALU
     const int col = lane & 31, half = lane >> 5;
     const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
     const int ntiles = (H + 31) >> 5;
-    // phase 1: one unit = 32 data rows x 32 hidden units; units are dealt round-robin to the waves (11 row blocks x 2 tiles
-    // over 8 waves: 3 or 2 each).  Straight-line address arithmetic, no divergent control flow: absent units of a partial
-    // tile read the last real unit again / whatever follows in LDS (finite weights) and meet W2 = 0.
-    const int nunits = (Npad >> 5) * ntiles;
-    for (int u = wave; u < nunits; u += nw) {
-        const int rb = (ntiles == 1) ? u : (u >> 1), t = (ntiles == 1) ? 0 : (u & 1);   // H <= 64: one or two tiles
-        const int n = rb * 32 + col;                                   // this lane's data row (Npad covers the last block)
+    // phase 1: one unit = 32 data rows x 32 hidden units (11 row blocks x 2 tiles for Ionosphere).  With two tiles the waves
+    // split between them, so a wave keeps ONE tile's operands -- the weights (A), biases and W2 rows of its 32 hidden units --
+    // in registers for all of its row blocks, and only the data columns (B) change.  Up to three row blocks run at once:
+    // the k-steps of one accumulator depend on each other (a 32x32x2 MFMA issues in 64 cycles but its result returns later),
+    // three independent accumulators keep the matrix pipe busy.  Every accumulator still adds its k-steps in ascending
+    // order.  Straight-line address arithmetic, no divergent control flow: absent units of a partial tile read the last
+    // real unit again / whatever follows in LDS (finite weights) and meet W2 = 0.
+    const int nrb = Npad >> 5;
+    const int tsplit = (ntiles == 2 && nw >= 2) ? 2 : 1;
+    const int t0 = (tsplit == 2) ? (wave & 1) : 0, tcount = (tsplit == 2) ? 1 : ntiles;
+    const int rb0 = (tsplit == 2) ? (wave >> 1) : wave, rbstride = nw / tsplit;
+    for (int tt = 0; tt < tcount; ++tt) {
+        const int t = t0 + tt;
         const int hbase = t * 32;
         const float* pa = wl + half * H + min(hbase + col, H - 1);
-        const float* pb = xt + half * Npad + n;
-        float bf[KS], aa[KS];
+        float aa[KS];
 #pragma unroll
-        for (int s_ = 0; s_ < KS; ++s_) {                              // all k-steps in one batch of conflict-free LDS reads
+        for (int s_ = 0; s_ < KS; ++s_) {
             const bool pad = (IK != I) && (s_ == KS - 1) && half;      // odd I: k = I of the upper lane half is padding
-            const float vb = pb[(size_t)s_ * 2 * Npad - (pad ? Npad : 0)];
             const float va = pa[s_ * 2 * H - (pad ? H : 0)];
-            bf[s_] = pad ? 0.0f : vb;
             aa[s_] = pad ? 0.0f : va;
         }
-        // bias and W2 rows of this lane's 16 hidden units, fetched while the matrix pipe works (absent units: both zero,
-        // so their sigmoid is a finite 0.5 that meets W2 = 0)
+        // bias and W2 rows of this lane's 16 hidden units (absent units: both zero, so their sigmoid is a finite 0.5 that
+        // meets W2 = 0)
         const int hq = hbase + 4 * half;
         const float* pb1 = wl + oB1 + hq;
         const float* pw2 = wl + oW2 + hq * O;
@@ -1065,27 +1137,51 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_coop(const float* __restrict_
 #pragma unroll
             for (int o = 0; o < O; ++o) { const float v = pw2[dh * O + o]; w2r[r_][o] = in ? v : 0.0f; }
         }
-        f32x16 acc;
+        auto batch = [&](auto nb_, int rb) {
+            constexpr int NB = decltype(nb_)::value;
+            float bf[NB][KS];
+            f32x16 acc[NB];
 #pragma unroll
-        for (int r_ = 0; r_ < 16; ++r_) acc[r_] = 0.0f;
+            for (int b_ = 0; b_ < NB; ++b_) {
+                const float* pb = xt + half * Npad + (rb + b_ * rbstride) * 32 + col;   // this lane's data row (Npad covers the last block)
 #pragma unroll
-        for (int s_ = 0; s_ < KS; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[s_], bf[s_], acc, 0, 0, 0);
-        float sum[O];
+                for (int s_ = 0; s_ < KS; ++s_) {                      // all k-steps in one batch of conflict-free LDS reads
+                    const bool pad = (IK != I) && (s_ == KS - 1) && half;
+                    const float vb = pb[(size_t)s_ * 2 * Npad - (pad ? Npad : 0)];
+                    bf[b_][s_] = pad ? 0.0f : vb;
+                }
 #pragma unroll
-        for (int o = 0; o < O; ++o) sum[o] = 0.0f;
+                for (int r_ = 0; r_ < 16; ++r_) acc[b_][r_] = 0.0f;
+            }
 #pragma unroll
-        for (int r_ = 0; r_ < 16; ++r_) {
-            const float hid = sigmoidf_fast(acc[r_] - b1r[r_]);
+            for (int s_ = 0; s_ < KS; ++s_)
 #pragma unroll
-            for (int o = 0; o < O; ++o) sum[o] = fmaf(hid, w2r[r_][o], sum[o]);
-        }
+                for (int b_ = 0; b_ < NB; ++b_) acc[b_] = __builtin_amdgcn_mfma_f32_32x32x2f32(aa[s_], bf[b_][s_], acc[b_], 0, 0, 0);
 #pragma unroll
-        for (int o = 0; o < O; ++o) {                                  // hidden units 4..7, 12..15, ... live in lanes 32..63
-            const unsigned uu = __builtin_bit_cast(unsigned, sum[o]);
-            auto r2 = __builtin_amdgcn_permlane32_swap(uu, uu, false, false);
-            const float tot = __builtin_bit_cast(float, (unsigned)r2[0]) + __builtin_bit_cast(float, (unsigned)r2[1]);
-            if (half == 0) part[((size_t)t * Npad + n) * O + o] = tot;
-        }
+            for (int b_ = 0; b_ < NB; ++b_) {
+                const int n = (rb + b_ * rbstride) * 32 + col;
+                float sum[O];
+#pragma unroll
+                for (int o = 0; o < O; ++o) sum[o] = 0.0f;
+#pragma unroll
+                for (int r_ = 0; r_ < 16; ++r_) {
+                    const float hid = sigmoidf_fast(acc[b_][r_] - b1r[r_]);
+#pragma unroll
+                    for (int o = 0; o < O; ++o) sum[o] = fmaf(hid, w2r[r_][o], sum[o]);
+                }
+#pragma unroll
+                for (int o = 0; o < O; ++o) {                          // hidden units 4..7, 12..15, ... live in lanes 32..63
+                    const unsigned uu = __builtin_bit_cast(unsigned, sum[o]);
+                    auto r2 = __builtin_amdgcn_permlane32_swap(uu, uu, false, false);
+                    const float tot = __builtin_bit_cast(float, (unsigned)r2[0]) + __builtin_bit_cast(float, (unsigned)r2[1]);
+                    if (half == 0) part[((size_t)t * Npad + n) * O + o] = tot;
+                }
+            }
+        };
+        int rb = rb0;
+        for (; rb + 2 * rbstride < nrb; rb += 3 * rbstride) batch(std::integral_constant<int, 3>{}, rb);
+        if (rb + rbstride < nrb) { batch(std::integral_constant<int, 2>{}, rb); rb += 2 * rbstride; }
+        if (rb < nrb) batch(std::integral_constant<int, 1>{}, rb);
     }
     __syncthreads();
     // phase 2: one lane per data row joins the tiles (ascending) and scores the row
@@ -1127,25 +1223,7 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_coop(const float* __restrict_
         if (n < Ntr) { a_tr += a; b_tr += bb; c_tr += c; }
         else { a_te += a; b_te += bb; c_te += c; }
     }
-    a_tr = wave_allsum(a_tr);
-    a_te = wave_allsum(a_te);
-    if (TASK == TASK_CLS) {
-        b_tr = wave_allsum(b_tr); c_tr = wave_allsum(c_tr);
-        b_te = wave_allsum(b_te); c_te = wave_allsum(c_te);
-    }
-    EvalSums s;
-    __syncthreads();
-    if (lane == 0) {
-        float* r = red + wave * 8;
-        r[0] = a_tr; r[1] = b_tr; r[2] = c_tr; r[3] = a_te; r[4] = b_te; r[5] = c_te;
-    }
-    __syncthreads();
-    s.a_tr = s.b_tr = s.c_tr = s.a_te = s.b_te = s.c_te = 0.f;
-    for (int k = 0; k < nw; ++k) {
-        const float* r = red + k * 8;
-        s.a_tr += r[0]; s.b_tr += r[1]; s.c_tr += r[2]; s.a_te += r[3]; s.b_te += r[4]; s.c_te += r[5];
-    }
-    return s;
+    return reduce_eval<TASK, false, LEAN>(a_tr, b_tr, c_tr, a_te, b_te, c_te, red, extra);
 }
 
 
@@ -1171,7 +1249,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
     const int gid = p.first_global + r;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int Nall = p.Ntr + p.Nte;
-    const Lds l = carve(smem, Nall, p.IPY, p.PS, p.H, p.FWS);
+    const Lds l = carve(smem, Nall, p.IPY, p.PS, p.H, p.FWS, p.use_lg != 0);
     const int P = p.P, PS = p.PS, H = p.H;
 
     // stage the data set and this replica's vectors (coalesced)
@@ -1184,10 +1262,10 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
     for (int j = tid; j < PS; j += nthr) {
         l.w_cur[j] = gw[j];
         l.rec_w[j] = p.rec_w[(size_t)r * PS + j];
-        l.w_gd[j] = p.gd_w[(size_t)r * PS + j];
+        if (p.use_lg) l.w_gd[j] = p.gd_w[(size_t)r * PS + j];
     }
     // MFMA forward pass (host decides): transposed data image and per-tile partial sums behind the common LDS block
-    float* xt_l = smem + lds_floats(Nall, p.IPY, p.PS, p.H, p.FWS);
+    float* xt_l = smem + lds_floats(Nall, p.IPY, p.PS, p.H, p.FWS, p.use_lg != 0);
     float* part_l = xt_l + (size_t)I * p.Npad;
     if (p.fw_mfma)
         for (int e = tid; e < I * p.Npad; e += nthr) xt_l[e] = p.xt[e];
@@ -1221,17 +1299,42 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
     const unsigned long long stamp_t0 = stamp_last;
 #endif
     const size_t trow = (size_t)r * p.trace_cap;        // traces are rings of trace_cap rows per replica (== S unless streaming)
-    for (int i = step_begin; i < step_begin + n_steps; ++i) {
+    // A step is three phases between two work-group barriers (a random-walk step; a Langevin step adds its SGD epochs):
+    //   A  proposal and its packed forward image in one pass over the weights
+    //   B  forward pass over all rows; |proposal|^2 for the prior rides in the same reduction; the random tape of the NEXT
+    //      step is drawn here too (it depends on nothing the chain computes), by the last wave alone when it fits one wave
+    //      (that wave has the fewest data rows, for Iris none)
+    //   C  every thread finishes likelihood, prior and the MH test from the reduced sums; trace row
+    // The weight vectors are not copied on an accept: current, recorded and proposed vector rotate through three buffers
+    // (the recorded vector differs from the current one only until the first accept after a swap), and so do the two
+    // cached SGD epochs.  Double-buffered tape, one reduction array: nothing a slow thread still reads in C is written
+    // before the next barrier.
+    const int step_end = step_begin + n_steps;
+    const int wave = uni_i(tid >> 6), nwaves = nthr >> 6;
+    const bool tape_one_wave = ((P + 3) >> 2) + 1 <= WAVE && nwaves > 1;
+    float* const wbuf = l.w_cur;                          // w_cur, w_prop, rec_w, w_gd, w_pgd: PS floats each, in this order
+    int o_cur = 0, o_prop = PS, o_rec = 2 * PS, o_gd = 3 * PS, o_pgd = 4 * PS;
+    int par = 0;
+    int ring_pos = (step_begin + 1) % p.trace_cap;       // trace row of step i is row (i + 1) mod trace_cap of the replica's ring
+    if (n_steps > 0) tape_step(p, gid, step_begin, l.noise, l.scal);
+    __syncthreads();
+    for (int i = step_begin; i < step_end; ++i) {
         STAMP(0);
+        float* const w_cur = wbuf + o_cur;
+        float* const w_prop = wbuf + o_prop;
+        const float* const noise = l.noise + par * (PS + 8);
+        const float* const scal = l.scal + par * (PS + 8);
         // R10 temperature schedule (REG:317-324): tempered until the switch step, canonical afterwards
         float adapttemp = (p.switch_step >= 0 && i >= p.switch_step) ? 1.0f : T;
         if (i == p.switch_step) {
             // re-evaluate the current w with the LAST PROPOSED tau (Q9, REG:322)
             EvalSums sc;
+            float none = 0.0f;
+            __syncthreads();                                // the previous step's readers of red[]
             if (p.fw_mfma) {
-                sc = eval_rows_mfma_coop<TASK, I, O>(l.w_cur, xt_l, part_l, l.xy, p.IPY, H, p.Ntr, Nall, p.Npad, l.red);
+                sc = eval_rows_mfma_coop<TASK, I, O>(w_cur, xt_l, part_l, l.xy, p.IPY, H, p.Ntr, Nall, p.Npad, l.red, none);
             } else {
-                build_fw<I, O>(l.w_cur, l.fw, H, p.FWS);
+                build_fw<I, O>(w_cur, l.fw, H, p.FWS);
                 __syncthreads();
                 sc = eval_rows<TASK, I, O>(l.fw, l.xy, p.IPY, p.FWS, H, p.Ntr, Nall, l.red);
             }
@@ -1240,80 +1343,82 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
             lik = ll;                                       // adapttemp == 1
             __syncthreads();
         }
-        tape_step(p, gid, i, l.noise, l.scal);
-        __syncthreads();
-        STAMP(1);                                         // tape
-        const float lx = l.scal[0], u = l.scal[1], n_eta = l.scal[2];
+        STAMP(1);
+        const float lx = scal[0], u = scal[1], n_eta = scal[2];
         float diff_prop = 0.0f;
         const bool lg = p.use_lg && (lx < p.l_prob);
         if (lg) {
             // Langevin proposal (REG:329-347): w_gd = SGD epoch from w (cached while w is unchanged),
             // w_proposal = w_gd + step_w * noise, w_prop_gd = SGD epoch from w_proposal
+            float* const w_gd = wbuf + o_gd;
+            float* const w_pgd = wbuf + o_pgd;
             if (!gd_valid) {
-                if (tid < WAVE) sgd_sweep_dispatch<TASK, I, O>(l.w_cur, l.w_gd, l.xy, p.data, p.Ntr, H, p.lr);
+                if (tid < WAVE) sgd_sweep_dispatch<TASK, I, O>(w_cur, w_gd, l.xy, p.data, p.Ntr, H, p.lr);
                 gd_valid = 1;
                 __syncthreads();
             }
-            for (int j = tid; j < P; j += nthr) l.w_prop[j] = fmaf(p.step_w, l.noise[j], l.w_gd[j]);
+            for (int j = tid; j < P; j += nthr) w_prop[j] = fmaf(p.step_w, noise[j], w_gd[j]);
             __syncthreads();
-            if (tid < WAVE) sgd_sweep_dispatch<TASK, I, O>(l.w_prop, l.w_pgd, l.xy, p.data, p.Ntr, H, p.lr);
+            if (tid < WAVE) sgd_sweep_dispatch<TASK, I, O>(w_prop, w_pgd, l.xy, p.data, p.Ntr, H, p.lr);
             __syncthreads();
             // first - second = [-0.5 |w - w_prop_gd|^2 + 0.5 |w_proposal - w_gd|^2] / step_w^2; the second norm is
             // step_w^2 |noise|^2 exactly in real arithmetic
-            const float d1 = block_sumsq_diff(l.w_cur, l.w_pgd, P, l.red);
-            const float d2 = block_sumsq(l.noise, P, l.red);
-            diff_prop = (-0.5f * d1 / (p.step_w * p.step_w) + 0.5f * d2) / adapttemp;   // Q6
+            const float d1 = block_sumsq_diff(w_cur, w_pgd, P, l.red);
+            const float d2 = block_sumsq(noise, P, l.red);
+            diff_prop = langevin_ratio(d1, d2, p.step_w, adapttemp);   // Q6
             lg_count += 1;
+            if (!p.fw_mfma) build_fw<I, O>(w_prop, l.fw, H, p.FWS);
+        } else if (p.fw_mfma) {
+            for (int j = tid; j < P; j += nthr) w_prop[j] = fmaf(p.step_w, noise[j], w_cur[j]);
         } else {
-            for (int j = tid; j < P; j += nthr) l.w_prop[j] = fmaf(p.step_w, l.noise[j], l.w_cur[j]);
-            __syncthreads();
+            propose_build_fw<I, O>(w_cur, noise, p.step_w, w_prop, l.fw, H, p.FWS);
         }
+        __syncthreads();
         float eta_pro = eta;
         if (TASK == TASK_REG) { eta_pro = fmaf(p.step_eta, n_eta, eta); tau_eta_last = eta_pro; }
-        STAMP(2);                                         // proposal (+ SGD epochs)
+        STAMP(2);                                         // proposal (+ SGD epochs) and packed forward image
 
-        EvalSums es;
-        if (p.fw_mfma) {
-            STAMP(3);
-            es = eval_rows_mfma_coop<TASK, I, O>(l.w_prop, xt_l, part_l, l.xy, p.IPY, H, p.Ntr, Nall, p.Npad, l.red);
-        } else {
-            build_fw<I, O>(l.w_prop, l.fw, H, p.FWS);
-            __syncthreads();
-            STAMP(3);                                     // packed forward image
-            es = eval_rows<TASK, I, O>(l.fw, l.xy, p.IPY, p.FWS, H, p.Ntr, Nall, l.red);
+        float ssq = 0.0f;                                 // this thread's part of |proposal|^2 (block_sumsq's partition)
+        for (int j = tid; j < P; j += nthr) ssq = fmaf(w_prop[j], w_prop[j], ssq);
+        if (i + 1 < step_end) {
+            float* const nn = l.noise + (par ^ 1) * (PS + 8);
+            float* const ns = l.scal + (par ^ 1) * (PS + 8);
+            if (!tape_one_wave) tape_step(p, gid, i + 1, nn, ns);
+            else if (wave == nwaves - 1) tape_step<true>(p, gid, i + 1, nn, ns);
         }
-        float ll, rm_tr, rm_te, ac_tr, ac_te;
-        finish_eval<TASK>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
-        const float lik_prop = ll / adapttemp;
+        STAMP(3);                                         // next step's tape
+        EvalSums es;
+        if (p.fw_mfma) es = eval_rows_mfma_coop<TASK, I, O, true>(w_prop, xt_l, part_l, l.xy, p.IPY, H, p.Ntr, Nall, p.Npad, l.red, ssq);
+        else es = eval_rows<TASK, I, O, false, true>(l.fw, l.xy, p.IPY, p.FWS, H, p.Ntr, Nall, l.red, ssq);
+        const float lik_prop = finish_loglik<TASK>(es, p.Ntr, eta_pro) / adapttemp;
         STAMP(4);                                         // forward pass over all rows + likelihood
-        const float ssq = block_sumsq(l.w_prop, P, l.red);
         const float prior_prop = prior_value<TASK>(p, ssq, eta_pro);
 
         // R9 Metropolis-Hastings (REG:372-423): NaN -> accept (Q8), overflow -> 1
         const float logalpha = (lik_prop - lik) + (prior_prop - prior_cur) + diff_prop;
         const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
-        const bool accept = u < mh;
+        const bool accept = uni_i((u < mh) ? 1 : 0) != 0;  // the same value in every thread: a scalar branch
         const int acc_before = nacc;
         if (accept) {
             nacc += 1;
             lik = lik_prop;
             prior_cur = prior_prop;
             eta = eta_pro;
-            rec_rmse_tr = rm_tr; rec_rmse_te = rm_te;
-            rec_acc_tr = ac_tr; rec_acc_te = ac_te;       // REG: 0 (REG:403-404); CLS: accuracy (CLS:414-415)
+            // the recorded scores live in wave 0 only: thread 0 writes them (trace row, state write-back)
+            if (wave == 0) finish_scores<TASK>(es, p.Ntr, p.Nte, rec_rmse_tr, rec_rmse_te, rec_acc_tr, rec_acc_te);   // REG: acc 0 (REG:403-404); CLS: accuracy (CLS:414-415)
             gd_valid = lg ? 1 : 0;                        // w_prop_gd is langevin_gradient(new w): keep it as the cache
-            for (int j = tid; j < P; j += nthr) {
-                const float v = l.w_prop[j];
-                l.w_cur[j] = v; l.rec_w[j] = v;
-                if (lg) l.w_gd[j] = l.w_pgd[j];
-            }
+            const int old_cur = o_cur;
+            o_cur = o_prop; o_rec = o_prop; o_prop = old_cur;   // old_cur is neither the new current nor the new recorded vector
+            if (lg) { const int t_ = o_gd; o_gd = o_pgd; o_pgd = t_; }
         }
-        __syncthreads();
+        par ^= 1;
         STAMP(5);                                         // prior, MH, state update
         // trace row i+1 (the only HBM traffic of a step)
-        const size_t tpos = trow + (size_t)((i + 1) % p.trace_cap);
+        const size_t tpos = trow + (size_t)ring_pos;
+        ring_pos = (ring_pos + 1 == p.trace_cap) ? 0 : ring_pos + 1;
         float* prow = p.tr_pos_w + tpos * (size_t)p.PW;
-        for (int j = tid; j < p.PW; j += nthr) prow[j] = (j < P) ? l.rec_w[j] : 0.0f;
+        const float* const w_rec = wbuf + o_rec;
+        for (int j = tid; j < p.PW; j += nthr) prow[j] = (j < P) ? w_rec[j] : 0.0f;
         if (tid == 0) {
             store_trace_row(p.tr_scal + tpos * TR_COUNT, (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp /* REG:391 / CLS:404 */,
                             rec_rmse_tr, rec_rmse_te, rec_acc_tr, rec_acc_te, acc_before /* REG:380 */, logalpha);
@@ -1331,9 +1436,9 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p,
     // write the chain state back and post the swap scalars
     __syncthreads();
     for (int j = tid; j < PS; j += nthr) {
-        gw[j] = (j == P) ? eta : l.w_cur[j];
-        p.rec_w[(size_t)r * PS + j] = l.rec_w[j];
-        p.gd_w[(size_t)r * PS + j] = l.w_gd[j];
+        gw[j] = (j == P) ? eta : wbuf[o_cur + j];
+        p.rec_w[(size_t)r * PS + j] = wbuf[o_rec + j];
+        if (p.use_lg) p.gd_w[(size_t)r * PS + j] = wbuf[o_gd + j];
     }
     if (tid == 0) {
         sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur; sf[SF_TAU_LAST] = tau_eta_last;
@@ -1532,7 +1637,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
                 gsync<true>();
                 const float d1 = block_sumsq_diff<true>(w_cur, my_pgd, P, nullptr);
                 const float d2 = block_sumsq<true>(my_noise, P, nullptr);
-                diff_prop = (-0.5f * d1 / (p.step_w * p.step_w) + 0.5f * d2) / adapttemp;
+                diff_prop = langevin_ratio(d1, d2, p.step_w, adapttemp);
             } else {
                 for (int e = lane; e < P; e += WAVE) my_prop[e] = fmaf(p.step_w, my_noise[e], w_cur[e]);
                 gsync<true>();
@@ -1968,7 +2073,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
                     r1[c] = (16 * c < P) ? group_allsum<4>(a1) : 0.0f;     // a row beyond P sums zeros: exactly 0 either way
                 }
                 const float d1 = (r1[0] + r1[1]) + (r1[2] + r1[3]);
-                if (sl[SL_LG] != 0.0f) diff_prop = (-0.5f * d1 / (p.step_w * p.step_w) + 0.5f * sl[SL_D2]) / sl[SL_ADAPT];
+                if (sl[SL_LG] != 0.0f) diff_prop = langevin_ratio(d1, sl[SL_D2], p.step_w, sl[SL_ADAPT]);
             }
             const float logalpha = (sl[SL_LIKPROP] - lik) + (sl[SL_PRIORPROP] - prior_cur) + diff_prop;
             const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
@@ -2463,7 +2568,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
             sgd_sweep_wide<TASK, I, O>(w_prop, w_pgd, xy, p.IPY, p.Ntr, H, p.lr, part);
             const float d1 = block_sumsq_diff(w_cur, w_pgd, P, red);
             const float d2 = block_sumsq(noise, P, red);
-            diff_prop = (-0.5f * d1 / (p.step_w * p.step_w) + 0.5f * d2) / adapttemp;
+            diff_prop = langevin_ratio(d1, d2, p.step_w, adapttemp);
             lg_count += 1;
         } else {
             for (int j = tid; j < P; j += nthr) w_prop[j] = fmaf(p.step_w, noise[j], w_cur[j]);

@@ -138,6 +138,10 @@ def run(seed=0, ncase=30, verbose=True, shapes="timeseries+iris", oracle=False):
               bad += 1
               diffs = [k for k in ref[0] if not np.array_equal(got[0][k], ref[0][k], equal_nan=True)]
               print(f"MISMATCH case {case}: task={task} {name} H={H} ntr={ntr} nte={nte} R={R} S={S} si={si} lg={lg} seed={seed} {refv} vs {v}: {diffs} stats {ref[1]} {got[1]}", flush=True)
+              for k in diffs[:3]:                          # where and by how much (first few positions)
+                  a_, b_ = np.asarray(ref[0][k]), np.asarray(got[0][k])
+                  idx = np.argwhere(~((a_ == b_) | (np.isnan(a_) & np.isnan(b_))))[:6]
+                  print("   ", k, [(tuple(int(t) for t in ix), float(a_[tuple(ix)]), float(b_[tuple(ix)])) for ix in idx], flush=True)
       if verbose:
           print(f"case {case}: task={task} {name} H={H} ntr={ntr} R={R} S={S} si={si} lg={lg} ok", flush=True)
   if verbose:
