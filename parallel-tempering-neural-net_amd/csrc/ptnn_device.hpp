@@ -2489,13 +2489,18 @@ __device__ __forceinline__ EvalSums eval_rows_mfma(const float* __restrict__ wl,
 
 // forward pass of a wide net under weight vector w (global): MFMA when the hidden layer tiles (H % 32 == 0), else the
 // lane-per-row VALU path on the packed image.  `img` is the LDS image area (max of both layouts).
+__device__ __forceinline__ bool wide_mfma(const SegParams& p) { return (p.H & 31) == 0 && p.xt != nullptr; }
+
+// img_ready: the caller has already put the flat copy of w into img (MFMA layout only) and passed a barrier
 template <int TASK, int I, int O>
 __device__ __forceinline__ EvalSums wide_forward(const SegParams& p, const float* __restrict__ w, float* __restrict__ img,
-                                                 float* __restrict__ red) {
+                                                 float* __restrict__ red, bool img_ready = false) {
     const int Nall = p.Ntr + p.Nte;
-    if ((p.H & 31) == 0 && p.xt != nullptr) {
-        for (int j = threadIdx.x; j < p.P; j += blockDim.x) img[j] = w[j];        // flat copy: the layout IS [k][h]
-        __syncthreads();
+    if (wide_mfma(p)) {
+        if (!img_ready) {
+            for (int j = threadIdx.x; j < p.P; j += blockDim.x) img[j] = w[j];    // flat copy: the layout IS [k][h]
+            __syncthreads();
+        }
         if (p.forward_bf16) return eval_rows_mfma<TASK, I, O, true>(img, p.xt, p.data, p.IPY, p.H, p.Ntr, Nall, p.Npad, red);
         return eval_rows_mfma<TASK, I, O, false>(img, p.xt, p.data, p.IPY, p.H, p.Ntr, Nall, p.Npad, red);
     }
@@ -2553,34 +2558,76 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
             lik = ll;
             __syncthreads();
         }
-        tape_step(p, gid, i, noise, scal);
-        __syncthreads();
-        const float lx = scal[0], u = scal[1], n_eta = scal[2];
+        // the step's scalars {lx, u, n_eta}: every thread draws them itself (one Philox call) instead of one thread + a barrier
+        float lx, u, n_eta;
+        {
+            uint32_t x[4];
+            philox4x32_10(0u, (uint32_t)i, p.noise_shared ? 0u : (uint32_t)gid, STREAM_STEP, p.seed_lo, p.seed_hi, x);
+            float n2, n3;
+            box_muller(x[2], x[3], n2, n3);
+            lx = uni_f(u23(x[0])); u = uni_f(u23(x[1])); n_eta = uni_f(n2);
+        }
         float diff_prop = 0.0f;
         const bool lg = p.use_lg && (lx < p.l_prob);
-        if (lg) {
-            if (!gd_valid) {
-                sgd_sweep_wide<TASK, I, O>(w_cur, w_gd, xy, p.IPY, p.Ntr, H, p.lr, part);
-                gd_valid = 1;
+        if (lg && !gd_valid) {
+            sgd_sweep_wide<TASK, I, O>(w_cur, w_gd, xy, p.IPY, p.Ntr, H, p.lr, part);
+            gd_valid = 1;
+        }
+        // ONE pass over the weights: draw the noise (4 normals per Philox call), form the proposal from w (random walk) or
+        // from the cached SGD epoch (Langevin), put it where the forward pass reads it (the flat LDS image of the MFMA
+        // layout) and in its global row, and add up |proposal|^2 (prior) and |noise|^2 (Langevin ratio) on the way.  The
+        // noise itself is never stored.  (It used to be five passes through global memory: tape, proposal, image copy and
+        // the two norms.)
+        const bool img_direct = wide_mfma(p);
+        float ssq_part = 0.0f, nsq_part = 0.0f;
+        {
+            const float* base = lg ? w_gd : w_cur;
+            const int nq = (P + 3) >> 2;
+            for (int q = tid; q < nq; q += nthr) {
+                uint32_t x[4];
+                philox4x32_10((uint32_t)q, (uint32_t)i, p.noise_shared ? 0u : (uint32_t)gid, STREAM_WNOISE, p.seed_lo, p.seed_hi, x);
+                float n[4];
+                box_muller(x[0], x[1], n[0], n[1]);
+                box_muller(x[2], x[3], n[2], n[3]);
+                const int j0 = 4 * q;
+                if (j0 + 3 < P) {
+                    const float4 b = *reinterpret_cast<const float4*>(base + j0);
+                    const float4 v = make_float4(fmaf(p.step_w, n[0], b.x), fmaf(p.step_w, n[1], b.y), fmaf(p.step_w, n[2], b.z),
+                                                 fmaf(p.step_w, n[3], b.w));
+                    *reinterpret_cast<float4*>(w_prop + j0) = v;
+                    if (img_direct) *reinterpret_cast<float4*>(fw + j0) = v;
+                    ssq_part = fmaf(v.x, v.x, ssq_part); ssq_part = fmaf(v.y, v.y, ssq_part);
+                    ssq_part = fmaf(v.z, v.z, ssq_part); ssq_part = fmaf(v.w, v.w, ssq_part);
+                    nsq_part = fmaf(n[0], n[0], nsq_part); nsq_part = fmaf(n[1], n[1], nsq_part);
+                    nsq_part = fmaf(n[2], n[2], nsq_part); nsq_part = fmaf(n[3], n[3], nsq_part);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (j0 + e < P) {
+                            const float v = fmaf(p.step_w, n[e], base[j0 + e]);
+                            w_prop[j0 + e] = v;
+                            if (img_direct) fw[j0 + e] = v;
+                            ssq_part = fmaf(v, v, ssq_part);
+                            nsq_part = fmaf(n[e], n[e], nsq_part);
+                        }
+                }
             }
-            for (int j = tid; j < P; j += nthr) w_prop[j] = fmaf(p.step_w, noise[j], w_gd[j]);
-            __syncthreads();
+        }
+        __syncthreads();
+        if (lg) {
             sgd_sweep_wide<TASK, I, O>(w_prop, w_pgd, xy, p.IPY, p.Ntr, H, p.lr, part);
             const float d1 = block_sumsq_diff(w_cur, w_pgd, P, red);
-            const float d2 = block_sumsq(noise, P, red);
+            const float d2 = block_sum(nsq_part, red);
             diff_prop = langevin_ratio(d1, d2, p.step_w, adapttemp);
             lg_count += 1;
-        } else {
-            for (int j = tid; j < P; j += nthr) w_prop[j] = fmaf(p.step_w, noise[j], w_cur[j]);
-            __syncthreads();
         }
         float eta_pro = eta;
         if (TASK == TASK_REG) { eta_pro = fmaf(p.step_eta, n_eta, eta); tau_eta_last = eta_pro; }
-        const EvalSums es = wide_forward<TASK, I, O>(p, w_prop, fw, red);
+        const EvalSums es = wide_forward<TASK, I, O>(p, w_prop, fw, red, img_direct);
         float ll, rm_tr, rm_te, ac_tr, ac_te;
         finish_eval<TASK>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
         const float lik_prop = ll / adapttemp;
-        const float ssq = block_sumsq(w_prop, P, red);
+        const float ssq = block_sum(ssq_part, red);
         const float prior_prop = prior_value<TASK>(p, ssq, eta_pro);
         const float logalpha = (lik_prop - lik) + (prior_prop - prior_cur) + diff_prop;
         const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
@@ -2589,19 +2636,37 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
         __syncthreads();                                    // every reader of w_cur / w_gd of this step is done
         const size_t tpos = trow + (size_t)((i + 1) % p.trace_cap);
         float* prow = p.tr_pos_w + tpos * (size_t)p.PW;
-        for (int j = P + tid; j < p.PW; j += nthr) prow[j] = 0.0f;
+        // rows of PS / PW floats are 16-byte aligned and padded: whole float4s, the tail past P rewritten as it must be
+        // (trace row: zeros; state rows: the element at P is eta, restored at the end of the launch, the rest is padding)
+        const int nv = (P + 3) >> 2;
+        for (int j = 4 * nv + tid; j < p.PW; j += nthr) prow[j] = 0.0f;
         if (accept) {
             nacc += 1;
             lik = lik_prop; prior_cur = prior_prop; eta = eta_pro;
             rec_rmse_tr = rm_tr; rec_rmse_te = rm_te; rec_acc_tr = ac_tr; rec_acc_te = ac_te;
             gd_valid = lg ? 1 : 0;
-            for (int j = tid; j < P; j += nthr) {
-                const float v = w_prop[j];
-                w_cur[j] = v; rec_w[j] = v; prow[j] = v;
-                if (lg) w_gd[j] = w_pgd[j];
+            for (int q = tid; q < nv; q += nthr) {
+                float4 v = *reinterpret_cast<const float4*>(w_prop + 4 * q);
+                if (4 * q + 3 >= P) {                        // the last, partial quad: nothing of the proposal past P
+                    if (4 * q + 1 >= P) v.y = 0.0f;
+                    if (4 * q + 2 >= P) v.z = 0.0f;
+                    v.w = 0.0f;
+                }
+                *reinterpret_cast<float4*>(w_cur + 4 * q) = v;
+                *reinterpret_cast<float4*>(rec_w + 4 * q) = v;
+                *reinterpret_cast<float4*>(prow + 4 * q) = v;
+                if (lg) *reinterpret_cast<float4*>(w_gd + 4 * q) = *reinterpret_cast<const float4*>(w_pgd + 4 * q);
             }
         } else {
-            for (int j = tid; j < P; j += nthr) prow[j] = rec_w[j];
+            for (int q = tid; q < nv; q += nthr) {
+                float4 v = *reinterpret_cast<const float4*>(rec_w + 4 * q);
+                if (4 * q + 3 >= P) {
+                    if (4 * q + 1 >= P) v.y = 0.0f;
+                    if (4 * q + 2 >= P) v.z = 0.0f;
+                    v.w = 0.0f;
+                }
+                *reinterpret_cast<float4*>(prow + 4 * q) = v;
+            }
         }
         if (tid == 0) {
             store_trace_row(p.tr_scal + tpos * TR_COUNT, (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp, rec_rmse_tr, rec_rmse_te,
