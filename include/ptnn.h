@@ -30,6 +30,7 @@ extern "C" {
 #define PTNN_SCHED_COOPERATIVE 1
 #define PTNN_SCHED_SPECULATIVE 2
 #define PTNN_SCHED_PACKED 3      /* speculative, all slots of a round on one CU (n_hidden <= 8) */
+#define PTNN_SCHED_TREE 4        /* prefetching: 2^D - 1 work-groups evaluate every outcome of the next D decisions (random-walk classification) */
 
 typedef struct ptnn_handle ptnn_handle;
 
@@ -50,9 +51,13 @@ typedef struct ptnn_config {
     int32_t waves_per_replica;    /* 0 = auto; 1,2,4,8: wavefronts per work-group */
     int32_t schedule;             /* 0 = auto, 1 = cooperative (all waves share one MH step), 2 = speculative
                                    * (wave v pre-computes step i+v; identical chain), 3 = packed
-                                   * speculative (n_hidden <= 8: 16 slots on one CU, SGD epochs in lane groups) */
+                                   * speculative (n_hidden <= 8: 16 slots on one CU, SGD epochs in lane groups), 4 = prefetching
+                                   * tree (random-walk classification runs: groups_per_replica = 2^D - 1 work-groups evaluate the
+                                   * proposals of all outcomes of the next D accept/reject decisions, D steps per round; identical
+                                   * chain; chosen automatically when replicas x 3 work-groups fit the GPU) */
     int32_t groups_per_replica;   /* speculative schedule: work-groups (CUs) cooperating on one replica; 0 = auto
-                                   * (as many of 1, 2, 4 as keeps replicas x groups <= number of CUs) */
+                                   * (as many of 1, 2, 4 as keeps replicas x groups <= number of CUs).  Tree schedule: 3, 7, 15
+                                   * or 31 (0 = auto: the deepest tree up to 15 nodes that is resident) */
     int32_t trace_capacity;       /* rows per replica kept on the device (ring); 0 = all n_samples rows.  With a smaller
                                    * value the caller drains with ptnn_get_traces at least every trace_capacity steps */
     int32_t forward_bf16;         /* wide nets (n_hidden > 64, multiple of 32): 1 = forward-pass GEMM operands rounded to

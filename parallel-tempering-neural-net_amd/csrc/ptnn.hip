@@ -74,6 +74,7 @@ struct ptnn_handle {
     bool speculative = false;
     bool wide = false;              // 64 < H: vectors in HBM, one thread per hidden unit
     bool packed = false;            // H <= 16: packed speculative schedule on one CU
+    bool tree = false;              // prefetching tree schedule: groups = 2^depth - 1 work-groups per replica
     int pk_nred = 3;                // its lane-group width: 2^3 (H <= 8) or 2^4 hidden units
     float* d_wide_scratch = nullptr;
     float* d_xt = nullptr;          // transposed data image for the MFMA forward pass
@@ -150,6 +151,8 @@ struct ptnn_handle {
 
 namespace {
 
+inline int tree_depth(int groups) { int d = 0; while ((1 << (d + 1)) - 1 <= groups) ++d; return d; }   // groups = 2^d - 1
+
 // Q10: REG hands off after step i when i % si == 0 and i != 0 (REG:427); CLS when (i+1) % si == 0 (CLS:438)
 inline bool swap_trigger(const ptnn_config& c, int i) {
     if (c.task == PTNN_TASK_REG) return (i % c.swap_interval == 0) && i != 0;
@@ -174,8 +177,8 @@ int launch_segment(ptnn_handle* h, int begin, int n) {
     const bool timed = h->timing_stride > 0 && (h->launch_count++ % h->timing_stride) == 0;
     if (!timed) {
         const SegParams p = h->seg_params();
-        const int grid = h->cfg.n_replicas_local * ((h->speculative && !h->packed) ? h->groups : 1);
-        hipLaunchKernelGGL(h->wide ? h->shape->seg_wide : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg)),
+        const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree) ? h->groups : 1);
+        hipLaunchKernelGGL(h->wide ? h->shape->seg_wide : (h->tree ? h->shape->tree : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg))),
                            dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
         h->epoch_base += (unsigned)n + 1u;
         HIP_TRY(hipGetLastError());
@@ -195,8 +198,8 @@ int launch_segment(ptnn_handle* h, int begin, int n) {
     auto& ev = h->timing[h->timing_used++];
     const SegParams p = h->seg_params();
     HIP_TRY(hipEventRecord(ev.first, h->stream));
-    const int grid = h->cfg.n_replicas_local * ((h->speculative && !h->packed) ? h->groups : 1);
-    hipLaunchKernelGGL(h->wide ? h->shape->seg_wide : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg)),
+    const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree) ? h->groups : 1);
+    hipLaunchKernelGGL(h->wide ? h->shape->seg_wide : (h->tree ? h->shape->tree : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg))),
                        dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
     h->epoch_base += (unsigned)n + 1u;                    // granule tags never repeat across launches
     HIP_TRY(hipGetLastError());
@@ -457,9 +460,11 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
     int sched = h->cfg.schedule;
     if (sched == PTNN_SCHED_AUTO)
         sched = (h->cfg.task == PTNN_TASK_REG || h->cfg.use_langevin) ? PTNN_SCHED_SPECULATIVE : PTNN_SCHED_COOPERATIVE;
-    if (sched != PTNN_SCHED_COOPERATIVE && sched != PTNN_SCHED_SPECULATIVE && sched != PTNN_SCHED_PACKED)
+    if (sched != PTNN_SCHED_COOPERATIVE && sched != PTNN_SCHED_SPECULATIVE && sched != PTNN_SCHED_PACKED && sched != PTNN_SCHED_TREE)
         return fail(-1, "unknown schedule %d", sched);
-    h->packed = false;
+    if (sched == PTNN_SCHED_TREE && (h->cfg.task != PTNN_TASK_CLS || h->cfg.use_langevin))
+        return fail(-3, "the prefetching tree schedule is built for random-walk classification runs");
+    h->packed = false; h->tree = false;
     {
         // packed speculative: all slots of a round on one CU, the SGD epochs of the slots in the lane groups of two waves:
         // 16 slots in groups of 8 lanes for n_hidden <= 8, 8 slots in groups of 16 lanes for n_hidden <= 16.  Taken
@@ -557,11 +562,57 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         h->fw_mfma = (H >= 24 && I >= 6 && seg_lds + extra <= LDS_MAX);
         if (h->fw_mfma) h->seg_lds = seg_lds + extra;
     }
+    if (sched == PTNN_SCHED_TREE || (sched == PTNN_SCHED_COOPERATIVE && h->cfg.schedule == PTNN_SCHED_AUTO && h->cfg.task == PTNN_TASK_CLS &&
+                                     !h->cfg.use_langevin && h->cfg.groups_per_replica == 0 && h->cfg.waves_per_replica == 0)) {
+        // Prefetching tree: 2^D - 1 work-groups per replica, all of them resident (they wait for each other's records).
+        // Explicit: groups_per_replica = 3, 7, 15 or 31 (0: deepest that fits, up to 15); auto: deepest of 15 / 7 / 3 that fits,
+        // none -> the cooperative schedule stays.
+        const bool explicit_tree = sched == PTNN_SCHED_TREE;
+        const int Rl = h->cfg.n_replicas_local;
+        const int want = h->cfg.groups_per_replica;
+        if (explicit_tree && want != 0 && want != 3 && want != 7 && want != 15 && want != 31)
+            return fail(-1, "tree schedule: groups_per_replica must be 0 (auto), 3, 7, 15 or 31");
+        h->nthreads = (nw ? nw : coop_nw) * 64;
+        const size_t extra = mfma_coop_lds_floats(I, h->cfg.n_out, H, h->Npad) * sizeof(float);
+        const bool coop_mfma = H >= 24 && I >= 6 && lds_floats(Nall, IPY, h->PS, H, h->FWS, false) * sizeof(float) + extra <= LDS_MAX;
+        int chosen = 0;
+        size_t chosen_lds = 0;
+        bool chosen_mfma = false;
+        const void* fn = reinterpret_cast<const void*>(h->shape->tree);
+        for (int G = (explicit_tree && want) ? want : 15; G >= 3; G = (G - 1) / 2) {
+            const int Dp = tree_depth(G);
+            size_t lds = tree_lds_floats(Nall, IPY, h->PS, H, h->FWS, Dp) * sizeof(float);
+            // same forward pass as the cooperative schedule would run (matrix cores or not): a deeper tree that has no room
+            // for the transposed data image is not taken
+            const bool mf = coop_mfma;
+            if (mf) lds += extra;
+            // (the runtime may refuse a dynamic-LDS ceiling just below 160 KiB: such a depth does not fit either)
+            const bool fits = lds <= LDS_MAX && raise_lds_limit(fn, lds) == 0;
+            if (!fits) (void)hipGetLastError();                 // a refused ceiling must not surface at the next launch
+            if (fits) {
+                int per_cu = 0;
+                HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, h->nthreads, lds));
+                if ((long long)Rl * G <= (long long)per_cu * h->num_cus) { chosen = G; chosen_lds = lds; chosen_mfma = mf; h->blocks_per_cu = per_cu; break; }
+            }
+            if (explicit_tree && want) break;
+        }
+        if (chosen) {
+            h->tree = true; h->speculative = false; h->groups = chosen; h->seg_lds = chosen_lds; h->fw_mfma = chosen_mfma;
+            if (h->d_xslots) { HIP_TRY(hipFree(h->d_xslots)); h->d_xslots = nullptr; }
+            const size_t ng = (size_t)Rl * 2 * (TREE_MAX_NODES + 1) * TREE_REC;
+            HIP_TRY(hipMalloc(&h->d_xslots, ng * sizeof(unsigned long long)));
+            HIP_TRY(hipMemset(h->d_xslots, 0, ng * sizeof(unsigned long long)));
+            h->epoch_base = 1;                                  // tag 0 = never written
+        } else if (explicit_tree) {
+            return fail(-3, "tree schedule: %d replicas x %d work-groups of %d threads cannot all be resident on %d CUs (or need more than "
+                            "160 KiB of LDS)", Rl, want ? want : 3, h->nthreads, h->num_cus);
+        }
+    }
     h->Ntr = ntr; h->Nte = nte;
     if (h->d_data) { HIP_TRY(hipFree(h->d_data)); h->d_data = nullptr; }
     HIP_TRY(hipMalloc(&h->d_data, packed.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(h->d_data, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (int rc = raise_lds_limit(reinterpret_cast<const void*>(h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg)),
+    if (int rc = raise_lds_limit(reinterpret_cast<const void*>(h->tree ? h->shape->tree : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg))),
                                  h->seg_lds)) return rc;
     if (int rc = raise_lds_limit(reinterpret_cast<const void*>(h->shape->model), h->model_lds)) return rc;
     h->have_data = true;
@@ -1236,21 +1287,22 @@ int ptnn_tape(ptnn_handle* h, int replica, int step, float* noise, float* scal) 
 int ptnn_describe(ptnn_handle* h, char* buf, int nbytes) {
     if (!h || !buf || nbytes < 1) return fail(-1, "bad argument");
     if (!h->have_data) return fail(-1, "ptnn_set_data has not been called (the schedule depends on the data set)");
-    const char* kern = h->wide ? "segment_wide_kernel" : (h->packed ? "segment_pack_kernel" : (h->speculative ? "segment_spec_kernel" : "segment_kernel"));
-    const void* fn = reinterpret_cast<const void*>(h->wide ? h->shape->seg_wide : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg)));
+    const char* kern = h->wide ? "segment_wide_kernel" : (h->tree ? "segment_tree_kernel" : (h->packed ? "segment_pack_kernel" : (h->speculative ? "segment_spec_kernel" : "segment_kernel")));
+    const void* fn = reinterpret_cast<const void*>(h->wide ? h->shape->seg_wide : (h->tree ? h->shape->tree : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg))));
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, h->nthreads, h->seg_lds));
     hipFuncAttributes fa{};
     HIP_TRY(hipFuncGetAttributes(&fa, fn));
-    const int grid = h->cfg.n_replicas_local * ((h->speculative && !h->packed) ? h->groups : 1);
-    const int slots = h->wide || !h->speculative ? 1 : (h->packed ? pack_slots(h->pk_nred) : h->groups * (h->nthreads / WAVE));
+    const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree) ? h->groups : 1);
+    // tree: the steps committed per round (its depth)
+    const int slots = h->tree ? tree_depth(h->groups) : (h->wide || !h->speculative ? 1 : (h->packed ? pack_slots(h->pk_nred) : h->groups * (h->nthreads / WAVE)));
     const int n = std::snprintf(buf, (size_t)nbytes,
                                 "{\"kernel\": \"ptnn::%s<%d,%d,%d>\", \"schedule\": \"%s\", \"grid_blocks\": %d, \"block_threads\": %d, "
                                 "\"lds_bytes\": %zu, \"groups_per_replica\": %d, \"slots_per_round\": %d, \"num_cus\": %d, "
                                 "\"blocks_per_cu\": %d, \"vgprs\": %d, \"scratch_bytes\": %zu, \"forward_mfma\": %d, \"exchange\": \"%s\"}",
                                 kern, h->cfg.task, h->cfg.n_in, h->cfg.n_out,
-                                h->wide ? "cooperative-wide" : (h->packed ? "packed-speculative" : (h->speculative ? "speculative" : "cooperative")),
+                                h->wide ? "cooperative-wide" : (h->tree ? "prefetching-tree" : (h->packed ? "packed-speculative" : (h->speculative ? "speculative" : "cooperative"))),
                                 grid, h->nthreads, h->seg_lds, h->groups, slots, h->num_cus, per_cu, fa.numRegs, (size_t)fa.localSizeBytes,
                                 (h->fw_mfma || (h->wide && h->cfg.n_hidden % 32 == 0)) ? 1 : 0,
                                 h->comm.kind == COMM_NONE ? "none" : (h->cfg.label_swap ? "labels" : (resolved_xchg_mode(h) == PTNN_XCHG_GATHER ? "gather" : "boundary")));

@@ -2941,6 +2941,267 @@ __global__ void swap_kernel(const SwapParams sp, const int round, const int mode
 #endif  // PTNN_SHAPE_TU
 
 // ------------------------------------------------------------------------------------------------
+// Prefetching ("tree") schedule for random-walk classification chains, where half of the proposals are accepted and
+// speculating on rejections alone gains nothing: G = 2^D - 1 work-groups (one per CU) evaluate, at the same time, the
+// proposals of ALL 2^D - 1 outcomes of the next D accept/reject decisions.  Work-group g is node g + 1 of a binary heap:
+// the root proposes step i from the current state; the left child of a node proposes the next step assuming the node's
+// proposal was rejected (same state), the right child assuming it was accepted (state = the node's proposal).  A random-walk
+// proposal is state + step * noise and the noise of a step depends on the step number only, so a node forms its proposal
+// from the shared state and the tapes of the steps on its path -- the same fused multiply-adds, in the same order, as the
+// sequential chain -- runs the cooperative forward pass on it and publishes ONE record {likelihood, prior, scores}.  Every
+// work-group then reads all records, walks the D decisions (each against the likelihood / prior of the state the walk has
+// reached), and rebuilds the new state locally from the tapes: D steps are committed per round, whatever the decisions,
+// and no vector ever crosses CUs.  Bit-identical to the cooperative schedule at the same block size (tested).
+// Records are 8-byte {tag, value} granules (granule_store / granule_wait), two-deep by round parity: a work-group needs
+// every record of round n before it can publish round n + 1, so nobody is more than one round ahead.
+// ------------------------------------------------------------------------------------------------
+constexpr int TREE_MAX_DEPTH = 5;
+constexpr int TREE_MAX_NODES = 31;
+constexpr int TREE_REC = 8;            // lik_prop, prior_prop, rmse_tr, rmse_te, acc_tr, acc_te, 2 spare
+__host__ __device__ inline size_t tree_lds_floats(int Nall, int IPY, int PS, int H, int FWS, int D) {
+    return (size_t)(Nall + 2) * IPY + 3 * (size_t)PS + (size_t)D * (PS + 8) + fw_floats(H, FWS) + MAX_WAVES * 8 +
+           (size_t)(TREE_MAX_NODES + 1) * TREE_REC;
+}
+
+template <int TASK, int I, int O>
+__global__ void __launch_bounds__(MAX_THREADS) segment_tree_kernel(const SegParams p, const int step_begin, const int n_steps) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int G = p.G;                                     // 2^D - 1
+    const int D = 31 - __clz(G + 1);
+    const int r = blockIdx.x / G, g = blockIdx.x - r * G;
+    const int node = g + 1, depth = 31 - __clz(node);      // heap index, level (root: 0)
+    const int gid = p.first_global + r;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int wave = uni_i(tid >> 6);
+    const int Nall = p.Ntr + p.Nte;
+    const int P = p.P, PS = p.PS, H = p.H;
+    float* xy = smem;
+    float* w_cur = xy + (size_t)(Nall + 2) * p.IPY;
+    float* w_prop = w_cur + PS;
+    float* rec_w = w_prop + PS;
+    float* tapes = rec_w + PS;                             // D x {noise[PS], scal[8]}
+    float* fw = tapes + (size_t)D * (PS + 8);
+    float* red = fw + fw_floats(H, p.FWS);
+    float* recs = red + MAX_WAVES * 8;                     // [nodes][TREE_REC]
+    float* xt_l = smem + tree_lds_floats(Nall, p.IPY, PS, H, p.FWS, D);
+    float* part_l = xt_l + (size_t)I * p.Npad;
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.data);
+        float4* dst = reinterpret_cast<float4*>(xy);
+        for (int e = tid; e < ((Nall + 2) * p.IPY) >> 2; e += nthr) dst[e] = src[e];
+    }
+    float* gw = p.w_state + (size_t)r * PS;
+    for (int j = tid; j < PS; j += nthr) {
+        w_cur[j] = gw[j];
+        rec_w[j] = p.rec_w[(size_t)r * PS + j];
+    }
+    if (p.fw_mfma)
+        for (int e = tid; e < I * p.Npad; e += nthr) xt_l[e] = p.xt[e];
+    __syncthreads();
+
+    const float T = p.temps[r];
+    float eta = 0.0f;                                      // classification: no noise parameter
+    float* sf = p.st_f + (size_t)r * SF_COUNT;
+    int* si = p.st_i + (size_t)r * SI_COUNT;
+    float lik, prior_cur, rec_rmse_tr, rec_rmse_te, rec_acc_tr, rec_acc_te;
+    int nacc;
+    if (step_begin == 0) {                                 // every group of the replica computes the same start-up
+        chain_startup<TASK, I, O>(p, xy, w_cur, fw, red, T, eta, lik, prior_cur);
+        rec_rmse_tr = rec_rmse_te = rec_acc_tr = rec_acc_te = 0.f;
+        nacc = 0;
+        __syncthreads();
+    } else {
+        lik = sf[SF_LIK]; prior_cur = sf[SF_PRIOR];
+        rec_rmse_tr = sf[SF_REC_RMSE_TR]; rec_rmse_te = sf[SF_REC_RMSE_TE];
+        rec_acc_tr = sf[SF_REC_ACC_TR]; rec_acc_te = sf[SF_REC_ACC_TE];
+        nacc = si[SI_NACC];
+    }
+    lik = uni_f(lik); prior_cur = uni_f(prior_cur); nacc = uni_i(nacc);
+    rec_rmse_tr = uni_f(rec_rmse_tr); rec_rmse_te = uni_f(rec_rmse_te); rec_acc_tr = uni_f(rec_acc_tr); rec_acc_te = uni_f(rec_acc_te);
+
+    granule_t* const xrec = reinterpret_cast<granule_t*>(p.xslots) + (size_t)r * 2 * (TREE_MAX_NODES + 1) * TREE_REC;
+    const size_t trow = (size_t)r * p.trace_cap;
+    const int step_end = step_begin + n_steps;
+    const int nq1 = ((P + 3) >> 2) + 1;
+    unsigned epoch = p.epoch_base;
+    int par = 0;
+    bool failed = false;
+    int i = step_begin;
+    while (i < step_end) {
+        // steps of this round: a round never crosses the temperature switch (its re-evaluation opens a round)
+        int dr = min(D, step_end - i);
+        if (p.switch_step > i) dr = min(dr, p.switch_step - i);
+        const float adapttemp = (p.switch_step >= 0 && i >= p.switch_step) ? 1.0f : T;
+        if (i == p.switch_step) {                            // re-evaluate the current w untempered (Q9, REG:322 / CLS)
+            EvalSums sc;
+            float none = 0.0f;
+            if (p.fw_mfma) {
+                sc = eval_rows_mfma_coop<TASK, I, O>(w_cur, xt_l, part_l, xy, p.IPY, H, p.Ntr, Nall, p.Npad, red, none);
+            } else {
+                build_fw<I, O>(w_cur, fw, H, p.FWS);
+                __syncthreads();
+                sc = eval_rows<TASK, I, O>(fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, red);
+            }
+            lik = uni_f(finish_loglik<TASK>(sc, p.Ntr, eta));
+            __syncthreads();
+        }
+        // 1. the random tapes of the dr steps (tape_step's body, flattened over (step, counter quad))
+        for (int e = tid; e < dr * nq1; e += nthr) {
+            const int l = e / nq1, q = e - l * nq1;
+            const bool sc = (q == nq1 - 1);
+            float* tp = tapes + (size_t)l * (PS + 8);
+            uint32_t x[4];
+            philox4x32_10(sc ? 0u : (uint32_t)q, (uint32_t)(i + l), p.noise_shared ? 0u : (uint32_t)gid, sc ? STREAM_STEP : STREAM_WNOISE,
+                          p.seed_lo, p.seed_hi, x);
+            float n0, n1, n2, n3;
+            box_muller(x[0], x[1], n0, n1);
+            box_muller(x[2], x[3], n2, n3);
+            if (sc) { tp[PS] = u23(x[0]); tp[PS + 1] = u23(x[1]); tp[PS + 2] = n2; }
+            else *reinterpret_cast<float4*>(tp + 4 * q) = make_float4(n0, n1, n2, n3);
+        }
+        __syncthreads();
+        // 2. this node's proposal: the state after the accepted ancestors on its path, plus its own step
+        const bool active = depth < dr;
+        auto path_value = [&](int idx) {
+            float v = w_cur[idx];
+            for (int l = 0; l < depth; ++l)
+                if ((node >> (depth - l - 1)) & 1) v = fmaf(p.step_w, tapes[(size_t)l * (PS + 8) + idx], v);
+            return fmaf(p.step_w, tapes[(size_t)depth * (PS + 8) + idx], v);
+        };
+        if (active) {
+            if (p.fw_mfma) {
+                for (int j = tid; j < P; j += nthr) w_prop[j] = path_value(j);
+            } else {
+                const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
+                constexpr int K = I + 1 + O;
+                const bool pairs = FwLayout<I>::pairs(H);
+                const int HR = pairs ? 2 * fw_pairs(H) : H;
+                for (int e = tid; e < HR * K; e += nthr) {
+                    const int h = e / K, c = e - h * K;
+                    float v = 0.0f;
+                    if (h < H) {
+                        const int idx = (c < I) ? c * H + h : (c == I) ? oB1 + h : oW2 + h * O + (c - I - 1);
+                        v = path_value(idx);
+                        w_prop[idx] = v;
+                    }
+                    fw[pairs ? (h >> 1) * 2 * p.FWS + 2 * c + (h & 1) : h * p.FWS + c] = v;
+                }
+                if (tid < O) {
+                    const float v = path_value(oB2 + tid);
+                    w_prop[oB2 + tid] = v;
+                    fw[HR * p.FWS + tid] = v;
+                }
+            }
+        }
+        __syncthreads();
+        // 3. forward pass of the node's proposal (the cooperative kernel's phase B)
+        float rv[TREE_REC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (active) {
+            float ssq = 0.0f;
+            for (int j = tid; j < P; j += nthr) ssq = fmaf(w_prop[j], w_prop[j], ssq);
+            EvalSums es;
+            if (p.fw_mfma) es = eval_rows_mfma_coop<TASK, I, O, true>(w_prop, xt_l, part_l, xy, p.IPY, H, p.Ntr, Nall, p.Npad, red, ssq);
+            else es = eval_rows<TASK, I, O, false, true>(fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, red, ssq);
+            rv[0] = finish_loglik<TASK>(es, p.Ntr, eta) / adapttemp;
+            rv[1] = prior_value<TASK>(p, ssq, eta);
+            finish_scores<TASK>(es, p.Ntr, p.Nte, rv[2], rv[3], rv[4], rv[5]);
+        }
+        // 4. publish the record (idle nodes publish their tag too: everybody waits for everybody, which keeps the groups
+        //    within one round of each other)
+        granule_t* const xr = xrec + (size_t)par * (TREE_MAX_NODES + 1) * TREE_REC;
+        if (tid < TREE_REC) {
+            float v = rv[0];
+#pragma unroll
+            for (int f = 1; f < TREE_REC; ++f) v = (tid == f) ? rv[f] : v;
+            granule_store(xr + (size_t)g * TREE_REC + tid, epoch, v);
+        }
+        // 5. all records of the round
+        bool ok = true;
+        for (int q = tid; q < G * TREE_REC; q += nthr) {
+            float v = 0.0f;
+            ok = granule_wait(xr + q, epoch, v) && ok;
+            recs[q] = v;
+        }
+        if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
+        // 6. the dr decisions, by every thread alike: each against the likelihood / prior of the state the walk has reached
+        unsigned accmask = 0, my_mask = 0;
+        int my_acc_before = 0;
+        float my_likprop = 0.f, my_logalpha = 0.f, my_s0 = 0.f, my_s1 = 0.f, my_s2 = 0.f, my_s3 = 0.f;
+        int nd = 1;
+        for (int l = 0; l < dr; ++l) {
+            const float* rc = recs + (size_t)(nd - 1) * TREE_REC;
+            const float u = tapes[(size_t)l * (PS + 8) + PS + 1];
+            const float lik_prop = rc[0], prior_prop = rc[1];
+            // R9 Metropolis-Hastings (REG:372-423): NaN -> accept (Q8), overflow -> 1; random walk: no proposal ratio
+            const float logalpha = (lik_prop - lik) + (prior_prop - prior_cur) + 0.0f;
+            const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
+            const bool accept = uni_i((u < mh) ? 1 : 0) != 0;
+            const int acc_before = nacc;
+            if (accept) {
+                nacc += 1;
+                lik = uni_f(lik_prop); prior_cur = uni_f(prior_prop);
+                rec_rmse_tr = uni_f(rc[2]); rec_rmse_te = uni_f(rc[3]); rec_acc_tr = uni_f(rc[4]); rec_acc_te = uni_f(rc[5]);
+                accmask |= 1u << l;
+            }
+            if (l == g) {                                    // group l writes the trace row of step i + l
+                my_mask = accmask; my_acc_before = acc_before; my_likprop = lik_prop; my_logalpha = logalpha;
+                my_s0 = rec_rmse_tr; my_s1 = rec_rmse_te; my_s2 = rec_acc_tr; my_s3 = rec_acc_te;
+            }
+            nd = 2 * nd + (accept ? 1 : 0);
+        }
+        // 7. the new state, rebuilt from the tapes, and the trace rows (row of step i + l: the recorded vector after that
+        //    step's decision = the state after it if anything was accepted up to there, else the old recorded vector)
+        const bool write_row = g < dr;
+        float* prow = nullptr;
+        if (write_row) {
+            const size_t tpos = trow + (size_t)((i + g + 1) % p.trace_cap);
+            prow = p.tr_pos_w + tpos * (size_t)p.PW;
+            if (tid == 0)
+                store_trace_row(p.tr_scal + tpos * TR_COUNT, (TASK == TASK_REG) ? my_likprop : my_likprop * adapttemp, my_s0, my_s1, my_s2,
+                                my_s3, my_acc_before, my_logalpha);
+        }
+        for (int j = tid; j < p.PW; j += nthr) {
+            float rowv = 0.0f;
+            if (j < P) {
+                float v = w_cur[j];
+                float vrow = v;
+                for (int l = 0; l < dr; ++l) {
+                    if ((accmask >> l) & 1u) v = fmaf(p.step_w, tapes[(size_t)l * (PS + 8) + j], v);
+                    if (l == g) vrow = v;
+                }
+                rowv = my_mask ? vrow : rec_w[j];
+                if (accmask) { w_cur[j] = v; rec_w[j] = v; }
+            }
+            if (write_row) prow[j] = rowv;
+        }
+        __syncthreads();                                    // the next round's tapes and proposals read what was just written
+        i += dr;
+        epoch += 1;
+        par ^= 1;
+    }
+    if (failed) {
+        if (tid == 0) atomicAdd(p.error_flag, 1);           // a bounded spin ran out: the host reports it
+        return;
+    }
+    if (g == 0) {
+        for (int j = tid; j < PS; j += nthr) {
+            gw[j] = (j == P) ? eta : w_cur[j];
+            p.rec_w[(size_t)r * PS + j] = rec_w[j];
+        }
+        if (tid == 0) {
+            sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur;
+            sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;
+            sf[SF_REC_ACC_TR] = rec_acc_tr; sf[SF_REC_ACC_TE] = rec_acc_te;
+            si[SI_NACC] = nacc;
+            if (step_begin == 0) { sf[SF_TAU_LAST] = eta; si[SI_LG_COUNT] = 0; p.gd_valid[r] = 0; }   // what the other schedules leave
+            p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;      // Q11
+            p.L_final[gid] = lik;
+            post_raw(p, gid, lik, prior_cur, T, step_begin + n_steps - 1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // stand-alone model functions (same device code): mode 0 = evaluate, 1 = langevin_gradient, 2 = tape
 // ------------------------------------------------------------------------------------------------
 template <int TASK, int I, int O>

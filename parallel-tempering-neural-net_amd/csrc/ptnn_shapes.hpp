@@ -24,5 +24,6 @@ struct Shape {
     seg_fn seg_wide;        // 64 < H <= 512
     model_fn model_wide;
     seg_fn pack;            // H <= 8: packed speculative schedule
+    seg_fn tree;            // prefetching tree schedule (random-walk classification), H <= 64
 };
 }  // namespace ptnn
