@@ -75,6 +75,7 @@ struct ptnn_handle {
     bool wide = false;              // 64 < H: vectors in HBM, one thread per hidden unit
     bool packed = false;            // H <= 16: packed speculative schedule on one CU
     bool tree = false;              // prefetching tree schedule: groups = 2^depth - 1 work-groups per replica
+    bool tree_ahead = false;        // ... with room in LDS for two sets of tapes
     int pk_nred = 3;                // its lane-group width: 2^3 (H <= 8) or 2^4 hidden units
     float* d_wide_scratch = nullptr;
     float* d_xt = nullptr;          // transposed data image for the MFMA forward pass
@@ -144,7 +145,7 @@ struct ptnn_handle {
         p.L_handoff = d_L_handoff; p.L_final = d_L_final;
         p.L_raw = (cfg.swap_rule == 1) ? d_L_raw : nullptr; p.prior_post = d_prior_post;
         p.tr_pos_w = d_pos_w; p.tr_scal = d_scal; p.PW = PW;
-        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.xverdict = d_xverdict; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.noise_shared = cfg.shared_noise ? 1 : 0; p.pk_nred = pk_nred; p.xt = d_xt; p.Npad = Npad; p.fw_mfma = fw_mfma ? 1 : 0; p.forward_bf16 = cfg.forward_bf16;
+        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.xverdict = d_xverdict; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.noise_shared = cfg.shared_noise ? 1 : 0; p.pk_nred = pk_nred; p.xt = d_xt; p.Npad = Npad; p.fw_mfma = fw_mfma ? 1 : 0; p.forward_bf16 = cfg.forward_bf16; p.tree_ahead = tree_ahead ? 1 : 0;
         return p;
     }
 };
@@ -581,7 +582,10 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         const void* fn = reinterpret_cast<const void*>(h->shape->tree);
         for (int G = (explicit_tree && want) ? want : 15; G >= 3; G = (G - 1) / 2) {
             const int Dp = tree_depth(G);
-            size_t lds = tree_lds_floats(Nall, IPY, h->PS, H, h->FWS, Dp) * sizeof(float);
+            // two sets of tapes (the next round's drawn while the records travel) when they fit
+            const size_t ceiling = 152 * 1024;                  // dynamic-LDS ceilings just below 160 KiB are refused by the runtime
+            bool ah = tree_lds_floats(Nall, IPY, h->PS, H, h->FWS, Dp, true, coop_mfma) * sizeof(float) + (coop_mfma ? extra : 0) <= ceiling;
+            size_t lds = tree_lds_floats(Nall, IPY, h->PS, H, h->FWS, Dp, ah, coop_mfma) * sizeof(float);
             // same forward pass as the cooperative schedule would run (matrix cores or not): a deeper tree that has no room
             // for the transposed data image is not taken
             const bool mf = coop_mfma;
@@ -592,7 +596,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
             if (fits) {
                 int per_cu = 0;
                 HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, h->nthreads, lds));
-                if ((long long)Rl * G <= (long long)per_cu * h->num_cus) { chosen = G; chosen_lds = lds; chosen_mfma = mf; h->blocks_per_cu = per_cu; break; }
+                if ((long long)Rl * G <= (long long)per_cu * h->num_cus) { chosen = G; chosen_lds = lds; chosen_mfma = mf; h->tree_ahead = ah; h->blocks_per_cu = per_cu; break; }
             }
             if (explicit_tree && want) break;
         }

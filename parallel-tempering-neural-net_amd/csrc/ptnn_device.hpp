@@ -73,6 +73,7 @@ struct SegParams {
     // speculative schedule across G work-groups (CUs) per replica
     int G;                   // work-groups per replica (1 = no cross-CU exchange)
     unsigned epoch_base;     // granule tags of this launch are epoch_base + round
+    int tree_ahead;          // tree schedule: LDS holds two sets of tapes, the next round's are drawn while the records travel
     unsigned long long* xverdict; // [Rl][2][MAX_SLOTS] one {tag, accepted?} granule per slot and round: all a foreign group polls
     unsigned long long* xslots;   // [Rl][2][MAX_SLOTS][16] result granules of an ACCEPTED slot (read by the other groups at commit)
     unsigned long long* xw;       // [Rl][2][MAX_SLOTS][2 PS] accepted-proposal granules
@@ -2958,9 +2959,12 @@ __global__ void swap_kernel(const SwapParams sp, const int round, const int mode
 constexpr int TREE_MAX_DEPTH = 5;
 constexpr int TREE_MAX_NODES = 31;
 constexpr int TREE_REC = 8;            // lik_prop, prior_prop, rmse_tr, rmse_te, acc_tr, acc_te, 2 spare
-__host__ __device__ inline size_t tree_lds_floats(int Nall, int IPY, int PS, int H, int FWS, int D) {
-    return (size_t)(Nall + 2) * IPY + 3 * (size_t)PS + (size_t)D * (PS + 8) + fw_floats(H, FWS) + MAX_WAVES * 8 +
-           (size_t)(TREE_MAX_NODES + 1) * TREE_REC;
+// mfma: the forward pass reads the transposed data image (behind this block), so only the labels of the row-major image are kept
+__host__ __device__ inline size_t tree_lds_floats(int Nall, int IPY, int PS, int H, int FWS, int D, bool ahead, bool mfma) {
+    size_t tapes = (size_t)(ahead ? 2 : 1) * D * (PS + 8);
+    if (mfma && tapes < fw_floats(H, FWS)) tapes = fw_floats(H, FWS);      // the start-up builds its forward image there
+    return (mfma ? (size_t)((Nall + 3) & ~3) : (size_t)(Nall + 2) * IPY) + 3 * (size_t)PS + tapes + (mfma ? 0 : fw_floats(H, FWS)) +
+           MAX_WAVES * 8 + (size_t)(TREE_MAX_NODES + 1) * TREE_REC;
 }
 
 template <int TASK, int I, int O>
@@ -2975,17 +2979,26 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_tree_kernel(const SegPara
     const int wave = uni_i(tid >> 6);
     const int Nall = p.Ntr + p.Nte;
     const int P = p.P, PS = p.PS, H = p.H;
-    float* xy = smem;
-    float* w_cur = xy + (size_t)(Nall + 2) * p.IPY;
+    const bool mfma = p.fw_mfma != 0;
+    float* xy = smem;                                      // row-major data image, or (matrix-core forward) just its labels
+    float* w_cur = xy + (mfma ? (size_t)((Nall + 3) & ~3) : (size_t)(Nall + 2) * p.IPY);
     float* w_prop = w_cur + PS;
     float* rec_w = w_prop + PS;
-    float* tapes = rec_w + PS;                             // D x {noise[PS], scal[8]}
-    float* fw = tapes + (size_t)D * (PS + 8);
-    float* red = fw + fw_floats(H, p.FWS);
+    float* const tapes0 = rec_w + PS;                      // D x {noise[PS], scal[8]}, twice when the tapes are drawn ahead
+    const bool ahead = p.tree_ahead != 0;
+    size_t tape_floats = (size_t)(ahead ? 2 : 1) * D * (PS + 8);
+    if (mfma && tape_floats < fw_floats(H, p.FWS)) tape_floats = fw_floats(H, p.FWS);
+    float* fw = tapes0 + tape_floats;
+    float* red = fw + (mfma ? 0 : fw_floats(H, p.FWS));
     float* recs = red + MAX_WAVES * 8;                     // [nodes][TREE_REC]
-    float* xt_l = smem + tree_lds_floats(Nall, p.IPY, PS, H, p.FWS, D);
+    float* xt_l = smem + tree_lds_floats(Nall, p.IPY, PS, H, p.FWS, D, ahead, mfma);
     float* part_l = xt_l + (size_t)I * p.Npad;
-    {
+    // what the scoring reads as xy[n * stride + I]
+    const float* const ysrc = mfma ? xy - I : xy;
+    const int ystride = mfma ? 1 : p.IPY;
+    if (mfma) {
+        for (int n = tid; n < Nall; n += nthr) xy[n] = p.data[(size_t)n * p.IPY + I];
+    } else {
         const float4* src = reinterpret_cast<const float4*>(p.data);
         float4* dst = reinterpret_cast<float4*>(xy);
         for (int e = tid; e < ((Nall + 2) * p.IPY) >> 2; e += nthr) dst[e] = src[e];
@@ -3006,7 +3019,9 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_tree_kernel(const SegPara
     float lik, prior_cur, rec_rmse_tr, rec_rmse_te, rec_acc_tr, rec_acc_te;
     int nacc;
     if (step_begin == 0) {                                 // every group of the replica computes the same start-up
-        chain_startup<TASK, I, O>(p, xy, w_cur, fw, red, T, eta, lik, prior_cur);
+        // matrix-core mode keeps neither the row-major image nor the packed forward image in LDS: the one-off start-up reads
+        // the image from global memory and builds its forward image in the (still unused) tape area
+        chain_startup<TASK, I, O>(p, mfma ? p.data : xy, w_cur, mfma ? tapes0 : fw, red, T, eta, lik, prior_cur);
         rec_rmse_tr = rec_rmse_te = rec_acc_tr = rec_acc_te = 0.f;
         nacc = 0;
         __syncthreads();
@@ -3027,16 +3042,39 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_tree_kernel(const SegPara
     int par = 0;
     bool failed = false;
     int i = step_begin;
+    // steps of the round that starts at step `first`: a round never crosses the temperature switch (its re-evaluation opens one)
+    auto round_steps = [&](int first) {
+        int n = min(D, step_end - first);
+        if (p.switch_step > first) n = min(n, p.switch_step - first);
+        return n;
+    };
+    // the random tapes of `count` steps from `first` (tape_step's body, flattened over (step, counter quad))
+    auto draw_tapes = [&](float* base, int first, int count) {
+        for (int e = tid; e < count * nq1; e += nthr) {
+            const int l = e / nq1, q = e - l * nq1;
+            const bool sc = (q == nq1 - 1);
+            float* tp = base + (size_t)l * (PS + 8);
+            uint32_t x[4];
+            philox4x32_10(sc ? 0u : (uint32_t)q, (uint32_t)(first + l), p.noise_shared ? 0u : (uint32_t)gid, sc ? STREAM_STEP : STREAM_WNOISE,
+                          p.seed_lo, p.seed_hi, x);
+            float n0, n1, n2, n3;
+            box_muller(x[0], x[1], n0, n1);
+            box_muller(x[2], x[3], n2, n3);
+            if (sc) { tp[PS] = u23(x[0]); tp[PS + 1] = u23(x[1]); tp[PS + 2] = n2; }
+            else *reinterpret_cast<float4*>(tp + 4 * q) = make_float4(n0, n1, n2, n3);
+        }
+    };
+    int tpar = 0;
+    if (ahead && i < step_end) { draw_tapes(tapes0, i, round_steps(i)); __syncthreads(); }
     while (i < step_end) {
-        // steps of this round: a round never crosses the temperature switch (its re-evaluation opens a round)
-        int dr = min(D, step_end - i);
-        if (p.switch_step > i) dr = min(dr, p.switch_step - i);
+        const int dr = round_steps(i);
+        float* const tapes = tapes0 + (size_t)tpar * D * (PS + 8);
         const float adapttemp = (p.switch_step >= 0 && i >= p.switch_step) ? 1.0f : T;
         if (i == p.switch_step) {                            // re-evaluate the current w untempered (Q9, REG:322 / CLS)
             EvalSums sc;
             float none = 0.0f;
             if (p.fw_mfma) {
-                sc = eval_rows_mfma_coop<TASK, I, O>(w_cur, xt_l, part_l, xy, p.IPY, H, p.Ntr, Nall, p.Npad, red, none);
+                sc = eval_rows_mfma_coop<TASK, I, O>(w_cur, xt_l, part_l, ysrc, ystride, H, p.Ntr, Nall, p.Npad, red, none);
             } else {
                 build_fw<I, O>(w_cur, fw, H, p.FWS);
                 __syncthreads();
@@ -3045,21 +3083,8 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_tree_kernel(const SegPara
             lik = uni_f(finish_loglik<TASK>(sc, p.Ntr, eta));
             __syncthreads();
         }
-        // 1. the random tapes of the dr steps (tape_step's body, flattened over (step, counter quad))
-        for (int e = tid; e < dr * nq1; e += nthr) {
-            const int l = e / nq1, q = e - l * nq1;
-            const bool sc = (q == nq1 - 1);
-            float* tp = tapes + (size_t)l * (PS + 8);
-            uint32_t x[4];
-            philox4x32_10(sc ? 0u : (uint32_t)q, (uint32_t)(i + l), p.noise_shared ? 0u : (uint32_t)gid, sc ? STREAM_STEP : STREAM_WNOISE,
-                          p.seed_lo, p.seed_hi, x);
-            float n0, n1, n2, n3;
-            box_muller(x[0], x[1], n0, n1);
-            box_muller(x[2], x[3], n2, n3);
-            if (sc) { tp[PS] = u23(x[0]); tp[PS + 1] = u23(x[1]); tp[PS + 2] = n2; }
-            else *reinterpret_cast<float4*>(tp + 4 * q) = make_float4(n0, n1, n2, n3);
-        }
-        __syncthreads();
+        // 1. the random tapes of the dr steps (drawn during the previous round's exchange when LDS has room for two sets)
+        if (!ahead) { draw_tapes(tapes, i, dr); __syncthreads(); }
         // 2. this node's proposal: the state after the accepted ancestors on its path, plus its own step
         const bool active = depth < dr;
         auto path_value = [&](int idx) {
@@ -3100,7 +3125,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_tree_kernel(const SegPara
             float ssq = 0.0f;
             for (int j = tid; j < P; j += nthr) ssq = fmaf(w_prop[j], w_prop[j], ssq);
             EvalSums es;
-            if (p.fw_mfma) es = eval_rows_mfma_coop<TASK, I, O, true>(w_prop, xt_l, part_l, xy, p.IPY, H, p.Ntr, Nall, p.Npad, red, ssq);
+            if (p.fw_mfma) es = eval_rows_mfma_coop<TASK, I, O, true>(w_prop, xt_l, part_l, ysrc, ystride, H, p.Ntr, Nall, p.Npad, red, ssq);
             else es = eval_rows<TASK, I, O, false, true>(fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, red, ssq);
             rv[0] = finish_loglik<TASK>(es, p.Ntr, eta) / adapttemp;
             rv[1] = prior_value<TASK>(p, ssq, eta);
@@ -3115,6 +3140,8 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_tree_kernel(const SegPara
             for (int f = 1; f < TREE_REC; ++f) v = (tid == f) ? rv[f] : v;
             granule_store(xr + (size_t)g * TREE_REC + tid, epoch, v);
         }
+        // ... and while the records travel, the tapes of the next round (they depend on step numbers only)
+        if (ahead && i + dr < step_end) draw_tapes(tapes0 + (size_t)(tpar ^ 1) * D * (PS + 8), i + dr, round_steps(i + dr));
         // 5. all records of the round
         bool ok = true;
         for (int q = tid; q < G * TREE_REC; q += nthr) {
@@ -3178,6 +3205,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_tree_kernel(const SegPara
         i += dr;
         epoch += 1;
         par ^= 1;
+        if (ahead) tpar ^= 1;
     }
     if (failed) {
         if (tid == 0) atomicAdd(p.error_flag, 1);           // a bounded spin ran out: the host reports it

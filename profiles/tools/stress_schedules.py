@@ -57,6 +57,10 @@ def run(seed=0, ncase=30, verbose=True, shapes="timeseries+iris", oracle=False):
           variants.append(dict(schedule=1, waves=1))
       if H <= 64:
           variants += [dict(schedule=1, waves=4), dict(schedule=1, waves=2), dict(schedule=0)]
+      if task == 1 and not lg and H <= 64:            # prefetching tree: random-walk classification only
+          if H < 24 or I < 6:
+              variants += [dict(schedule=4, waves=1, groups=3), dict(schedule=4, waves=1, groups=15)]   # one wave: bit-identical
+          variants.append(dict(schedule=4, groups=7))                                                 # default block: round-off
       ref = None
       for v in variants:
           try:
@@ -127,7 +131,7 @@ def run(seed=0, ncase=30, verbose=True, shapes="timeseries+iris", oracle=False):
                               print("   r", r, "la-lu", np.round(o.logalpha[r, :n_] - o.logu[r, :n_], 3).tolist(), flush=True)
                       print(f"ORACLE MISMATCH case {case}: task={task} {name} topo={topo} ntr={ntr} nte={nte} R={R} S={S} si={si} lg={lg} seed={seed}: {str(e)[:300]}", flush=True)
               continue
-          loose = v.get("schedule") in (0, 1) and (v.get("waves", 0) != 1 or (H >= 24 and I >= 6))
+          loose = v.get("schedule") in (0, 1, 4) and (v.get("waves", 0) != 1 or (H >= 24 and I >= 6))
           if loose:
               same_dec = np.array_equal(got[0]["accept"], ref[0]["accept"])
               ok = (not same_dec) or (got[1] == ref[1] and np.array_equal(got[2], ref[2]) and

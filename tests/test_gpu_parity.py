@@ -746,6 +746,75 @@ def test_random_configurations_commit_the_same_chain_under_every_schedule():
     assert mod.run(seed=7, ncase=14, verbose=False, shapes="all", oracle=True) == 0
 
 
+TREE_CASES = [("iris", (4, 12, 3), 6, 60, 10, 3), ("iris", (4, 12, 3), 6, 60, 10, 7), ("iris", (4, 12, 3), 4, 100, 7, 15),
+              ("iris", (4, 5, 3), 3, 50, 10, 31), ("ions", (34, 50, 2), 4, 40, 10, 3), ("ions", (34, 50, 2), 4, 50, 10, 7),
+              ("ions", (34, 50, 2), 2, 120, 40, 15), ("ions", (34, 20, 2), 5, 64, 8, 15), ("iris", (4, 12, 3), 8, 25, 5, 31),
+              ("iris", (4, 12, 3), 16, 300, 100, 0)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,topo,R,S,si,G", TREE_CASES, ids=[f"{c[0]}-H{c[1][1]}-R{c[2]}-S{c[3]}-si{c[4]}-G{c[5]}" for c in TREE_CASES])
+def test_prefetching_tree_commits_the_cooperative_chain(name, topo, R, S, si, G):
+    """The prefetching tree schedule (2^D - 1 work-groups per replica evaluate every outcome of the next D decisions; D steps
+    per round) must commit the cooperative schedule's chain bit for bit: traces, swap statistics, swap log and final state, for
+    every depth (3 .. 31 work-groups, auto), with and without the matrix-core forward pass (Ionosphere 34-50-2 takes it),
+    across swap rounds, the temperature switch (S = 50, 60, 100, 120, 300: 0.6 S is integral) and interval ends that cut a round
+    short."""
+    d = np.load(os.path.join(parity.ROOT, "tests", "golden", "datasets.npz"))
+    train, test = d[name + "_train"], d[name + "_test"]
+    from ptnn_amd import ladder, philox
+    P = topo[0] * topo[1] + topo[1] * topo[2] + topo[1] + topo[2]
+    w0 = np.stack([philox.initial_weights(5, r, P) for r in range(R)])
+    T = ladder.temperatures(R, 10)
+    out = []
+    for sched, groups in ((1, 0), (4, G)):
+        s = parity.make_sampler(1, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=False, lr=0.01, seed=11,
+                                schedule=sched, groups=groups)
+        s.set_state(w0, T); s.run(-1); s.sync()
+        out.append((s.traces(), s.swap_stats(), s.swap_log().copy(), s.state(), s.describe()))
+        s.close()
+    (tr_c, st_c, log_c, state_c, _), (tr_t, st_t, log_t, state_t, desc) = out
+    assert desc["schedule"] == "prefetching-tree" and desc["slots_per_round"] >= 2
+    if G:
+        assert desc["groups_per_replica"] == G
+    assert st_c == st_t and np.array_equal(log_c, log_t)
+    for k in tr_c:
+        assert np.array_equal(tr_c[k], tr_t[k], equal_nan=True), k
+    for k in state_c:
+        assert np.array_equal(state_c[k], state_t[k], equal_nan=True), k
+
+
+@pytest.mark.gpu
+def test_prefetching_tree_refusals_and_auto_choice():
+    """The tree schedule is for random-walk classification runs whose 2^D - 1 work-groups per replica are all resident: a
+    regression run, a Langevin run, a group count that is not 2^D - 1 and a ladder that cannot be resident are configuration
+    errors (never a spin); schedule 0 takes the deepest tree up to 15 work-groups that is resident and keeps the cooperative
+    schedule otherwise."""
+    from ptnn_amd import _lib
+    d = np.load(os.path.join(parity.ROOT, "tests", "golden", "datasets.npz"))
+    iris = (d["iris_train"], d["iris_test"])
+    sun = (d["sunspot_train"], d["sunspot_test"])
+    with pytest.raises(_lib.PtnnError, match="random-walk classification"):
+        parity.make_sampler(0, (4, 5, 1), *sun, R_local=4, R_global=4, first=0, S=30, si=10, use_lg=False, lr=0.1, seed=1, schedule=4)
+    with pytest.raises(_lib.PtnnError, match="random-walk classification"):
+        parity.make_sampler(1, (4, 12, 3), *iris, R_local=4, R_global=4, first=0, S=30, si=10, use_lg=True, lr=0.01, seed=1, schedule=4)
+    with pytest.raises(_lib.PtnnError, match="3, 7, 15 or 31"):
+        parity.make_sampler(1, (4, 12, 3), *iris, R_local=4, R_global=4, first=0, S=30, si=10, use_lg=False, lr=0.01, seed=1, schedule=4, groups=4)
+    with pytest.raises(_lib.PtnnError, match="resident"):
+        parity.make_sampler(1, (4, 12, 3), *iris, R_local=128, R_global=128, first=0, S=30, si=10, use_lg=False, lr=0.01, seed=1, schedule=4, groups=31)
+    for R, want in ((4, 15), (16, 15), (32, 7), (64, 3)):
+        s = parity.make_sampler(1, (4, 12, 3), *iris, R_local=R, R_global=R, first=0, S=30, si=10, use_lg=False, lr=0.01, seed=1)
+        desc = s.describe()
+        s.close()
+        cap = desc["num_cus"] * desc["blocks_per_cu"]
+        assert desc["schedule"] == "prefetching-tree" and desc["groups_per_replica"] * R <= cap, desc
+        assert desc["groups_per_replica"] >= want, desc          # two work-groups per CU may allow a deeper tree than CUs alone
+    s = parity.make_sampler(1, (4, 12, 3), *iris, R_local=1024, R_global=1024, first=0, S=30, si=10, use_lg=False, lr=0.01, seed=1)
+    desc = s.describe()
+    s.close()
+    assert desc["schedule"] == "cooperative", desc
+
+
 @pytest.mark.gpu
 def test_sharded_ladder_two_ranks_on_one_gpu():
     """ptnn_run on a sharded ladder with a REAL cross-process exchange on real device buffers: two processes share the one GPU
