@@ -2958,7 +2958,8 @@ __global__ void swap_kernel(const SwapParams sp, const int round, const int mode
 // ------------------------------------------------------------------------------------------------
 constexpr int TREE_MAX_DEPTH = 5;
 constexpr int TREE_MAX_NODES = 31;
-constexpr int TREE_REC = 8;            // lik_prop, prior_prop, rmse_tr, rmse_te, acc_tr, acc_te, 2 spare
+constexpr int TREE_REC = 8;            // row stride of a record
+constexpr int TREE_FIELDS = 6;         // lik_prop, prior_prop, rmse_tr, rmse_te, acc_tr, acc_te: what is published and polled
 // mfma: the forward pass reads the transposed data image (behind this block), so only the labels of the row-major image are kept
 __host__ __device__ inline size_t tree_lds_floats(int Nall, int IPY, int PS, int H, int FWS, int D, bool ahead, bool mfma) {
     size_t tapes = (size_t)(ahead ? 2 : 1) * D * (PS + 8);
@@ -3120,7 +3121,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_tree_kernel(const SegPara
         }
         __syncthreads();
         // 3. forward pass of the node's proposal (the cooperative kernel's phase B)
-        float rv[TREE_REC] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float rv[TREE_FIELDS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (active) {
             float ssq = 0.0f;
             for (int j = tid; j < P; j += nthr) ssq = fmaf(w_prop[j], w_prop[j], ssq);
@@ -3134,20 +3135,21 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_tree_kernel(const SegPara
         // 4. publish the record (idle nodes publish their tag too: everybody waits for everybody, which keeps the groups
         //    within one round of each other)
         granule_t* const xr = xrec + (size_t)par * (TREE_MAX_NODES + 1) * TREE_REC;
-        if (tid < TREE_REC) {
+        if (tid < TREE_FIELDS) {
             float v = rv[0];
 #pragma unroll
-            for (int f = 1; f < TREE_REC; ++f) v = (tid == f) ? rv[f] : v;
+            for (int f = 1; f < TREE_FIELDS; ++f) v = (tid == f) ? rv[f] : v;
             granule_store(xr + (size_t)g * TREE_REC + tid, epoch, v);
         }
         // ... and while the records travel, the tapes of the next round (they depend on step numbers only)
         if (ahead && i + dr < step_end) draw_tapes(tapes0 + (size_t)(tpar ^ 1) * D * (PS + 8), i + dr, round_steps(i + dr));
         // 5. all records of the round
         bool ok = true;
-        for (int q = tid; q < G * TREE_REC; q += nthr) {
+        for (int q = tid; q < G * TREE_FIELDS; q += nthr) {
+            const int nd_ = q / TREE_FIELDS, f_ = q - nd_ * TREE_FIELDS;
             float v = 0.0f;
-            ok = granule_wait(xr + q, epoch, v) && ok;
-            recs[q] = v;
+            ok = granule_wait(xr + (size_t)nd_ * TREE_REC + f_, epoch, v) && ok;
+            recs[nd_ * TREE_REC + f_] = v;
         }
         if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
         // 6. the dr decisions, by every thread alike: each against the likelihood / prior of the state the walk has reached

@@ -92,7 +92,7 @@ class ParallelTemperingBase:
         self.exchange = {"auto": _lib.XCHG_AUTO, "gather": _lib.XCHG_GATHER, "boundary": _lib.XCHG_BOUNDARY}[exchange]
         self.transport = transport
         self.waves_per_replica = int(waves_per_replica)
-        self.schedule = int(schedule)            # 0 auto, 1 cooperative, 2 speculative (include/ptnn.h)
+        self.schedule = int(schedule)            # 0 auto, 1 cooperative, 2 speculative, 3 packed, 4 prefetching tree (include/ptnn.h)
         self.groups_per_replica = int(groups_per_replica)
         self.swap_rule = int(swap_rule)          # 0 = the reference's cascade; 1 = even/odd Metropolis exchange (not in the reference)
         self.shared_noise = bool(shared_noise)   # True: all chains read one noise tape, as the reference's forked chains do (Q14)
