@@ -816,6 +816,58 @@ def test_prefetching_tree_refusals_and_auto_choice():
 
 
 @pytest.mark.gpu
+def test_prefetching_tree_streams_and_resumes():
+    """The tree schedule under the run-time features of the boundary: a trace ring drained in windows whose chunk sizes cut
+    rounds short anywhere (7, 1, 13 steps), a checkpoint taken in the middle of a swap interval and restored into a fresh
+    handle that resolves to a DIFFERENT tree depth -- all must reproduce the cooperative schedule's uninterrupted run."""
+    d = ds()
+    from ptnn_amd import ladder, philox
+    topo, R, S, si, seed, cap = (4, 12, 3), 6, 10 * 12 + 5, 12, 77, 24
+    Pw = topo[0] * topo[1] + topo[1] * topo[2] + topo[1] + topo[2]
+    w0 = np.stack([philox.initial_weights(seed, r, Pw) for r in range(R)])
+    T = ladder.temperatures(R, 10)
+
+    def make(sched, groups=0, trace_capacity=0):
+        return parity.make_sampler(orc.TASK_CLS, topo, d["iris_train"], d["iris_test"], R_local=R, R_global=R, first=0, S=S, si=si,
+                                   use_lg=False, lr=0.01, seed=seed, schedule=sched, groups=groups, trace_capacity=trace_capacity)
+    full = make(1)
+    full.set_state(w0, T); full.run(-1); full.sync()
+    want, want_log, want_stats = full.traces(), full.swap_log().copy(), full.swap_stats()
+    full.close()
+    ring = make(4, 15, cap)
+    ring.set_state(w0, T)
+    parts, row, k = [], 0, 0
+    chunks = [7, 1, 13, cap - 1, 2]
+    while ring.steps_done() < S - 1:
+        ring.run(min(chunks[k % len(chunks)], S - 1 - ring.steps_done()))
+        k += 1
+        ring.sync()
+        hi = ring.steps_done() + 1
+        parts.append(ring.traces(row, hi - row))
+        row = hi
+    ring.run(-1); ring.sync()
+    got = {key: np.concatenate([p[key] for p in parts], axis=1) for key in parts[0]}
+    for key in want:
+        assert np.array_equal(got[key], want[key], equal_nan=True), key
+    assert ring.swap_stats() == want_stats and np.array_equal(ring.swap_log(), want_log)
+    ring.close()
+    stop = 5 * si + 7
+    a = make(4, 7)
+    a.set_state(w0, T); a.run(stop); a.sync()
+    head = a.traces(0, stop + 1)
+    blob = a.checkpoint()
+    a.close()
+    b = make(4, 3)
+    b.restore(blob)
+    b.run(-1); b.sync()
+    tail = b.traces(stop + 1, S - stop - 1)
+    for key in want:
+        assert np.array_equal(np.concatenate([head[key], tail[key]], axis=1), want[key], equal_nan=True), key
+    assert b.swap_stats() == want_stats
+    b.close()
+
+
+@pytest.mark.gpu
 def test_sharded_ladder_two_ranks_on_one_gpu():
     """ptnn_run on a sharded ladder with a REAL cross-process exchange on real device buffers: two processes share the one GPU
     of the box, each owns half of the ladder through the C ABI and they talk through the host-staged transport over gloo (RCCL
