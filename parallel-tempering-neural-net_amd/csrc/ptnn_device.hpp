@@ -12,6 +12,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// No implicit fused multiply-adds anywhere in the device code: whether `a * b + c` becomes one v_fma or a multiply and an add
+// would otherwise be decided per inlined copy by what surrounds it, and the same function could round differently in two kernels
+// (found by the stress tool: the bias update `b1 -= g * ldh` of the SGD epoch differed by one ulp between the packed and the
+// multi-CU speculative kernel on classification nets).  Every fused operation in this file is written as fmaf / v_pk_fma.
+#pragma clang fp contract(off)
+
 namespace ptnn {
 
 constexpr int TASK_REG = 0;
@@ -2167,6 +2173,10 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
     else segment_pack_body<TASK, I, O, 3>(p, step_begin, n_steps);
 }
 
+// The wide-net section is compared with nothing but itself and the float64 oracle: here the compiler may fuse as it likes
+// (5 % on config 5); the policy of the top of the file returns after model_wide_kernel.
+#pragma clang fp contract(fast)
+
 // ------------------------------------------------------------------------------------------------
 // Wide hidden layers (64 < H <= 512, e.g. BASELINE config 5: 32-512-1, P = 17 409): one THREAD per hidden unit over up to
 // 8 waves of the work-group.  The per-replica vectors (w, proposal, SGD results, noise: 70 KB each) no longer fit in LDS
@@ -2198,7 +2208,7 @@ __host__ __device__ inline size_t wide_img_floats(int H, int FWS, int PS) {
 // buffers, 10 flat loads).  Called out of line: inlined twice into the segment kernel next to the two MFMA forward variants
 // it pushed 312 VGPRs of the kernel into scratch (1236 B per lane for the 32-H-1 shape).
 template <int TASK, int I, int O>
-__device__ __attribute__((noinline)) void sgd_sweep_wide(const float* __restrict__ w_in, float* __restrict__ w_out,
+__device__ __attribute__((noinline, aligned(256))) void sgd_sweep_wide(const float* __restrict__ w_in, float* __restrict__ w_out,
                                                          const float* __restrict__ data, int IPY, int Ntr, int H, float lr,
                                                          float* __restrict__ part) {
     constexpr float C = -LOG2E, IC = -LN2;
@@ -2260,6 +2270,9 @@ __device__ __attribute__((noinline)) void sgd_sweep_wide(const float* __restrict
     float zp = zpart(xz);
     load_row(0, xu);
     load_row(1, xz);
+    // the row loop is one latency-bound dependent chain with three synchronisation points per row: where its head falls in an
+    // instruction-cache line decided 8 % of the epoch (472 vs 512 us for the same instructions), so it is pinned
+    asm volatile(".p2align 8");
     for (int n = 0; n < ntr; ++n) {
         const cfloat* row = cdata + (size_t)n * ipy;
         const float yn = row[I], dn = row[I + 1];
@@ -2724,6 +2737,8 @@ __global__ void __launch_bounds__(MAX_THREADS) model_wide_kernel(const SegParams
         o[0] = ll; o[1] = r1; o[2] = r2; o[3] = a_tr; o[4] = a_te; o[5] = pr; o[6] = ll_te; o[7] = 0.f;
     }
 }
+
+#pragma clang fp contract(off)
 
 // ------------------------------------------------------------------------------------------------
 // R12 swap cascade (REG:659-690, 741-748): one sequential bubble pass over the ladder.  Every block recomputes it

@@ -744,6 +744,10 @@ def test_random_configurations_commit_the_same_chain_under_every_schedule():
     # every compiled shape on synthetic data, hidden layers up to 64 units: speculative layouts bit-identical, cooperative
     # (several waves / matrix-core forward pass) within round-off, nothing non-finite
     assert mod.run(seed=7, ncase=14, verbose=False, shapes="all", oracle=True) == 0
+    # seeds that once failed: the SGD epoch's bias update was fused in one kernel and not in another (classification nets with more
+    # than 8 inputs, packed vs multi-CU speculative) until implicit contraction was switched off for the device code
+    assert mod.run(seed=202, ncase=24, verbose=False, shapes="all", oracle=True) == 0
+    assert mod.run(seed=303, ncase=24, verbose=False, shapes="all", oracle=True) == 0
 
 
 TREE_CASES = [("iris", (4, 12, 3), 6, 60, 10, 3), ("iris", (4, 12, 3), 6, 60, 10, 7), ("iris", (4, 12, 3), 4, 100, 7, 15),
