@@ -1473,7 +1473,7 @@ constexpr unsigned SPIN_LIMIT = 1u << 22;   // x (s_sleep 2 + one L2 round trip)
 
 __host__ __device__ inline size_t spec_wave_floats(int PS, int H, int FWS) { return 3 * (size_t)PS + fw_floats(H, FWS) + 8; }
 __host__ __device__ inline size_t spec_lds_floats(int Nall, int IPY, int PS, int H, int FWS, int NW, int G) {
-    return (size_t)(Nall + 2) * IPY + 3 * (size_t)PS + MAX_WAVES * 8 + (size_t)NW * G * SL_COUNT + (size_t)NW * spec_wave_floats(PS, H, FWS);
+    return (size_t)(Nall + 2) * IPY + 3 * (size_t)PS + MAX_WAVES * 8 + 32 + (size_t)NW * G * SL_COUNT + (size_t)NW * spec_wave_floats(PS, H, FWS);
 }
 
 // 8-byte {tag, value} granule written by ONE agent-scope relaxed atomic store (sc1, write-through) and polled with
@@ -1520,6 +1520,9 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
     float* w_gd = q; q += PS;
     float* rec_w = q; q += PS;
     float* red = q; q += MAX_WAVES * 8;
+    // forward passes of Langevin slots are taken over by waves of the work-group that have nothing left to do (below): per wave
+    // {proposal ready, forward claimed, forward done}, each the tag of the round it refers to
+    unsigned* pready = reinterpret_cast<unsigned*>(q); unsigned* fclaim = pready + MAX_WAVES; unsigned* fdone = fclaim + MAX_WAVES; q += 32;
     float* slots = q; q += K * SL_COUNT;
     // private part of every wave: proposal, its SGD epoch, noise, packed forward image, scalars
     const size_t wfl = spec_wave_floats(PS, H, p.FWS);
@@ -1546,6 +1549,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
         rec_w[j] = p.rec_w[(size_t)r * PS + j];
         w_gd[j] = p.gd_w[(size_t)r * PS + j];
     }
+    if (tid < 3 * MAX_WAVES) pready[tid] = 0u;                 // tag 0 is never a round's tag
     __syncthreads();
 
     const float T = uni_f(p.temps[r]);
@@ -1634,32 +1638,61 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
         float* sl = slots + sidx * SL_COUNT;
         bool acc_mine = false;
         STAMP(2);                                         // langevin_gradient(w) recompute (rare)
+        // forward pass + likelihood + prior of a proposal of THIS work-group (own or another wave's), on this wave's image scratch
+        auto forward_of = [&](const float* prop, float eta_x, float adapt_x, float& lik_prop, float& prior_prop, float& rm_tr,
+                              float& rm_te, float& ac_tr, float& ac_te) {
+            build_fw<I, O, true>(prop, my_fw, H, p.FWS);
+            gsync<true>();
+            const EvalSums es = eval_rows<TASK, I, O, true>(my_fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, nullptr);
+            float ll;
+            finish_eval<TASK>(es, p.Ntr, p.Nte, eta_x, ll, rm_tr, rm_te, ac_tr, ac_te);
+            lik_prop = ll / adapt_x;
+            const float ssq = block_sumsq<true>(prop, P, nullptr);
+            prior_prop = prior_value<TASK>(p, ssq, eta_x);
+        };
         if (active) {
             const float adapttemp = (p.switch_step >= 0 && j >= p.switch_step) ? 1.0f : T;
             float diff_prop = 0.0f;
+            float eta_pro = eta;
+            if (TASK == TASK_REG) eta_pro = fmaf(p.step_eta, n_eta, eta);
+            float lik_prop = 0.f, prior_prop = 0.f, rm_tr = 0.f, rm_te = 0.f, ac_tr = 0.f, ac_te = 0.f;
+            bool have_forward = false;
             if (lg) {
                 for (int e = lane; e < P; e += WAVE) my_prop[e] = fmaf(p.step_w, my_noise[e], w_gd[e]);
+                // The forward pass of the proposal does not depend on its SGD epoch: announce the proposal, so that a wave of
+                // this work-group with nothing left to do (a random-walk slot, an idle slot at the end of an interval) runs it
+                // while this wave sweeps.  Whoever sets the claim word to the round's tag first does the pass.
+                if (lane == 0) { sl[SL_ETAPRO] = eta_pro; sl[SL_ADAPT] = adapttemp; }
                 gsync<true>();
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(pready + wave, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 sgd_sweep_dispatch<TASK, I, O>(my_prop, my_pgd, xy, p.data, p.Ntr, H, p.lr);
                 gsync<true>();
                 const float d1 = block_sumsq_diff<true>(w_cur, my_pgd, P, nullptr);
                 const float d2 = block_sumsq<true>(my_noise, P, nullptr);
                 diff_prop = langevin_ratio(d1, d2, p.step_w, adapttemp);
+                unsigned prev = 0u;
+                if (lane == 0) prev = __hip_atomic_exchange(fclaim + wave, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                prev = (unsigned)uni_i((int)prev);
+                if (prev == epoch) {                            // a helper took it: wait for its results (it is far ahead of us)
+                    bool done = false;
+                    for (unsigned spins = 0; spins < (1u << 20) && !done; ++spins) {
+                        done = uni_i((int)__hip_atomic_load(fdone + wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == (int)epoch;
+                        if (!done) __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (done) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        lik_prop = uni_f(sl[SL_LIKPROP]); prior_prop = uni_f(sl[SL_PRIORPROP]);
+                        rm_tr = uni_f(sl[SL_RM_TR]); rm_te = uni_f(sl[SL_RM_TE]); ac_tr = uni_f(sl[SL_AC_TR]); ac_te = uni_f(sl[SL_AC_TE]);
+                        have_forward = true;
+                    }                                           // (never seen: the pass is then simply done here, same values)
+                }
             } else {
                 for (int e = lane; e < P; e += WAVE) my_prop[e] = fmaf(p.step_w, my_noise[e], w_cur[e]);
                 gsync<true>();
             }
             STAMP(3);                                     // proposal (+ SGD epoch for a Langevin slot)
-            float eta_pro = eta;
-            if (TASK == TASK_REG) eta_pro = fmaf(p.step_eta, n_eta, eta);
-            build_fw<I, O, true>(my_prop, my_fw, H, p.FWS);
-            gsync<true>();
-            const EvalSums es = eval_rows<TASK, I, O, true>(my_fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, nullptr);
-            float ll, rm_tr, rm_te, ac_tr, ac_te;
-            finish_eval<TASK>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
-            const float lik_prop = ll / adapttemp;
-            const float ssq = block_sumsq<true>(my_prop, P, nullptr);
-            const float prior_prop = prior_value<TASK>(p, ssq, eta_pro);
+            if (!have_forward) forward_of(my_prop, eta_pro, adapttemp, lik_prop, prior_prop, rm_tr, rm_te, ac_tr, ac_te);
             const float logalpha = (lik_prop - lik) + (prior_prop - prior_cur) + diff_prop;
             const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
             acc_mine = u < mh;
@@ -1697,6 +1730,29 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegPara
         // buffers suffice.
         if (G > 1 && lane == 0) granule_store(xv + (size_t)par * MAX_SLOTS + sidx, epoch, (active && acc_mine) ? 1.0f : 0.0f);
         STAMP(5);                                         // publish
+        // With its own step decided (or none to do), a wave takes over forward passes of Langevin slots of its work-group that are
+        // still sweeping: same code on the same proposal, so the values are those the owner would compute.
+        if (p.use_lg) {
+            for (int t_ = 0; t_ < NW; ++t_) {
+                if (t_ == wave) continue;
+                const bool ready = uni_i((int)__hip_atomic_load(pready + t_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == (int)epoch;
+                if (!ready) continue;
+                unsigned prev = epoch;
+                if (lane == 0) prev = __hip_atomic_exchange(fclaim + t_, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                prev = (unsigned)uni_i((int)prev);
+                if (prev == epoch) continue;                    // its owner or another helper has it
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                float* slt = slots + (grp * NW + t_) * SL_COUNT;
+                float lp, pp, r1, r2, a1, a2;
+                forward_of(priv0 + (size_t)t_ * wfl, uni_f(slt[SL_ETAPRO]), uni_f(slt[SL_ADAPT]), lp, pp, r1, r2, a1, a2);
+                if (lane == 0) {
+                    slt[SL_LIKPROP] = lp; slt[SL_PRIORPROP] = pp; slt[SL_RM_TR] = r1; slt[SL_RM_TE] = r2; slt[SL_AC_TR] = a1; slt[SL_AC_TE] = a2;
+                }
+                gsync<true>();
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(fdone + t_, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
         __syncthreads();
         STAMP(6);                                         // waiting for the slowest wave of this work-group
         if (G > 1) {
