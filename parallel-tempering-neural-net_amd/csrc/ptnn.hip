@@ -178,7 +178,7 @@ int launch_segment(ptnn_handle* h, int begin, int n) {
     const bool timed = h->timing_stride > 0 && (h->launch_count++ % h->timing_stride) == 0;
     if (!timed) {
         const SegParams p = h->seg_params();
-        const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree) ? h->groups : 1);
+        const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
         hipLaunchKernelGGL(h->wide ? h->shape->seg_wide : (h->tree ? h->shape->tree : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg))),
                            dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
         h->epoch_base += (unsigned)n + 1u;
@@ -199,7 +199,7 @@ int launch_segment(ptnn_handle* h, int begin, int n) {
     auto& ev = h->timing[h->timing_used++];
     const SegParams p = h->seg_params();
     HIP_TRY(hipEventRecord(ev.first, h->stream));
-    const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree) ? h->groups : 1);
+    const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
     hipLaunchKernelGGL(h->wide ? h->shape->seg_wide : (h->tree ? h->shape->tree : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg))),
                        dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
     h->epoch_base += (unsigned)n + 1u;                    // granule tags never repeat across launches
@@ -443,9 +443,45 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         if (h->d_data) { HIP_TRY(hipFree(h->d_data)); h->d_data = nullptr; }
         HIP_TRY(hipMalloc(&h->d_data, packed.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(h->d_data, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
-        if (!h->d_wide_scratch) HIP_TRY(hipMalloc(&h->d_wide_scratch, (size_t)h->cfg.n_replicas_local * 3 * h->PS * sizeof(float)));
         if (int rc = raise_lds_limit(reinterpret_cast<const void*>(h->shape->seg_wide), lds)) return rc;
         if (int rc = raise_lds_limit(reinterpret_cast<const void*>(h->shape->model_wide), lds)) return rc;
+        {
+            // Speculation over work-groups (one per CU): group g computes step i + g; all Rl x G groups must be resident (they wait
+            // for each other's verdicts).  groups_per_replica 1, 2 or 4; 0 = as many of 4, 2 as are resident, else 1.
+            const int Rl = h->cfg.n_replicas_local;
+            const int want = h->cfg.groups_per_replica;
+            if (want != 0 && want != 1 && want != 2 && want != 4) return fail(-1, "wide nets: groups_per_replica must be 0 (auto), 1, 2 or 4");
+            int per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(h->shape->seg_wide), h->nthreads, lds));
+            h->blocks_per_cu = per_cu;
+            const long long cap = (long long)per_cu * h->num_cus;
+            int G = 1;
+            if (want > 1) {
+                if ((long long)Rl * want > cap)
+                    return fail(-3, "%d replicas x %d work-groups cannot all be resident: %d work-group(s) of %d threads with %zu B of LDS fit "
+                                    "on each of the %d CUs", Rl, want, per_cu, h->nthreads, lds, h->num_cus);
+                G = want;
+            } else if (want == 0) {
+                if ((long long)Rl * 4 <= cap) G = 4;
+                else if ((long long)Rl * 2 <= cap) G = 2;
+            }
+            h->groups = G;
+            if (h->d_wide_scratch) { HIP_TRY(hipFree(h->d_wide_scratch)); h->d_wide_scratch = nullptr; }
+            HIP_TRY(hipMalloc(&h->d_wide_scratch, (size_t)Rl * G * 5 * h->PS * sizeof(float)));
+            if (h->d_xslots) { HIP_TRY(hipFree(h->d_xslots)); h->d_xslots = nullptr; }
+            if (h->d_xw) { HIP_TRY(hipFree(h->d_xw)); h->d_xw = nullptr; }
+            if (h->d_xverdict) { HIP_TRY(hipFree(h->d_xverdict)); h->d_xverdict = nullptr; }
+            if (G > 1) {
+                const size_t ns = (size_t)Rl * 2 * MAX_SLOTS * SL_COUNT, nx = (size_t)Rl * 2 * G * 2 * h->PS, nvd = (size_t)Rl * 2 * MAX_SLOTS;
+                HIP_TRY(hipMalloc(&h->d_xslots, ns * sizeof(unsigned long long)));
+                HIP_TRY(hipMalloc(&h->d_xw, nx * sizeof(unsigned long long)));
+                HIP_TRY(hipMalloc(&h->d_xverdict, nvd * sizeof(unsigned long long)));
+                HIP_TRY(hipMemset(h->d_xslots, 0, ns * sizeof(unsigned long long)));
+                HIP_TRY(hipMemset(h->d_xw, 0, nx * sizeof(unsigned long long)));
+                HIP_TRY(hipMemset(h->d_xverdict, 0, nvd * sizeof(unsigned long long)));
+                h->epoch_base = 1;                              // tag 0 = never written
+            }
+        }
         h->have_data = true;
         return 0;
     }
@@ -1298,15 +1334,15 @@ int ptnn_describe(ptnn_handle* h, char* buf, int nbytes) {
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, h->nthreads, h->seg_lds));
     hipFuncAttributes fa{};
     HIP_TRY(hipFuncGetAttributes(&fa, fn));
-    const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree) ? h->groups : 1);
+    const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
     // tree: the steps committed per round (its depth)
-    const int slots = h->tree ? tree_depth(h->groups) : (h->wide || !h->speculative ? 1 : (h->packed ? pack_slots(h->pk_nred) : h->groups * (h->nthreads / WAVE)));
+    const int slots = h->tree ? tree_depth(h->groups) : (h->wide ? h->groups : !h->speculative ? 1 : (h->packed ? pack_slots(h->pk_nred) : h->groups * (h->nthreads / WAVE)));
     const int n = std::snprintf(buf, (size_t)nbytes,
                                 "{\"kernel\": \"ptnn::%s<%d,%d,%d>\", \"schedule\": \"%s\", \"grid_blocks\": %d, \"block_threads\": %d, "
                                 "\"lds_bytes\": %zu, \"groups_per_replica\": %d, \"slots_per_round\": %d, \"num_cus\": %d, "
                                 "\"blocks_per_cu\": %d, \"vgprs\": %d, \"scratch_bytes\": %zu, \"forward_mfma\": %d, \"exchange\": \"%s\"}",
                                 kern, h->cfg.task, h->cfg.n_in, h->cfg.n_out,
-                                h->wide ? "cooperative-wide" : (h->tree ? "prefetching-tree" : (h->packed ? "packed-speculative" : (h->speculative ? "speculative" : "cooperative"))),
+                                h->wide ? (h->groups > 1 ? "speculative-wide" : "cooperative-wide") : (h->tree ? "prefetching-tree" : (h->packed ? "packed-speculative" : (h->speculative ? "speculative" : "cooperative"))),
                                 grid, h->nthreads, h->seg_lds, h->groups, slots, h->num_cus, per_cu, fa.numRegs, (size_t)fa.localSizeBytes,
                                 (h->fw_mfma || (h->wide && h->cfg.n_hidden % 32 == 0)) ? 1 : 0,
                                 h->comm.kind == COMM_NONE ? "none" : (h->cfg.label_swap ? "labels" : (resolved_xchg_mode(h) == PTNN_XCHG_GATHER ? "gather" : "boundary")));

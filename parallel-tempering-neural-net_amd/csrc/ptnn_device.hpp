@@ -2579,25 +2579,44 @@ __device__ __forceinline__ EvalSums wide_forward(const SegParams& p, const float
     return eval_rows<TASK, I, O>(img, p.data, p.IPY, p.FWS, p.H, p.Ntr, Nall, red);
 }
 
+// One work-group per replica (p.G == 1), or the speculative schedule over p.G work-groups (one per CU) as for the narrow nets:
+// group g computes step i + g assuming steps i .. i+g-1 reject, the prefix up to and including the first accepted step is
+// committed.  Wide nets accept 1 - 5 % of their proposals, so G groups commit almost G steps per round.  Every group keeps its
+// own copy of the chain vectors (group 0 the canonical rows, the others rows of the scratch buffer) and applies the same commits;
+// what crosses CUs are {tag, value} granules: one verdict per group and round, and -- only from a group whose step was accepted --
+// its record and its vectors (proposal, SGD epoch).
 template <int TASK, int I, int O>
 __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegParams p, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int OP = (O + 3) & ~3;
-    const int r = blockIdx.x;
+    const int G = p.G;
+    const int r = blockIdx.x / G, grp = blockIdx.x - r * G;
     const int gid = p.first_global + r;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int P = p.P, PS = p.PS, H = p.H;
     float* fw = smem;
     float* red = fw + wide_img_floats(H, p.FWS, PS);
     float* part = red + MAX_WAVES * 8;
-    float* scal = part + 2 * MAX_WAVES * OP;
+    float* scal = part + 2 * MAX_WAVES * OP;                    // 16 floats: staging of an accepted foreign record
     const float* xy = p.data;                                   // global (L2 / scalar cache)
-    float* w_cur = p.w_state + (size_t)r * PS;                  // chain state row, updated in place
-    float* w_gd = p.gd_w + (size_t)r * PS;
-    float* rec_w = p.rec_w + (size_t)r * PS;
-    float* w_prop = p.wide_scratch + ((size_t)r * 3 + 0) * PS;
-    float* w_pgd = p.wide_scratch + ((size_t)r * 3 + 1) * PS;
-    float* noise = p.wide_scratch + ((size_t)r * 3 + 2) * PS;
+    float* const mine = p.wide_scratch + (size_t)(r * G + grp) * 5 * PS;
+    float* w_prop = mine;
+    float* w_pgd = mine + PS;
+    float* w_cur = (grp == 0) ? p.w_state + (size_t)r * PS : mine + 2 * (size_t)PS;   // chain state row (group 0: updated in place)
+    float* w_gd = (grp == 0) ? p.gd_w + (size_t)r * PS : mine + 3 * (size_t)PS;
+    float* rec_w = (grp == 0) ? p.rec_w + (size_t)r * PS : mine + 4 * (size_t)PS;
+    if (grp > 0) {
+        // (group 0 touches the canonical rows at its first commit, which needs this group's first verdict)
+        for (int q = tid; q < PS / 4; q += nthr) {
+            reinterpret_cast<float4*>(w_cur)[q] = reinterpret_cast<const float4*>(p.w_state + (size_t)r * PS)[q];
+            reinterpret_cast<float4*>(w_gd)[q] = reinterpret_cast<const float4*>(p.gd_w + (size_t)r * PS)[q];
+            reinterpret_cast<float4*>(rec_w)[q] = reinterpret_cast<const float4*>(p.rec_w + (size_t)r * PS)[q];
+        }
+        __syncthreads();
+    }
+    granule_t* const xs = p.xslots + (size_t)r * 2 * MAX_SLOTS * SL_COUNT;
+    granule_t* const xv = p.xverdict + (size_t)r * 2 * MAX_SLOTS;
+    granule_t* const xw = p.xw + (size_t)r * 2 * G * 2 * PS;    // [parity][group][proposal ++ its SGD epoch]
 
     const float T = p.temps[r];
     float eta = (TASK == TASK_REG) ? w_cur[P] : 0.0f;
@@ -2619,8 +2638,16 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
     }
 
     const size_t trow = (size_t)r * p.trace_cap;        // traces are rings of trace_cap rows per replica (== S unless streaming)
-    for (int i = step_begin; i < step_begin + n_steps; ++i) {
-        const float adapttemp = (p.switch_step >= 0 && i >= p.switch_step) ? 1.0f : T;
+    const int end = step_begin + n_steps;
+    const int nv = (P + 3) >> 2;
+    unsigned epoch = p.epoch_base;
+    int par = 0;
+    bool failed = false;
+    int i = step_begin;
+    while (i < end) {
+        epoch += 1;
+        int k = min(G, end - i);
+        if (p.switch_step > i) k = min(k, p.switch_step - i);   // a round never straddles the temperature switch
         if (i == p.switch_step) {
             const EvalSums sc = wide_forward<TASK, I, O>(p, w_cur, fw, red);
             float ll, r1, r2, a1, a2;
@@ -2628,123 +2655,213 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
             lik = ll;
             __syncthreads();
         }
-        // the step's scalars {lx, u, n_eta}: every thread draws them itself (one Philox call) instead of one thread + a barrier
-        float lx, u, n_eta;
-        {
+        const int j = i + grp;                                 // my step
+        const bool active = grp < k;
+        const float adapttemp = (p.switch_step >= 0 && i >= p.switch_step) ? 1.0f : T;
+        bool lg = false, accept = false;
+        float lik_prop = 0.f, prior_prop = 0.f, logalpha = 0.f, eta_pro = eta, rm_tr = 0.f, rm_te = 0.f, ac_tr = 0.f, ac_te = 0.f;
+        if (active) {
+            // the step's scalars {lx, u, n_eta}: every thread draws them itself (one Philox call) instead of one thread + a barrier
+            float lx, u, n_eta;
+            {
+                uint32_t x[4];
+                philox4x32_10(0u, (uint32_t)j, p.noise_shared ? 0u : (uint32_t)gid, STREAM_STEP, p.seed_lo, p.seed_hi, x);
+                float n2, n3;
+                box_muller(x[2], x[3], n2, n3);
+                lx = uni_f(u23(x[0])); u = uni_f(u23(x[1])); n_eta = uni_f(n2);
+            }
+            float diff_prop = 0.0f;
+            lg = p.use_lg && (lx < p.l_prob);
+            if (lg && !gd_valid) {
+                sgd_sweep_wide<TASK, I, O>(w_cur, w_gd, xy, p.IPY, p.Ntr, H, p.lr, part);
+                gd_valid = 1;
+            }
+            // ONE pass over the weights: draw the noise (4 normals per Philox call), form the proposal from w (random walk) or
+            // from the cached SGD epoch (Langevin), put it where the forward pass reads it (the flat LDS image of the MFMA
+            // layout) and in its global row, and add up |proposal|^2 (prior) and |noise|^2 (Langevin ratio) on the way.  The
+            // noise itself is never stored.  (It used to be five passes through global memory: tape, proposal, image copy and
+            // the two norms.)
+            const bool img_direct = wide_mfma(p);
+            float ssq_part = 0.0f, nsq_part = 0.0f;
+            {
+                const float* base = lg ? w_gd : w_cur;
+                for (int q = tid; q < nv; q += nthr) {
+                    uint32_t x[4];
+                    philox4x32_10((uint32_t)q, (uint32_t)j, p.noise_shared ? 0u : (uint32_t)gid, STREAM_WNOISE, p.seed_lo, p.seed_hi, x);
+                    float n[4];
+                    box_muller(x[0], x[1], n[0], n[1]);
+                    box_muller(x[2], x[3], n[2], n[3]);
+                    const int j0 = 4 * q;
+                    if (j0 + 3 < P) {
+                        const float4 b = *reinterpret_cast<const float4*>(base + j0);
+                        const float4 v = make_float4(fmaf(p.step_w, n[0], b.x), fmaf(p.step_w, n[1], b.y), fmaf(p.step_w, n[2], b.z),
+                                                     fmaf(p.step_w, n[3], b.w));
+                        *reinterpret_cast<float4*>(w_prop + j0) = v;
+                        if (img_direct) *reinterpret_cast<float4*>(fw + j0) = v;
+                        ssq_part = fmaf(v.x, v.x, ssq_part); ssq_part = fmaf(v.y, v.y, ssq_part);
+                        ssq_part = fmaf(v.z, v.z, ssq_part); ssq_part = fmaf(v.w, v.w, ssq_part);
+                        nsq_part = fmaf(n[0], n[0], nsq_part); nsq_part = fmaf(n[1], n[1], nsq_part);
+                        nsq_part = fmaf(n[2], n[2], nsq_part); nsq_part = fmaf(n[3], n[3], nsq_part);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (j0 + e < P) {
+                                const float v = fmaf(p.step_w, n[e], base[j0 + e]);
+                                w_prop[j0 + e] = v;
+                                if (img_direct) fw[j0 + e] = v;
+                                ssq_part = fmaf(v, v, ssq_part);
+                                nsq_part = fmaf(n[e], n[e], nsq_part);
+                            }
+                    }
+                }
+            }
+            __syncthreads();
+            if (lg) {
+                sgd_sweep_wide<TASK, I, O>(w_prop, w_pgd, xy, p.IPY, p.Ntr, H, p.lr, part);
+                const float d1 = block_sumsq_diff(w_cur, w_pgd, P, red);
+                const float d2 = block_sum(nsq_part, red);
+                diff_prop = langevin_ratio(d1, d2, p.step_w, adapttemp);
+            }
+            if (TASK == TASK_REG) eta_pro = fmaf(p.step_eta, n_eta, eta);
+            const EvalSums es = wide_forward<TASK, I, O>(p, w_prop, fw, red, img_direct);
+            float ll;
+            finish_eval<TASK>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
+            lik_prop = ll / adapttemp;
+            const float ssq = block_sum(ssq_part, red);
+            prior_prop = prior_value<TASK>(p, ssq, eta_pro);
+            logalpha = (lik_prop - lik) + (prior_prop - prior_cur) + diff_prop;
+            const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
+            accept = u < mh;
+        }
+        // the first accepted step of the round
+        int m = k;
+        if (G == 1) {
+            if (accept) m = 0;
+        } else {
+            if (active && accept) {
+                // an accepted step publishes its record and its vectors; the other groups read them at commit, and only then
+                if (tid == 0) {
+                    granule_t* xr = xs + ((size_t)par * MAX_SLOTS + grp) * SL_COUNT;
+                    granule_store(xr + SL_LIKPROP, epoch, lik_prop); granule_store(xr + SL_PRIORPROP, epoch, prior_prop);
+                    granule_store(xr + SL_ETAPRO, epoch, eta_pro);
+                    granule_store(xr + SL_RM_TR, epoch, rm_tr); granule_store(xr + SL_RM_TE, epoch, rm_te);
+                    granule_store(xr + SL_AC_TR, epoch, ac_tr); granule_store(xr + SL_AC_TE, epoch, ac_te);
+                }
+                granule_t* xo = xw + ((size_t)par * G + grp) * 2 * PS;
+                for (int e = tid; e < P; e += nthr) {
+                    granule_store(xo + e, epoch, w_prop[e]);
+                    if (lg) granule_store(xo + PS + e, epoch, w_pgd[e]);
+                }
+            }
+            if (tid == 0) granule_store(xv + (size_t)par * MAX_SLOTS + grp, epoch, (active && accept) ? 1.0f : 0.0f);
+            bool ok = true;
+            if (tid < G) {
+                float v = 0.0f;
+                ok = granule_wait(xv + (size_t)par * MAX_SLOTS + tid, epoch, v);
+                scal[tid] = v;
+            }
+            if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
+            for (int s_ = k - 1; s_ >= 0; --s_)
+                if (scal[s_] != 0.0f) m = s_;
+            __syncthreads();                                    // scal[] is reused below
+        }
+        const int ncommit = (m < k) ? m + 1 : k;
+        // what the committed steps leave behind apart from the state: the Langevin count and the last PROPOSED eta -- both follow
+        // from the tape (every thread draws the scalars of the committed steps itself)
+        bool lg_m = false;
+        for (int s_ = 0; s_ < ncommit; ++s_) {
             uint32_t x[4];
-            philox4x32_10(0u, (uint32_t)i, p.noise_shared ? 0u : (uint32_t)gid, STREAM_STEP, p.seed_lo, p.seed_hi, x);
+            philox4x32_10(0u, (uint32_t)(i + s_), p.noise_shared ? 0u : (uint32_t)gid, STREAM_STEP, p.seed_lo, p.seed_hi, x);
             float n2, n3;
             box_muller(x[2], x[3], n2, n3);
-            lx = uni_f(u23(x[0])); u = uni_f(u23(x[1])); n_eta = uni_f(n2);
+            const bool lg_s = p.use_lg && (uni_f(u23(x[0])) < p.l_prob);
+            lg_count += lg_s ? 1 : 0;
+            if (TASK == TASK_REG) tau_eta_last = fmaf(p.step_eta, uni_f(n2), eta);
+            if (s_ == m) lg_m = lg_s;
         }
-        float diff_prop = 0.0f;
-        const bool lg = p.use_lg && (lx < p.l_prob);
-        if (lg && !gd_valid) {
-            sgd_sweep_wide<TASK, I, O>(w_cur, w_gd, xy, p.IPY, p.Ntr, H, p.lr, part);
-            gd_valid = 1;
-        }
-        // ONE pass over the weights: draw the noise (4 normals per Philox call), form the proposal from w (random walk) or
-        // from the cached SGD epoch (Langevin), put it where the forward pass reads it (the flat LDS image of the MFMA
-        // layout) and in its global row, and add up |proposal|^2 (prior) and |noise|^2 (Langevin ratio) on the way.  The
-        // noise itself is never stored.  (It used to be five passes through global memory: tape, proposal, image copy and
-        // the two norms.)
-        const bool img_direct = wide_mfma(p);
-        float ssq_part = 0.0f, nsq_part = 0.0f;
-        {
-            const float* base = lg ? w_gd : w_cur;
-            const int nq = (P + 3) >> 2;
-            for (int q = tid; q < nq; q += nthr) {
-                uint32_t x[4];
-                philox4x32_10((uint32_t)q, (uint32_t)i, p.noise_shared ? 0u : (uint32_t)gid, STREAM_WNOISE, p.seed_lo, p.seed_hi, x);
-                float n[4];
-                box_muller(x[0], x[1], n[0], n[1]);
-                box_muller(x[2], x[3], n[2], n[3]);
-                const int j0 = 4 * q;
-                if (j0 + 3 < P) {
-                    const float4 b = *reinterpret_cast<const float4*>(base + j0);
-                    const float4 v = make_float4(fmaf(p.step_w, n[0], b.x), fmaf(p.step_w, n[1], b.y), fmaf(p.step_w, n[2], b.z),
-                                                 fmaf(p.step_w, n[3], b.w));
-                    *reinterpret_cast<float4*>(w_prop + j0) = v;
-                    if (img_direct) *reinterpret_cast<float4*>(fw + j0) = v;
-                    ssq_part = fmaf(v.x, v.x, ssq_part); ssq_part = fmaf(v.y, v.y, ssq_part);
-                    ssq_part = fmaf(v.z, v.z, ssq_part); ssq_part = fmaf(v.w, v.w, ssq_part);
-                    nsq_part = fmaf(n[0], n[0], nsq_part); nsq_part = fmaf(n[1], n[1], nsq_part);
-                    nsq_part = fmaf(n[2], n[2], nsq_part); nsq_part = fmaf(n[3], n[3], nsq_part);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (j0 + e < P) {
-                            const float v = fmaf(p.step_w, n[e], base[j0 + e]);
-                            w_prop[j0 + e] = v;
-                            if (img_direct) fw[j0 + e] = v;
-                            ssq_part = fmaf(v, v, ssq_part);
-                            nsq_part = fmaf(n[e], n[e], nsq_part);
-                        }
-                }
-            }
-        }
-        __syncthreads();
-        if (lg) {
-            sgd_sweep_wide<TASK, I, O>(w_prop, w_pgd, xy, p.IPY, p.Ntr, H, p.lr, part);
-            const float d1 = block_sumsq_diff(w_cur, w_pgd, P, red);
-            const float d2 = block_sum(nsq_part, red);
-            diff_prop = langevin_ratio(d1, d2, p.step_w, adapttemp);
-            lg_count += 1;
-        }
-        float eta_pro = eta;
-        if (TASK == TASK_REG) { eta_pro = fmaf(p.step_eta, n_eta, eta); tau_eta_last = eta_pro; }
-        const EvalSums es = wide_forward<TASK, I, O>(p, w_prop, fw, red, img_direct);
-        float ll, rm_tr, rm_te, ac_tr, ac_te;
-        finish_eval<TASK>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
-        const float lik_prop = ll / adapttemp;
-        const float ssq = block_sum(ssq_part, red);
-        const float prior_prop = prior_value<TASK>(p, ssq, eta_pro);
-        const float logalpha = (lik_prop - lik) + (prior_prop - prior_cur) + diff_prop;
-        const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
-        const bool accept = u < mh;
+        const bool acc_me = active && (grp == m);
         const int acc_before = nacc;
-        __syncthreads();                                    // every reader of w_cur / w_gd of this step is done
-        const size_t tpos = trow + (size_t)((i + 1) % p.trace_cap);
-        float* prow = p.tr_pos_w + tpos * (size_t)p.PW;
-        // rows of PS / PW floats are 16-byte aligned and padded: whole float4s, the tail past P rewritten as it must be
-        // (trace row: zeros; state rows: the element at P is eta, restored at the end of the launch, the rest is padding)
-        const int nv = (P + 3) >> 2;
-        for (int j = 4 * nv + tid; j < p.PW; j += nthr) prow[j] = 0.0f;
-        if (accept) {
-            nacc += 1;
-            lik = lik_prop; prior_cur = prior_prop; eta = eta_pro;
-            rec_rmse_tr = rm_tr; rec_rmse_te = rm_te; rec_acc_tr = ac_tr; rec_acc_te = ac_te;
-            gd_valid = lg ? 1 : 0;
-            for (int q = tid; q < nv; q += nthr) {
-                float4 v = *reinterpret_cast<const float4*>(w_prop + 4 * q);
-                if (4 * q + 3 >= P) {                        // the last, partial quad: nothing of the proposal past P
-                    if (4 * q + 1 >= P) v.y = 0.0f;
-                    if (4 * q + 2 >= P) v.z = 0.0f;
-                    v.w = 0.0f;
+        __syncthreads();                                    // every reader of w_cur / w_gd of this round is done
+        // new chain scalars (an accepted foreign step: from its record)
+        if (m < k) {
+            if (!acc_me) {
+                bool ok = true;
+                if (G > 1 && tid < SL_COUNT && (tid == SL_LIKPROP || tid == SL_PRIORPROP || tid == SL_ETAPRO || tid == SL_RM_TR ||
+                                                 tid == SL_RM_TE || tid == SL_AC_TR || tid == SL_AC_TE)) {
+                    float v = 0.0f;
+                    ok = granule_wait(xs + ((size_t)par * MAX_SLOTS + m) * SL_COUNT + tid, epoch, v);
+                    scal[tid] = v;
                 }
-                *reinterpret_cast<float4*>(w_cur + 4 * q) = v;
-                *reinterpret_cast<float4*>(rec_w + 4 * q) = v;
-                *reinterpret_cast<float4*>(prow + 4 * q) = v;
-                if (lg) *reinterpret_cast<float4*>(w_gd + 4 * q) = *reinterpret_cast<const float4*>(w_pgd + 4 * q);
-            }
-        } else {
-            for (int q = tid; q < nv; q += nthr) {
-                float4 v = *reinterpret_cast<const float4*>(rec_w + 4 * q);
-                if (4 * q + 3 >= P) {
-                    if (4 * q + 1 >= P) v.y = 0.0f;
-                    if (4 * q + 2 >= P) v.z = 0.0f;
-                    v.w = 0.0f;
-                }
-                *reinterpret_cast<float4*>(prow + 4 * q) = v;
+                if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
             }
         }
-        if (tid == 0) {
-            store_trace_row(p.tr_scal + tpos * TR_COUNT, (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp, rec_rmse_tr, rec_rmse_te,
-                            rec_acc_tr, rec_acc_te, acc_before, logalpha);
+        // trace row of my step, if it is committed: rows of PS / PW floats are 16-byte aligned and padded: whole float4s, the tail
+        // past P rewritten as it must be (trace row: zeros; state rows: the element at P is eta, restored at the end of the launch)
+        if (grp < ncommit) {
+            const size_t tpos = trow + (size_t)((j + 1) % p.trace_cap);
+            float* prow = p.tr_pos_w + tpos * (size_t)p.PW;
+            for (int e = 4 * nv + tid; e < p.PW; e += nthr) prow[e] = 0.0f;
+            const float* src = acc_me ? w_prop : rec_w;
+            for (int q = tid; q < nv; q += nthr) {
+                float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+                if (4 * q + 3 >= P) {                        // the last, partial quad: nothing past P
+                    if (4 * q + 1 >= P) v.y = 0.0f;
+                    if (4 * q + 2 >= P) v.z = 0.0f;
+                    v.w = 0.0f;
+                }
+                *reinterpret_cast<float4*>(prow + 4 * q) = v;
+            }
+            if (tid == 0) {
+                store_trace_row(p.tr_scal + tpos * TR_COUNT, (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp,
+                                acc_me ? rm_tr : rec_rmse_tr, acc_me ? rm_te : rec_rmse_te, acc_me ? ac_tr : rec_acc_tr,
+                                acc_me ? ac_te : rec_acc_te, acc_before, logalpha);
+            }
+        }
+        if (m < k) {
+            nacc += 1;
+            gd_valid = lg_m ? 1 : 0;
+            if (acc_me) {
+                lik = lik_prop; prior_cur = prior_prop; eta = eta_pro;
+                rec_rmse_tr = rm_tr; rec_rmse_te = rm_te; rec_acc_tr = ac_tr; rec_acc_te = ac_te;
+                __syncthreads();                                // the trace row above has read rec_w
+                for (int q = tid; q < nv; q += nthr) {
+                    float4 v = *reinterpret_cast<const float4*>(w_prop + 4 * q);
+                    if (4 * q + 3 >= P) {
+                        if (4 * q + 1 >= P) v.y = 0.0f;
+                        if (4 * q + 2 >= P) v.z = 0.0f;
+                        v.w = 0.0f;
+                    }
+                    *reinterpret_cast<float4*>(w_cur + 4 * q) = v;
+                    *reinterpret_cast<float4*>(rec_w + 4 * q) = v;
+                    if (lg_m) *reinterpret_cast<float4*>(w_gd + 4 * q) = *reinterpret_cast<const float4*>(w_pgd + 4 * q);
+                }
+            } else {
+                lik = scal[SL_LIKPROP]; prior_cur = scal[SL_PRIORPROP]; eta = scal[SL_ETAPRO];
+                rec_rmse_tr = scal[SL_RM_TR]; rec_rmse_te = scal[SL_RM_TE]; rec_acc_tr = scal[SL_AC_TR]; rec_acc_te = scal[SL_AC_TE];
+                __syncthreads();                                // the trace row above has read rec_w
+                const granule_t* xo = xw + ((size_t)par * G + m) * 2 * PS;
+                bool ok = true;
+                for (int e = tid; e < 4 * nv; e += nthr) {
+                    float v = 0.0f, g_ = 0.0f;
+                    if (e < P) {
+                        ok = granule_wait(xo + e, epoch, v) && ok;
+                        if (lg_m) ok = granule_wait(xo + PS + e, epoch, g_) && ok;
+                    }
+                    w_cur[e] = v; rec_w[e] = v;
+                    if (lg_m) w_gd[e] = g_;
+                }
+                if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
+            }
         }
         __syncthreads();
+        i += ncommit;
+        par ^= 1;
     }
-    if (tid == 0) {
+    if (failed) {
+        if (tid == 0) atomicAdd(p.error_flag, 1);           // a bounded spin ran out: the host reports it
+        return;
+    }
+    if (grp == 0 && tid == 0) {
         w_cur[P] = eta;
         sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur; sf[SF_TAU_LAST] = tau_eta_last;
         sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;

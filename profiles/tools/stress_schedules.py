@@ -49,8 +49,8 @@ def run(seed=0, ncase=30, verbose=True, shapes="timeseries+iris", oracle=False):
       # order, and for mid-sized nets takes the matrix-core forward pass: compared within round-off.
       variants = [dict(schedule=2, waves=1, groups=1), dict(schedule=2, waves=4, groups=2), dict(schedule=2, waves=8, groups=1),
                   dict(schedule=2, waves=4, groups=4), dict(schedule=2, waves=2, groups=8)]
-      if H > 64:
-          variants = [dict(schedule=0), dict(schedule=1)]
+      if H > 64:                                      # one kernel, one to four work-groups per replica: bit-identical
+          variants = [dict(schedule=0, groups=1), dict(schedule=0, groups=2), dict(schedule=0, groups=4), dict(schedule=0), dict(schedule=1)]
       if H <= 16:
           variants.append(dict(schedule=3))
       if H < 24 or I < 6:
@@ -131,7 +131,7 @@ def run(seed=0, ncase=30, verbose=True, shapes="timeseries+iris", oracle=False):
                               print("   r", r, "la-lu", np.round(o.logalpha[r, :n_] - o.logu[r, :n_], 3).tolist(), flush=True)
                       print(f"ORACLE MISMATCH case {case}: task={task} {name} topo={topo} ntr={ntr} nte={nte} R={R} S={S} si={si} lg={lg} seed={seed}: {str(e)[:300]}", flush=True)
               continue
-          loose = v.get("schedule") in (0, 1, 4) and (v.get("waves", 0) != 1 or (H >= 24 and I >= 6))
+          loose = H <= 64 and v.get("schedule") in (0, 1, 4) and (v.get("waves", 0) != 1 or (H >= 24 and I >= 6))
           if loose:
               same_dec = np.array_equal(got[0]["accept"], ref[0]["accept"])
               ok = (not same_dec) or (got[1] == ref[1] and np.array_equal(got[2], ref[2]) and

@@ -871,6 +871,68 @@ def test_prefetching_tree_streams_and_resumes():
     b.close()
 
 
+WIDE_SPEC_CASES = [(0, (32, 96, 1), 4, 45, 10, True), (0, (32, 96, 1), 3, 50, 7, False), (0, (32, 70, 1), 3, 30, 10, True),
+                   (1, (34, 128, 2), 4, 50, 10, False), (1, (34, 96, 2), 3, 36, 9, True), (0, (32, 512, 1), 2, 24, 8, True)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task,topo,R,S,si,lg", WIDE_SPEC_CASES, ids=[f"t{c[0]}-H{c[1][1]}-R{c[2]}-S{c[3]}-lg{int(c[5])}" for c in WIDE_SPEC_CASES])
+def test_wide_nets_speculate_over_work_groups_without_changing_the_chain(task, topo, R, S, si, lg):
+    """Wide nets (n_hidden > 64): 2 or 4 work-groups per replica, group g computing step i + g on the assumption that the steps
+    before it reject, must commit the chain of the one-work-group kernel bit for bit -- traces, swap statistics, swap log, final
+    state -- with Langevin and random-walk proposals, matrix-core (H % 32 == 0) and vector forward passes, regression and
+    classification, across swap rounds and the temperature switch; the cases accept 15 - 130 steps, so accepted steps of a foreign
+    group (record + 2 x 70 KB of granules in the 32-512-1 case) are exercised."""
+    from ptnn_amd import ladder, philox
+    rng = np.random.default_rng(3)
+    I, H, O = topo
+    ntr, nte = 90, 30
+    X = rng.uniform(0, 1, (ntr + nte, I))
+    y = (np.argmax(X @ rng.standard_normal((I, O)), axis=1).astype(np.float64) if task else np.clip(0.5 + 0.3 * np.sin(X.sum(axis=1)), 0, 1))
+    data = np.hstack([X, y[:, None]])
+    train, test = data[:ntr], data[ntr:]
+    P = I * H + H * O + H + O
+    w0 = np.stack([0.3 * philox.initial_weights(5, r, P) for r in range(R)]).astype(np.float32)
+    T = ladder.temperatures(R, 10 if task else 2)
+    out = []
+    for groups in (1, 2, 4):
+        s = parity.make_sampler(task, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=lg, lr=0.01 if task else 0.1,
+                                seed=11, groups=groups)
+        s.set_state(w0, T); s.run(-1); s.sync()
+        out.append((s.traces(), s.swap_stats(), s.swap_log().copy(), s.state(), s.describe()))
+        s.close()
+    ref = out[0]
+    assert ref[4]["schedule"] == "cooperative-wide"
+    assert int(ref[0]["accept"][:, -1].sum()) >= 10                # the commit path of accepted steps is exercised
+    for got, groups in zip(out[1:], (2, 4)):
+        assert got[4]["schedule"] == "speculative-wide" and got[4]["groups_per_replica"] == groups and got[4]["slots_per_round"] == groups
+        assert got[1] == ref[1] and np.array_equal(got[2], ref[2])
+        for k in ref[0]:
+            assert np.array_equal(got[0][k], ref[0][k], equal_nan=True), (groups, k)
+        for k in ref[3]:
+            assert np.array_equal(got[3][k], ref[3][k], equal_nan=True), (groups, k)
+
+
+@pytest.mark.gpu
+def test_wide_nets_group_count_is_checked():
+    """groups_per_replica of a wide net is 0 (auto: 4 or 2 where all work-groups are resident, else 1), 1, 2 or 4; a ladder that
+    cannot be resident is refused, never spun on."""
+    from ptnn_amd import _lib
+    rng = np.random.default_rng(1)
+    data = np.hstack([rng.uniform(0, 1, (40, 32)), rng.uniform(0, 1, (40, 1))])
+    kw = dict(first=0, S=20, si=10, use_lg=False, lr=0.1, seed=1)
+    with pytest.raises(_lib.PtnnError, match="0 \\(auto\\), 1, 2 or 4"):
+        parity.make_sampler(0, (32, 96, 1), data[:30], data[30:], R_local=2, R_global=2, groups=3, **kw)
+    with pytest.raises(_lib.PtnnError, match="resident"):
+        parity.make_sampler(0, (32, 96, 1), data[:30], data[30:], R_local=2048, R_global=2048, groups=4, **kw)
+    for R in (8, 2048):
+        s = parity.make_sampler(0, (32, 96, 1), data[:30], data[30:], R_local=R, R_global=R, **kw)
+        d = s.describe()
+        s.close()
+        cap = d["num_cus"] * d["blocks_per_cu"]
+        assert d["groups_per_replica"] == (4 if R == 8 else 1) and (d["groups_per_replica"] == 1 or d["groups_per_replica"] * R <= cap), d
+
+
 @pytest.mark.gpu
 def test_sharded_ladder_two_ranks_on_one_gpu():
     """ptnn_run on a sharded ladder with a REAL cross-process exchange on real device buffers: two processes share the one GPU
