@@ -80,6 +80,7 @@ struct SegParams {
     int G;                   // work-groups per replica (1 = no cross-CU exchange)
     unsigned epoch_base;     // granule tags of this launch are epoch_base + round
     int tree_ahead;          // tree schedule: LDS holds two sets of tapes, the next round's are drawn while the records travel
+    int wide_window;         // wide nets, several work-groups: steps per round (<= WIDE_WINDOW)
     unsigned long long* xverdict; // [Rl][2][MAX_SLOTS] one {tag, accepted?} granule per slot and round: all a foreign group polls
     unsigned long long* xslots;   // [Rl][2][MAX_SLOTS][16] result granules of an ACCEPTED slot (read by the other groups at commit)
     unsigned long long* xw;       // [Rl][2][MAX_SLOTS][2 PS] accepted-proposal granules
@@ -2242,7 +2243,7 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t wide_lds_floats(int H, int FWS, int O, int PS) {
     const size_t img = (fw_floats(H, FWS) > (size_t)PS) ? fw_floats(H, FWS) : (size_t)PS;   // packed or flat image
-    return img + MAX_WAVES * 8 + 2 * MAX_WAVES * (size_t)((O + 3) & ~3) + 16;
+    return img + MAX_WAVES * 8 + 2 * MAX_WAVES * (size_t)((O + 3) & ~3) + 16 + 6 * 8;   // + per-slot scalars of a window (WIDE_WINDOW = 8)
 }
 __host__ __device__ inline size_t wide_img_floats(int H, int FWS, int PS) {
     return (fw_floats(H, FWS) > (size_t)PS) ? fw_floats(H, FWS) : (size_t)PS;
@@ -2579,12 +2580,17 @@ __device__ __forceinline__ EvalSums wide_forward(const SegParams& p, const float
     return eval_rows<TASK, I, O>(img, p.data, p.IPY, p.FWS, p.H, p.Ntr, Nall, red);
 }
 
-// One work-group per replica (p.G == 1), or the speculative schedule over p.G work-groups (one per CU) as for the narrow nets:
-// group g computes step i + g assuming steps i .. i+g-1 reject, the prefix up to and including the first accepted step is
-// committed.  Wide nets accept 1 - 5 % of their proposals, so G groups commit almost G steps per round.  Every group keeps its
-// own copy of the chain vectors (group 0 the canonical rows, the others rows of the scratch buffer) and applies the same commits;
-// what crosses CUs are {tag, value} granules: one verdict per group and round, and -- only from a group whose step was accepted --
-// its record and its vectors (proposal, SGD epoch).
+// One work-group per replica (p.G == 1), or the speculative schedule over p.G work-groups (one per CU): a round covers a WINDOW
+// of up to WIDE_WINDOW steps, every one computed on the assumption that the steps before it reject, and the prefix up to and
+// including the first accepted step is committed.  Wide nets accept 1 - 5 % of their proposals, so almost whole windows are
+// committed.  A Langevin step costs five times a random-walk step here (its SGD epoch), and which step is which is on the tape:
+// every group replays the same greedy list scheduling of the window (next step to the group with the least work so far), so the
+// groups finish together instead of one sweeping while the other waits.  A group stops at its first accepted step (what it would
+// compute after it can never be committed) and, before each step, looks whether an earlier step of another group has been accepted.
+// Every group keeps its own copy of the chain vectors (group 0 the canonical rows, the others rows of the scratch buffer) and
+// applies the same commits; what crosses CUs are {tag, value} granules: one verdict per step, and -- only from the group whose step
+// was accepted -- its record and its vectors (proposal, SGD epoch).
+constexpr int WIDE_WINDOW = 8;
 template <int TASK, int I, int O>
 __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegParams p, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -2597,7 +2603,13 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
     float* fw = smem;
     float* red = fw + wide_img_floats(H, p.FWS, PS);
     float* part = red + MAX_WAVES * 8;
-    float* scal = part + 2 * MAX_WAVES * OP;                    // 16 floats: staging of an accepted foreign record
+    float* scal = part + 2 * MAX_WAVES * OP;                    // 16 floats: staging of an accepted foreign record; then per window slot:
+    float* s_u = scal + 16;                                     // the step's uniform
+    float* s_ne = s_u + WIDE_WINDOW;                            // its eta noise
+    float* s_lg = s_ne + WIDE_WINDOW;                           // its Langevin coin (0 / 1)
+    float* s_lik = s_lg + WIDE_WINDOW;                          // proposal likelihood of a step this group computed
+    float* s_la = s_lik + WIDE_WINDOW;                          // its log alpha
+    float* s_v = s_la + WIDE_WINDOW;                            // verdicts of the window: 0 rejected, 1 accepted, 2 never computed
     const float* xy = p.data;                                   // global (L2 / scalar cache)
     float* const mine = p.wide_scratch + (size_t)(r * G + grp) * 5 * PS;
     float* w_prop = mine;
@@ -2606,7 +2618,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
     float* w_gd = (grp == 0) ? p.gd_w + (size_t)r * PS : mine + 3 * (size_t)PS;
     float* rec_w = (grp == 0) ? p.rec_w + (size_t)r * PS : mine + 4 * (size_t)PS;
     if (grp > 0) {
-        // (group 0 touches the canonical rows at its first commit, which needs this group's first verdict)
+        // (group 0 touches the canonical rows at its first commit, which needs this group's first verdicts)
         for (int q = tid; q < PS / 4; q += nthr) {
             reinterpret_cast<float4*>(w_cur)[q] = reinterpret_cast<const float4*>(p.w_state + (size_t)r * PS)[q];
             reinterpret_cast<float4*>(w_gd)[q] = reinterpret_cast<const float4*>(p.gd_w + (size_t)r * PS)[q];
@@ -2640,13 +2652,14 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
     const size_t trow = (size_t)r * p.trace_cap;        // traces are rings of trace_cap rows per replica (== S unless streaming)
     const int end = step_begin + n_steps;
     const int nv = (P + 3) >> 2;
+    const int W = (G > 1) ? min(max(p.wide_window, G), WIDE_WINDOW) : 1;
     unsigned epoch = p.epoch_base;
     int par = 0;
     bool failed = false;
     int i = step_begin;
-    while (i < end) {
+    while (i < end && !failed) {
         epoch += 1;
-        int k = min(G, end - i);
+        int k = min(W, end - i);
         if (p.switch_step > i) k = min(k, p.switch_step - i);   // a round never straddles the temperature switch
         if (i == p.switch_step) {
             const EvalSums sc = wide_forward<TASK, I, O>(p, w_cur, fw, red);
@@ -2655,23 +2668,51 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
             lik = ll;
             __syncthreads();
         }
-        const int j = i + grp;                                 // my step
-        const bool active = grp < k;
         const float adapttemp = (p.switch_step >= 0 && i >= p.switch_step) ? 1.0f : T;
-        bool lg = false, accept = false;
-        float lik_prop = 0.f, prior_prop = 0.f, logalpha = 0.f, eta_pro = eta, rm_tr = 0.f, rm_te = 0.f, ac_tr = 0.f, ac_te = 0.f;
-        if (active) {
-            // the step's scalars {lx, u, n_eta}: every thread draws them itself (one Philox call) instead of one thread + a barrier
-            float lx, u, n_eta;
-            {
-                uint32_t x[4];
-                philox4x32_10(0u, (uint32_t)j, p.noise_shared ? 0u : (uint32_t)gid, STREAM_STEP, p.seed_lo, p.seed_hi, x);
-                float n2, n3;
-                box_muller(x[2], x[3], n2, n3);
-                lx = uni_f(u23(x[0])); u = uni_f(u23(x[1])); n_eta = uni_f(n2);
+        // the scalars {lx, u, n_eta} of the window's steps: one Philox call each
+        if (tid < k) {
+            uint32_t x[4];
+            philox4x32_10(0u, (uint32_t)(i + tid), p.noise_shared ? 0u : (uint32_t)gid, STREAM_STEP, p.seed_lo, p.seed_hi, x);
+            float n2, n3;
+            box_muller(x[2], x[3], n2, n3);
+            s_u[tid] = u23(x[1]); s_ne[tid] = n2;
+            s_lg[tid] = (p.use_lg && u23(x[0]) < p.l_prob) ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        // who computes which step: greedy list scheduling on the known costs, replayed identically by every group
+        unsigned my_steps = 0;
+        {
+            int load[4] = {0, 0, 0, 0};
+            for (int s_ = 0; s_ < k; ++s_) {
+                int g_ = 0;
+                for (int c = 1; c < G; ++c)
+                    if (load[c] < load[g_]) g_ = c;
+                load[g_] += (s_lg[s_] != 0.0f) ? 5 : 1;
+                if (g_ == grp) my_steps |= 1u << s_;
             }
+        }
+        bool stopped = false;
+        int my_acc = -1;                                        // my accepted step of this window, if any (then my last one)
+        bool a_lg = false;
+        float a_lik = 0.f, a_prior = 0.f, a_eta = 0.f, a_rm_tr = 0.f, a_rm_te = 0.f, a_ac_tr = 0.f, a_ac_te = 0.f;
+        for (int s_ = 0; s_ < k && !failed; ++s_) {
+            if (!((my_steps >> s_) & 1u)) continue;
+            if (G > 1 && !stopped) {                            // has an earlier step of another group been accepted in the meantime?
+                bool hit = false;
+                if (tid < s_) {
+                    const granule_t x = __hip_atomic_load(xv + (size_t)par * MAX_SLOTS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hit = ((unsigned)(x >> 32) == epoch) && (__builtin_bit_cast(float, (unsigned)x) == 1.0f);
+                }
+                if (__syncthreads_or(hit ? 1 : 0)) stopped = true;
+            }
+            if (stopped) {
+                if (tid == 0) granule_store(xv + (size_t)par * MAX_SLOTS + s_, epoch, 2.0f);
+                continue;
+            }
+            const int j = i + s_;
+            const bool lg = s_lg[s_] != 0.0f;
+            const float u = s_u[s_], n_eta = s_ne[s_];
             float diff_prop = 0.0f;
-            lg = p.use_lg && (lx < p.l_prob);
             if (lg && !gd_valid) {
                 sgd_sweep_wide<TASK, I, O>(w_cur, w_gd, xy, p.IPY, p.Ntr, H, p.lr, part);
                 gd_valid = 1;
@@ -2722,86 +2763,83 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
                 const float d2 = block_sum(nsq_part, red);
                 diff_prop = langevin_ratio(d1, d2, p.step_w, adapttemp);
             }
+            float eta_pro = eta;
             if (TASK == TASK_REG) eta_pro = fmaf(p.step_eta, n_eta, eta);
             const EvalSums es = wide_forward<TASK, I, O>(p, w_prop, fw, red, img_direct);
-            float ll;
+            float ll, rm_tr, rm_te, ac_tr, ac_te;
             finish_eval<TASK>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
-            lik_prop = ll / adapttemp;
+            const float lik_prop = ll / adapttemp;
             const float ssq = block_sum(ssq_part, red);
-            prior_prop = prior_value<TASK>(p, ssq, eta_pro);
-            logalpha = (lik_prop - lik) + (prior_prop - prior_cur) + diff_prop;
+            const float prior_prop = prior_value<TASK>(p, ssq, eta_pro);
+            const float logalpha = (lik_prop - lik) + (prior_prop - prior_cur) + diff_prop;
             const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
-            accept = u < mh;
-        }
-        // the first accepted step of the round
-        int m = k;
-        if (G == 1) {
-            if (accept) m = 0;
-        } else {
-            if (active && accept) {
-                // an accepted step publishes its record and its vectors; the other groups read them at commit, and only then
-                if (tid == 0) {
-                    granule_t* xr = xs + ((size_t)par * MAX_SLOTS + grp) * SL_COUNT;
-                    granule_store(xr + SL_LIKPROP, epoch, lik_prop); granule_store(xr + SL_PRIORPROP, epoch, prior_prop);
-                    granule_store(xr + SL_ETAPRO, epoch, eta_pro);
-                    granule_store(xr + SL_RM_TR, epoch, rm_tr); granule_store(xr + SL_RM_TE, epoch, rm_te);
-                    granule_store(xr + SL_AC_TR, epoch, ac_tr); granule_store(xr + SL_AC_TE, epoch, ac_te);
-                }
-                granule_t* xo = xw + ((size_t)par * G + grp) * 2 * PS;
-                for (int e = tid; e < P; e += nthr) {
-                    granule_store(xo + e, epoch, w_prop[e]);
-                    if (lg) granule_store(xo + PS + e, epoch, w_pgd[e]);
+            const bool accept = u < mh;
+            if (tid == 0) { s_lik[s_] = lik_prop; s_la[s_] = logalpha; }
+            if (accept) {
+                my_acc = s_; stopped = true;
+                a_lg = lg; a_lik = lik_prop; a_prior = prior_prop; a_eta = eta_pro;
+                a_rm_tr = rm_tr; a_rm_te = rm_te; a_ac_tr = ac_tr; a_ac_te = ac_te;
+                if (G > 1) {
+                    // an accepted step publishes its record and its vectors; the other groups read them at commit, and only then
+                    if (tid == 0) {
+                        granule_t* xr = xs + ((size_t)par * MAX_SLOTS + s_) * SL_COUNT;
+                        granule_store(xr + SL_LIKPROP, epoch, lik_prop); granule_store(xr + SL_PRIORPROP, epoch, prior_prop);
+                        granule_store(xr + SL_ETAPRO, epoch, eta_pro);
+                        granule_store(xr + SL_RM_TR, epoch, rm_tr); granule_store(xr + SL_RM_TE, epoch, rm_te);
+                        granule_store(xr + SL_AC_TR, epoch, ac_tr); granule_store(xr + SL_AC_TE, epoch, ac_te);
+                    }
+                    granule_t* xo = xw + ((size_t)par * G + grp) * 2 * PS;
+                    for (int e = tid; e < P; e += nthr) {
+                        granule_store(xo + e, epoch, w_prop[e]);
+                        if (lg) granule_store(xo + PS + e, epoch, w_pgd[e]);
+                    }
                 }
             }
-            if (tid == 0) granule_store(xv + (size_t)par * MAX_SLOTS + grp, epoch, (active && accept) ? 1.0f : 0.0f);
+            if (G > 1 && tid == 0) granule_store(xv + (size_t)par * MAX_SLOTS + s_, epoch, accept ? 1.0f : 0.0f);
+        }
+        // the first accepted step of the window
+        int m = k;
+        if (G == 1) {
+            if (my_acc == 0) m = 0;
+        } else {
             bool ok = true;
-            if (tid < G) {
+            if (tid < k) {
                 float v = 0.0f;
                 ok = granule_wait(xv + (size_t)par * MAX_SLOTS + tid, epoch, v);
-                scal[tid] = v;
+                s_v[tid] = v;
             }
             if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
             for (int s_ = k - 1; s_ >= 0; --s_)
-                if (scal[s_] != 0.0f) m = s_;
-            __syncthreads();                                    // scal[] is reused below
+                if (s_v[s_] == 1.0f) m = s_;
         }
         const int ncommit = (m < k) ? m + 1 : k;
-        // what the committed steps leave behind apart from the state: the Langevin count and the last PROPOSED eta -- both follow
-        // from the tape (every thread draws the scalars of the committed steps itself)
-        bool lg_m = false;
-        for (int s_ = 0; s_ < ncommit; ++s_) {
-            uint32_t x[4];
-            philox4x32_10(0u, (uint32_t)(i + s_), p.noise_shared ? 0u : (uint32_t)gid, STREAM_STEP, p.seed_lo, p.seed_hi, x);
-            float n2, n3;
-            box_muller(x[2], x[3], n2, n3);
-            const bool lg_s = p.use_lg && (uni_f(u23(x[0])) < p.l_prob);
-            lg_count += lg_s ? 1 : 0;
-            if (TASK == TASK_REG) tau_eta_last = fmaf(p.step_eta, uni_f(n2), eta);
-            if (s_ == m) lg_m = lg_s;
-        }
-        const bool acc_me = active && (grp == m);
+        // what the committed steps leave behind apart from the state: the Langevin count and the last PROPOSED eta
+        for (int s_ = 0; s_ < ncommit; ++s_) lg_count += (s_lg[s_] != 0.0f) ? 1 : 0;
+        if (TASK == TASK_REG) tau_eta_last = fmaf(p.step_eta, s_ne[ncommit - 1], eta);
+        const bool lg_m = (m < k) && (s_lg[m] != 0.0f);
+        const bool acc_me = (m < k) && (my_acc == m);
         const int acc_before = nacc;
-        __syncthreads();                                    // every reader of w_cur / w_gd of this round is done
-        // new chain scalars (an accepted foreign step: from its record)
-        if (m < k) {
-            if (!acc_me) {
-                bool ok = true;
-                if (G > 1 && tid < SL_COUNT && (tid == SL_LIKPROP || tid == SL_PRIORPROP || tid == SL_ETAPRO || tid == SL_RM_TR ||
-                                                 tid == SL_RM_TE || tid == SL_AC_TR || tid == SL_AC_TE)) {
-                    float v = 0.0f;
-                    ok = granule_wait(xs + ((size_t)par * MAX_SLOTS + m) * SL_COUNT + tid, epoch, v);
-                    scal[tid] = v;
-                }
-                if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
+        // new chain scalars of an accepted foreign step: from its record
+        if (m < k && !acc_me) {
+            bool ok = true;
+            if (tid < SL_COUNT && (tid == SL_LIKPROP || tid == SL_PRIORPROP || tid == SL_ETAPRO || tid == SL_RM_TR || tid == SL_RM_TE ||
+                                   tid == SL_AC_TR || tid == SL_AC_TE)) {
+                float v = 0.0f;
+                ok = granule_wait(xs + ((size_t)par * MAX_SLOTS + m) * SL_COUNT + tid, epoch, v);
+                scal[tid] = v;
             }
+            if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
         }
-        // trace row of my step, if it is committed: rows of PS / PW floats are 16-byte aligned and padded: whole float4s, the tail
-        // past P rewritten as it must be (trace row: zeros; state rows: the element at P is eta, restored at the end of the launch)
-        if (grp < ncommit) {
-            const size_t tpos = trow + (size_t)((j + 1) % p.trace_cap);
+        __syncthreads();                                    // every reader of w_cur / w_gd of this round is done
+        // trace rows of my committed steps: rows of PS / PW floats are 16-byte aligned and padded: whole float4s, the tail past P
+        // rewritten as it must be (trace row: zeros; state rows: the element at P is eta, restored at the end of the launch)
+        for (int s_ = 0; s_ < ncommit; ++s_) {
+            if (!((my_steps >> s_) & 1u)) continue;
+            const bool acc_row = acc_me && (s_ == m);
+            const size_t tpos = trow + (size_t)((i + s_ + 1) % p.trace_cap);
             float* prow = p.tr_pos_w + tpos * (size_t)p.PW;
             for (int e = 4 * nv + tid; e < p.PW; e += nthr) prow[e] = 0.0f;
-            const float* src = acc_me ? w_prop : rec_w;
+            const float* src = acc_row ? w_prop : rec_w;
             for (int q = tid; q < nv; q += nthr) {
                 float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
                 if (4 * q + 3 >= P) {                        // the last, partial quad: nothing past P
@@ -2812,18 +2850,19 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
                 *reinterpret_cast<float4*>(prow + 4 * q) = v;
             }
             if (tid == 0) {
-                store_trace_row(p.tr_scal + tpos * TR_COUNT, (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp,
-                                acc_me ? rm_tr : rec_rmse_tr, acc_me ? rm_te : rec_rmse_te, acc_me ? ac_tr : rec_acc_tr,
-                                acc_me ? ac_te : rec_acc_te, acc_before, logalpha);
+                const float lp = s_lik[s_];
+                store_trace_row(p.tr_scal + tpos * TR_COUNT, (TASK == TASK_REG) ? lp : lp * adapttemp,
+                                acc_row ? a_rm_tr : rec_rmse_tr, acc_row ? a_rm_te : rec_rmse_te, acc_row ? a_ac_tr : rec_acc_tr,
+                                acc_row ? a_ac_te : rec_acc_te, acc_before, s_la[s_]);
             }
         }
         if (m < k) {
             nacc += 1;
             gd_valid = lg_m ? 1 : 0;
+            __syncthreads();                                    // the trace rows above have read rec_w
             if (acc_me) {
-                lik = lik_prop; prior_cur = prior_prop; eta = eta_pro;
-                rec_rmse_tr = rm_tr; rec_rmse_te = rm_te; rec_acc_tr = ac_tr; rec_acc_te = ac_te;
-                __syncthreads();                                // the trace row above has read rec_w
+                lik = a_lik; prior_cur = a_prior; eta = a_eta;
+                rec_rmse_tr = a_rm_tr; rec_rmse_te = a_rm_te; rec_acc_tr = a_ac_tr; rec_acc_te = a_ac_te;
                 for (int q = tid; q < nv; q += nthr) {
                     float4 v = *reinterpret_cast<const float4*>(w_prop + 4 * q);
                     if (4 * q + 3 >= P) {
@@ -2833,13 +2872,24 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
                     }
                     *reinterpret_cast<float4*>(w_cur + 4 * q) = v;
                     *reinterpret_cast<float4*>(rec_w + 4 * q) = v;
-                    if (lg_m) *reinterpret_cast<float4*>(w_gd + 4 * q) = *reinterpret_cast<const float4*>(w_pgd + 4 * q);
+                    if (a_lg) *reinterpret_cast<float4*>(w_gd + 4 * q) = *reinterpret_cast<const float4*>(w_pgd + 4 * q);
                 }
             } else {
                 lik = scal[SL_LIKPROP]; prior_cur = scal[SL_PRIORPROP]; eta = scal[SL_ETAPRO];
                 rec_rmse_tr = scal[SL_RM_TR]; rec_rmse_te = scal[SL_RM_TE]; rec_acc_tr = scal[SL_AC_TR]; rec_acc_te = scal[SL_AC_TE];
-                __syncthreads();                                // the trace row above has read rec_w
-                const granule_t* xo = xw + ((size_t)par * G + m) * 2 * PS;
+                // the accepted step's group: replay the assignment
+                int owner = 0;
+                {
+                    int load[4] = {0, 0, 0, 0};
+                    for (int s_ = 0; s_ <= m; ++s_) {
+                        int g_ = 0;
+                        for (int c = 1; c < G; ++c)
+                            if (load[c] < load[g_]) g_ = c;
+                        load[g_] += (s_lg[s_] != 0.0f) ? 5 : 1;
+                        owner = g_;
+                    }
+                }
+                const granule_t* xo = xw + ((size_t)par * G + owner) * 2 * PS;
                 bool ok = true;
                 for (int e = tid; e < 4 * nv; e += nthr) {
                     float v = 0.0f, g_ = 0.0f;
