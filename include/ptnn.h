@@ -57,7 +57,8 @@ typedef struct ptnn_config {
                                    * chain; chosen automatically when replicas x 3 work-groups fit the GPU) */
     int32_t groups_per_replica;   /* speculative schedule: work-groups (CUs) cooperating on one replica; 0 = auto
                                    * (as many of 1, 2, 4 as keeps replicas x groups <= number of CUs).  Tree schedule: 3, 7, 15
-                                   * or 31 (0 = auto: the deepest tree up to 15 nodes that is resident) */
+                                   * or 31 (0 = auto: the deepest tree up to 15 nodes that is resident).  Wide nets (n_hidden > 64):
+                                   * 1, 2 or 4 work-groups speculating over windows of steps (0 = auto: 4 or 2 where resident) */
     int32_t trace_capacity;       /* rows per replica kept on the device (ring); 0 = all n_samples rows.  With a smaller
                                    * value the caller drains with ptnn_get_traces at least every trace_capacity steps */
     int32_t forward_bf16;         /* wide nets (n_hidden > 64, multiple of 32): 1 = forward-pass GEMM operands rounded to
