@@ -343,7 +343,7 @@ def main():
         extras["first_half"] = {"value": R * half / (tm - tb), "unit": "samples/s", "mh_steps": f"1..{half}"}
         extras["kept_half"] = {"value": R * (S - 1 - half) / (te - tm), "unit": "samples/s", "mh_steps": f"{half + 1}..{S - 1}",
                                "note": "the samples the reference keeps (burn_in 0.5, REG:949,1004)"}
-        if info["slots_per_round"] > 1 and wl["lg"] and S * R * 4 < (1 << 28):
+        if info["slots_per_round"] > 1 and wl["lg"] and wl["topo"][0] == 4 and wl["topo"][2] == 1 and S * R * 4 < (1 << 28):   # the 4-H-1 nets of the stamped epoch
             # 298 rows x 143 cycles per row measured with in-kernel stamps at the 2.4 GHz shader clock
             epoch_ms = train.shape[0] * 143 / 2.4e9 * 1e3
             extras["dependent_chain"] = dependent_chain(s.traces(pos_w=False)["accept"], si, info["slots_per_round"], epoch_ms)
