@@ -438,7 +438,8 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         // wide net: one thread per hidden unit, vectors in HBM, only the packed forward image + scratch in LDS
         const size_t lds = wide_lds_floats(H, h->FWS, h->cfg.n_out, h->PS) * sizeof(float);
         if (lds > 160 * 1024) return fail(-3, "wide net needs %zu B of LDS (> 160 KiB)", lds);
-        if (h->cfg.schedule == PTNN_SCHED_SPECULATIVE) return fail(-3, "the speculative schedule is built for n_hidden <= 64");
+        if (h->cfg.schedule == PTNN_SCHED_SPECULATIVE || h->cfg.schedule == PTNN_SCHED_PACKED || h->cfg.schedule == PTNN_SCHED_TREE)
+            return fail(-3, "schedules 2-4 are built for n_hidden <= 64; a wide net speculates over work-groups through groups_per_replica");
         h->wide = true; h->speculative = false; h->groups = 1;
         h->nthreads = ((H + WAVE - 1) / WAVE) * WAVE;
         h->model_threads = h->nthreads;

@@ -2239,7 +2239,7 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
 // 8 waves of the work-group.  The per-replica vectors (w, proposal, SGD results, noise: 70 KB each) no longer fit in LDS
 // next to each other, so they live in HBM/L2 and are streamed with coalesced accesses; LDS holds the packed forward image of
 // the proposal and the reduction scratch; the data set is read through the scalar cache (wave-uniform rows) in the sweep
-// and through L2 in the forward pass.  Cooperative schedule only.
+// and through L2 in the forward pass.  All waves of a work-group share one MH step; several work-groups per replica speculate over steps (segment_wide_kernel).
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t wide_lds_floats(int H, int FWS, int O, int PS) {
     const size_t img = (fw_floats(H, FWS) > (size_t)PS) ? fw_floats(H, FWS) : (size_t)PS;   // packed or flat image
