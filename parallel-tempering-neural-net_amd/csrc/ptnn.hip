@@ -1341,7 +1341,7 @@ int ptnn_describe(ptnn_handle* h, char* buf, int nbytes) {
     HIP_TRY(hipFuncGetAttributes(&fa, fn));
     const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
     // tree: the steps committed per round (its depth)
-    const int slots = h->tree ? tree_depth(h->groups) : (h->wide ? h->groups : !h->speculative ? 1 : (h->packed ? pack_slots(h->pk_nred) : h->groups * (h->nthreads / WAVE)));
+    const int slots = h->tree ? tree_depth(h->groups) : (h->wide ? (h->groups > 1 && h->cfg.use_langevin ? 8 : h->groups) : !h->speculative ? 1 : (h->packed ? pack_slots(h->pk_nred) : h->groups * (h->nthreads / WAVE)));
     const int n = std::snprintf(buf, (size_t)nbytes,
                                 "{\"kernel\": \"ptnn::%s<%d,%d,%d>\", \"schedule\": \"%s\", \"grid_blocks\": %d, \"block_threads\": %d, "
                                 "\"lds_bytes\": %zu, \"groups_per_replica\": %d, \"slots_per_round\": %d, \"num_cus\": %d, "
