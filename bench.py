@@ -294,6 +294,12 @@ def main():
         torch.cuda.set_device(device)
     else:
         device = local_rank
+    if sharded and a.transport == "host" and N > 1 and not a.schedule and not a.groups:
+        # the rehearsal puts every rank on GPU 0: schedules whose work-groups wait for each other size themselves for a whole GPU
+        if wl["topo"][1] > 64:
+            a.groups = 1
+        elif wl["task"] == 1 and not wl["lg"]:
+            a.schedule = 1
     lad = Ladder(wl, a, train, test, rank, N, device)
     s = lad.s
     if sharded:
