@@ -141,9 +141,18 @@ int ptnn_steps_done(ptnn_handle *h);
  * whatever rendezvous launched them; every rank then calls ptnn_comm_init(h, id, 128, rank, nranks) with
  * rank == first_global_replica / n_replicas_local (ncclCommInitRank on the handle's device: collective, blocks until all
  * ranks have joined).  librccl.so is loaded on the first call (dlopen; $PTNN_RCCL_LIBRARY overrides the path), so single-GPU
- * users never load it.  Collectives run on the handle's own stream. */
+ * users never load it.  Collectives run on the handle's own stream.
+ * Nothing here blocks for ever (the reference's parent polls is_alive() each round, REG:721-727): loading the library,
+ * ncclGetUniqueId and ncclCommInitRank run on a helper thread that is abandoned after $PTNN_COMM_TIMEOUT_S seconds (default 120),
+ * and every wait behind a collective (ptnn_sync, the getters, the boundary exchange's per-round wait) gives up when the stream
+ * is busy but the device has completed no swap round for that long; all of them return -7 with the stage that stalled.
+ * Unless $PTNN_COMM_KEEP_ENV=1, the first call sets NCCL_SOCKET_IFNAME=lo and NCCL_IB_DISABLE=1 when they are unset: the
+ * ladder is sharded inside one node, so the bootstrap needs neither a routable interface nor a verbs probe. */
 int ptnn_comm_unique_id(void *id_out, int nbytes);
 int ptnn_comm_init(ptnn_handle *h, const void *unique_id, int nbytes, int rank, int nranks);
+/* the last stage a communicator bring-up / exchange entered in this process, as text ("ncclCommInitRank(rank 0 of 1, device 0)
+ * (entered 0.4 s ago)"); $PTNN_COMM_TRACE=1 prints every stage to stderr as it is entered.  Returns the length written. */
+int ptnn_comm_last_stage(char *buf, int nbytes);
 
 /* Host-staged transport: the library stages through pinned host memory and calls back.  For fabrics other than RCCL and
  * for tests (RCCL refuses two ranks on one device; a one-GPU box rehearses the N > 1 path with this).

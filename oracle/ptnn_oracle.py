@@ -310,8 +310,10 @@ class Replica:
             return likelihood_reg(data, w, tau, self.topo, self.adapttemp, self.faithful)
         return likelihood_cls(data, w, self.topo, self.adapttemp, self.faithful)
 
-    def step(self, i):
-        """Loop body for index i (REG:313-423 / CLS:313-434)."""
+    def step(self, i, force=None):
+        """Loop body for index i (REG:313-423 / CLS:313-434).  force = None: the chain decides for itself (the reference's
+        behaviour); True / False: the decision is imposed -- used by tests that FOLLOW the device's chain past a decision the
+        two sides took differently inside the fp32 error of log alpha; `last_natural` keeps what this chain would have done."""
         if i < self.pt_samples:
             self.adapttemp = self.T
         if i == self.pt_samples and self.init_count == 0:   # R10/Q9: stale tau_pro, float-equality trigger
@@ -360,7 +362,10 @@ class Replica:
         # size of the terms log alpha is the small difference of (the parity tests state fp32 error bounds relative to it)
         self.last_scale = (abs(lik_prop) + abs(self.likelihood) + abs(prior_prop) + abs(self.prior_current) +
                            ((abs(first) + abs(second)) / self.adapttemp if diff_prop != 0 else 0.0))
-        if u < mh_prob:
+        self.last_natural = bool(u < mh_prob)
+        take = self.last_natural if force is None else bool(force)
+        self.last_forced = take != self.last_natural
+        if take:
             self.num_accepted += 1
             self.lik_stale = False
             self.likelihood = lik_prop
@@ -488,7 +493,9 @@ class PTOracle:
                     out[k][t, row0:row1] = getattr(rep, k)[row0:row1]
         return out
 
-    def swap_round(self, L=None, apply=True):
+    def swap_round(self, L=None, apply=True, force_src=None):
+        """force_src: impose this permutation instead of the cascade's own (tests that follow the device's chain; the caller has
+        checked every pair decision in which the two differ); the scalars the round decided on are logged either way."""
         if self.swap_rule == 1:
             return self.swap_round_even_odd()
         R = self.R
@@ -496,6 +503,10 @@ class PTOracle:
             L = [rep.posted_L() for rep in self.replicas]
         u = self.tape.swap_uniforms(self.rounds_done, R - 1)
         src, nsw = swap_cascade(L, u)
+        self.last_natural_src = list(src)
+        if force_src is not None:
+            src = [int(v) for v in force_src]
+            nsw = sum(1 for k in range(R - 1) if src[k] == k + 1)
         self.num_swap += nsw
         self.total_swap_proposals += R - 1
         self.rounds_done += 1

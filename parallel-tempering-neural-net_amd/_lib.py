@@ -57,6 +57,7 @@ SYMBOLS = {
     "ptnn_steps_done": (C.c_int, [C.c_void_p]),
     "ptnn_comm_unique_id": (C.c_int, [C.c_void_p, C.c_int]),
     "ptnn_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "ptnn_comm_last_stage": (C.c_int, [C.c_char_p, C.c_int]),
     "ptnn_comm_init_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ptnn_comm_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "ptnn_comm_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _ip]),
@@ -127,6 +128,14 @@ def comm_unique_id():
     if lib.ptnn_comm_unique_id(buf, UNIQUE_ID_BYTES) < 0:
         raise PtnnError(lib.ptnn_last_error().decode())
     return buf.raw
+
+
+def comm_last_stage():
+    """The last stage a communicator bring-up / exchange entered in this process (text), for error reports."""
+    lib = load_library()
+    buf = C.create_string_buffer(256)
+    lib.ptnn_comm_last_stage(buf, 256)
+    return buf.value.decode()
 
 
 def route(src, n_local, rank):

@@ -16,7 +16,9 @@
 #include <unordered_map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+#include <sched.h>
 
 using namespace ptnn;
 
@@ -87,6 +89,9 @@ struct ptnn_handle {
     int num_cus = 0;
     unsigned long long *d_xslots = nullptr, *d_xw = nullptr, *d_xverdict = nullptr;
     int* d_error = nullptr;
+    int* h_progress = nullptr;      // pinned host word: swap rounds the device has completed (swap_kernel stores it)
+    bool failed = false;            // a run on this handle ended in an error (-5 / -7): results are refused until the chains restart
+    std::string failure;
     unsigned long long* d_stamps = nullptr;
     bool have_data = false, have_state = false, finalized = false;
     int cap = 0;            // trace ring rows per replica
@@ -156,6 +161,8 @@ struct ptnn_handle {
 
 namespace {
 
+int wait_stream(ptnn_handle* h);
+
 inline int tree_depth(int groups) { int d = 0; while ((1 << (d + 1)) - 1 <= groups) ++d; return d; }   // groups = 2^d - 1
 
 // Q10: REG hands off after step i when i % si == 0 and i != 0 (REG:427); CLS when (i+1) % si == 0 (CLS:438)
@@ -191,7 +198,7 @@ int launch_segment(ptnn_handle* h, int begin, int n) {
     }
     if (h->timing_used == h->timing.size()) {
         if (h->timing.size() >= 4096) {               // keep the pool bounded: drain it (synchronises)
-            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (int rc = wait_stream(h)) return rc;
             collect_timing(h);
         } else {
             hipEvent_t a, b;
@@ -234,6 +241,7 @@ int launch_swap(ptnn_handle* h, bool phantom, int mode, bool want_src) {
     sp.label_cur = h->d_label[h->lflip]; sp.slot_cur = h->d_slot_of[h->lflip];
     sp.label_next = h->d_label[h->lflip ^ 1]; sp.slot_next = h->d_slot_of[h->lflip ^ 1];
     sp.temps_local = h->d_temps;
+    sp.progress = (mode & 2) ? h->h_progress : nullptr;     // the counting pass of a round is its last kernel
     if (mode == -1) {
         hipLaunchKernelGGL(xchg_pack_kernel, dim3(sp.Rl), dim3(64), 0, h->stream, sp);
         HIP_TRY(hipGetLastError());
@@ -261,6 +269,53 @@ int raise_lds_limit(const void* func, size_t bytes) {
     if (bytes > cur) {
         HIP_TRY(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         cur = bytes;
+    }
+    return 0;
+}
+
+// Wait for everything queued on the handle's stream.  With an RCCL communicator attached the wait is bounded: a collective
+// whose peer never arrives would otherwise block the host for ever (the reference's parent at least polls is_alive() every
+// round, REG:721-727).  "No progress" = the stream is busy and the device has not completed a swap round (swap_kernel stores the
+// round count into a pinned host word) for comm_timeout_s() seconds; a long segment between two rounds is far below that.
+int wait_stream(ptnn_handle* h) {
+    if (h->comm.kind != COMM_RCCL) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return 0;
+    }
+    const double limit = comm_timeout_s();
+    volatile int* prog = h->h_progress;
+    int seen = *prog;
+    double t_seen = comm_clock();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) return fail(-2, "hipStreamQuery failed: %s", hipGetErrorString(q));
+        const int now = *prog;
+        if (now != seen) { seen = now; t_seen = comm_clock(); }
+        else if (comm_clock() - t_seen > limit) {
+            h->failed = true; h->comm.failed = true;
+            h->failure = "no progress on the handle's stream for " + std::to_string((int)limit) + " s with " + std::to_string(seen) +
+                         " of " + std::to_string(h->rounds_done) + " queued swap rounds completed on the device; last communicator stage: " +
+                         comm_last_stage();
+            return fail(-7, "%s", h->failure.c_str());
+        }
+        if (spins < 4096) sched_yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
+}
+
+// wait_stream + the device's error flag: a bounded spin that expired inside a segment kernel invalidates the run
+int finish_stream(ptnn_handle* h) {
+    if (h->failed) return fail(h->failure.find("no progress") == 0 ? -7 : -5, "%s", h->failure.c_str());
+    if (int rc = wait_stream(h)) return rc;
+    int err = 0;
+    HIP_TRY(hipMemcpy(&err, h->d_error, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) {
+        h->failed = true;
+        h->failure = "a cross-work-group hand-off timed out inside the segment kernel (" + std::to_string(err) +
+                     " work-groups gave up); the run is invalid -- restart the chains (ptnn_set_state / ptnn_checkpoint_load); schedules "
+                     "with several work-groups per replica expect the GPU to themselves";
+        return fail(-5, "%s", h->failure.c_str());
     }
     return 0;
 }
@@ -319,6 +374,8 @@ int create_buffers(ptnn_handle* h, const ptnn_config* cfg, const Shape* sh, cons
     HIP_TRY(hipMalloc(&h->d_src_log, (size_t)h->max_rounds * R * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_counters, 2 * sizeof(long long)));
     HIP_TRY(hipMalloc(&h->d_error, sizeof(int)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_progress), sizeof(int), hipHostMallocDefault));
+    *h->h_progress = 0;
     HIP_TRY(hipMalloc(&h->d_stamps, 160 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(h->d_stamps, 0, 160 * sizeof(unsigned long long), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_error, 0, sizeof(int), h->stream));
@@ -385,13 +442,21 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
 int ptnn_destroy(ptnn_handle* h) {
     if (!h) return 0;
     (void)hipSetDevice(h->cfg.device_id);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    h->comm.release();
+    if (h->stream && !h->comm.failed) (void)wait_stream(h);
+    h->comm.release();                                       // a failed communicator is aborted: its kernels leave the stream
+    if (h->comm.failed && h->stream) {
+        // give the aborted collective a few seconds to drain; if the stream still does not empty, leak the handle rather than
+        // block in hipFree for ever
+        const double t0 = comm_clock();
+        while (hipStreamQuery(h->stream) == hipErrorNotReady && comm_clock() - t0 < 5.0) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        if (hipStreamQuery(h->stream) == hipErrorNotReady) return fail(-7, "the stream of a failed communicator did not drain: handle leaked");
+    }
     void* ptrs[] = {h->d_data, h->d_state[0], h->d_state[1], h->d_rec_w, h->d_gd_w[0], h->d_gd_w[1], h->d_gd_valid[0], h->d_gd_valid[1], h->d_st_f, h->d_st_i, h->d_temps,
                     h->d_L_handoff, h->d_L_final, h->d_L_raw, h->d_prior_post, h->d_temps_global, h->d_pos_w, h->d_scal, h->d_src, h->d_label[0], h->d_label[1], h->d_slot_of[0], h->d_slot_of[1], h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_xverdict, h->d_stamps, h->d_wide_scratch, h->d_xt};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_src) (void)hipHostFree(h->h_src);
+    if (h->h_progress) (void)hipHostFree(h->h_progress);
     if (h->d_xchg) (void)hipFree(h->d_xchg);
     for (auto& ev : h->timing) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -668,7 +733,7 @@ int ptnn_set_state(ptnn_handle* h, const float* w0, const float* temperatures) {
     if (!h || !w0 || !temperatures) return fail(-1, "null argument");
     if (!h->have_data) return fail(-1, "call ptnn_set_data before ptnn_set_state");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    HIP_TRY(hipStreamSynchronize(h->stream));                // a restart must not overtake a run still in flight
+    if (int rc = wait_stream(h)) return rc;                // a restart must not overtake a run still in flight
     const int Rl = h->cfg.n_replicas_local, P = h->P, PS = h->PS, S = h->cap;
     std::vector<float> st((size_t)Rl * PS, 0.0f), ones((size_t)Rl * PS, 1.0f);
     for (int r = 0; r < Rl; ++r) std::memcpy(&st[(size_t)r * PS], w0 + (size_t)r * P, P * sizeof(float));
@@ -693,6 +758,9 @@ int ptnn_set_state(ptnn_handle* h, const float* w0, const float* temperatures) {
                         hipMemcpyHostToDevice));
     h->flip = 0; h->cur = 0; h->rounds_done = 0; h->finalized = false; h->drained = 0; h->first_row = 0;
     HIP_TRY(hipMemset(h->d_counters, 0, 2 * sizeof(long long)));
+    HIP_TRY(hipMemset(h->d_error, 0, sizeof(int)));           // a restart clears a failed run (a failed communicator stays failed)
+    if (!h->comm.failed) { h->failed = false; h->failure.clear(); }
+    *h->h_progress = 0;
     {
         std::vector<int> ident(h->cfg.n_replicas_global);
         for (size_t k = 0; k < ident.size(); ++k) ident[k] = (int)k;
@@ -757,7 +825,7 @@ static int comm_swap_round(ptnn_handle* h, bool phantom) {
         } else {
             if (int rc = launch_swap(h, false, 0, true)) return rc;                     // cascade only: src[R]
             HIP_TRY(hipMemcpyAsync(h->h_src, h->d_src, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));                                   // the one host wait of this mode
+            if (int rc = wait_stream(h)) return rc;                                   // the one host wait of this mode
             route_rows(h->h_src, R, Rl, c.rank, h->route);
             float* cur = h->d_state[h->flip];
             float* next = h->d_state[h->flip ^ 1];
@@ -840,9 +908,17 @@ int ptnn_comm_unique_id(void* id_out, int nbytes) {
     std::string why;
     const RcclApi* api = rccl_api(why);
     if (!api) return fail(-7, "cannot load RCCL: %s", why.c_str());
-    ncclUniqueId id;
-    const ncclResult_t r = api->GetUniqueId(&id);
-    if (r != ncclSuccess) return fail(-7, "ncclGetUniqueId failed: %s", api->GetErrorString(r));
+    // static storage: the helper thread may outlive this call when the stage is abandoned
+    static ncclUniqueId id;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    comm_stage("ncclGetUniqueId");
+    int r = 0;
+    if (!run_bounded([api]() -> int { return (int)api->GetUniqueId(&id); }, comm_timeout_s(), &r))
+        return fail(-7, "ncclGetUniqueId did not return within %d s (it opens the bootstrap listener: NCCL_SOCKET_IFNAME=%s)",
+                    (int)comm_timeout_s(), std::getenv("NCCL_SOCKET_IFNAME") ? std::getenv("NCCL_SOCKET_IFNAME") : "unset");
+    if (r != (int)ncclSuccess) return fail(-7, "ncclGetUniqueId failed: %s", api->GetErrorString((ncclResult_t)r));
+    comm_stage("ncclGetUniqueId done");
     std::memcpy(id_out, &id, sizeof id);
     return (int)sizeof id;
 }
@@ -854,13 +930,32 @@ int ptnn_comm_init(ptnn_handle* h, const void* unique_id, int nbytes, int rank, 
     const RcclApi* api = rccl_api(why);
     if (!api) return fail(-7, "cannot load RCCL: %s", why.c_str());
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    ncclUniqueId id;
-    std::memcpy(&id, unique_id, sizeof id);
-    ncclComm_t comm = nullptr;
-    const ncclResult_t r = api->CommInitRank(&comm, nranks, id, rank);
-    if (r != ncclSuccess) return fail(-7, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, nranks, h->cfg.device_id, api->GetErrorString(r));
-    h->comm.api = api; h->comm.nccl = comm; h->comm.rank = rank; h->comm.nranks = nranks; h->comm.kind = COMM_RCCL;
+    // ncclCommInitRank is a collective: it returns when all nranks have joined.  A peer that never does (it failed before, or was
+    // never started) would block this thread for ever, so the call runs on a helper that is abandoned after comm_timeout_s().
+    struct Job { ncclUniqueId id; ncclComm_t comm = nullptr; };
+    auto job = std::make_shared<Job>();
+    std::memcpy(&job->id, unique_id, sizeof job->id);
+    const int dev = h->cfg.device_id;
+    comm_stage("ncclCommInitRank(rank %d of %d, device %d)", rank, nranks, dev);
+    int r = 0;
+    const bool finished = run_bounded([api, job, dev, rank, nranks]() -> int {
+        if (hipSetDevice(dev) != hipSuccess) return (int)ncclUnhandledCudaError;
+        return (int)api->CommInitRank(&job->comm, nranks, job->id, rank);
+    }, comm_timeout_s(), &r);
+    if (!finished)
+        return fail(-7, "ncclCommInitRank(rank %d of %d, device %d) did not return within %d s: a rank never joined, or the bring-up "
+                        "stalled ($PTNN_COMM_TRACE=1 and NCCL_DEBUG=INFO show where)", rank, nranks, dev, (int)comm_timeout_s());
+    if (r != (int)ncclSuccess) return fail(-7, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, nranks, dev, api->GetErrorString((ncclResult_t)r));
+    comm_stage("ncclCommInitRank done (rank %d of %d)", rank, nranks);
+    h->comm.api = api; h->comm.nccl = job->comm; h->comm.rank = rank; h->comm.nranks = nranks; h->comm.kind = COMM_RCCL;
     return 0;
+}
+
+int ptnn_comm_last_stage(char* buf, int nbytes) {
+    if (!buf || nbytes < 1) return fail(-1, "bad argument");
+    const std::string s = comm_last_stage();
+    std::snprintf(buf, (size_t)nbytes, "%s", s.c_str());
+    return (int)std::min<size_t>(s.size(), (size_t)nbytes - 1);
 }
 
 int ptnn_comm_init_host(ptnn_handle* h, int rank, int nranks, ptnn_all_gather_fn all_gather, ptnn_send_recv_fn send_recv, void* ctx) {
@@ -892,9 +987,10 @@ int ptnn_comm_stats(ptnn_handle* h, int64_t* bytes_sent, int64_t* bytes_received
 int ptnn_comm_finalize(ptnn_handle* h) {
     if (!h) return fail(-1, "null handle");
     (void)hipSetDevice(h->cfg.device_id);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    int rc = 0;
+    if (h->stream && !h->comm.failed) rc = wait_stream(h);
     h->comm.release();
-    return 0;
+    return rc;
 }
 
 int ptnn_route(const int32_t* src, int n_global, int n_local, int rank, int32_t* msg, int max_msgs) {
@@ -914,12 +1010,8 @@ int ptnn_route(const int32_t* src, int n_global, int n_local, int rank, int32_t*
 int ptnn_sync(ptnn_handle* h) {
     if (!h) return fail(-1, "null handle");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = finish_stream(h)) return rc;
     collect_timing(h);
-    int err = 0;
-    HIP_TRY(hipMemcpy(&err, h->d_error, sizeof(int), hipMemcpyDeviceToHost));
-    if (err) return fail(-5, "a cross-work-group hand-off timed out inside the segment kernel (%d work-groups gave up); "
-                             "the run is invalid", err);
     return 0;
 }
 
@@ -956,7 +1048,7 @@ int ptnn_swap_L_ptr(ptnn_handle* h, int phantom, void** dev_ptr) {
 int ptnn_swap_set_L(ptnn_handle* h, int phantom, const float* L_host) {
     if (!h || !L_host) return fail(-1, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = wait_stream(h)) return rc;
     HIP_TRY(hipMemcpy(phantom ? h->d_L_final : h->d_L_handoff, L_host, h->cfg.n_replicas_global * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
@@ -968,7 +1060,7 @@ int ptnn_swap_cascade(ptnn_handle* h, int phantom, int32_t* src_host) {
     if (int rc = launch_swap(h, phantom != 0, 0, true)) return rc;
     const size_t bytes = h->cfg.n_replicas_global * sizeof(int);
     HIP_TRY(hipMemcpyAsync(h->h_src, h->d_src, bytes, hipMemcpyDeviceToHost, h->stream));   // pinned: no staging copy
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = wait_stream(h)) return rc;
     std::memcpy(src_host, h->h_src, bytes);
     return 0;
 }
@@ -1032,7 +1124,7 @@ int ptnn_get_traces(ptnn_handle* h, int step0, int nsteps, float* pos_w, float* 
     if (step0 < h->first_row) return fail(-1, "rows below %d were produced before the checkpoint these chains were restored from", h->first_row);
     if (step0 < h->cur + 1 - cap) return fail(-1, "row %d has already been overwritten in the trace ring (capacity %d, %d steps done)", step0, cap, h->cur);
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = finish_stream(h)) return rc;
     collect_timing(h);
     // the range may wrap around the ring: at most two contiguous pieces
     auto copy2d = [&](void* dst, const void* src_base, size_t elem_bytes, size_t per_step) -> hipError_t {
@@ -1094,7 +1186,7 @@ int ptnn_get_trace_rows(ptnn_handle* h, int step0, int nsteps, float* rows) {
     if (step0 + nsteps > h->cur + 1) return fail(-1, "rows up to %d requested but only %d MH steps have been queued", step0 + nsteps - 1, h->cur);
     if (step0 < h->first_row || step0 < h->cur + 1 - cap) return fail(-1, "row %d is no longer (or was never) on this device", step0);
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = finish_stream(h)) return rc;
     const size_t rowb = TR_COUNT * sizeof(float);
     int done = 0;
     while (done < nsteps) {                                  // the range may wrap around the ring
@@ -1111,7 +1203,7 @@ int ptnn_get_trace_rows(ptnn_handle* h, int step0, int nsteps, float* rows) {
 int ptnn_get_swap_stats(ptnn_handle* h, int64_t* num_swap, int64_t* total_proposals, int32_t* rounds_done) {
     if (!h) return fail(-1, "null handle");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = finish_stream(h)) return rc;
     long long c[2];
     HIP_TRY(hipMemcpy(c, h->d_counters, sizeof c, hipMemcpyDeviceToHost));
     if (num_swap) *num_swap = c[0];
@@ -1123,7 +1215,7 @@ int ptnn_get_swap_stats(ptnn_handle* h, int64_t* num_swap, int64_t* total_propos
 int ptnn_get_labels(ptnn_handle* h, int32_t* label) {
     if (!h || !label) return fail(-1, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = finish_stream(h)) return rc;
     HIP_TRY(hipMemcpy(label, h->d_label[h->lflip], (size_t)h->cfg.n_replicas_global * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
 }
@@ -1131,7 +1223,7 @@ int ptnn_get_labels(ptnn_handle* h, int32_t* label) {
 int ptnn_get_swap_log(ptnn_handle* h, int32_t* src, int max_rounds) {
     if (!h || !src) return fail(-1, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = finish_stream(h)) return rc;
     const int n = std::min(max_rounds, std::min(h->rounds_done, h->max_rounds));
     if (n > 0) HIP_TRY(hipMemcpy(src, h->d_src_log, (size_t)n * h->cfg.n_replicas_global * sizeof(int), hipMemcpyDeviceToHost));
     return n;
@@ -1141,7 +1233,7 @@ int ptnn_get_state(ptnn_handle* h, float* w, float* eta, float* likelihood, floa
                    int32_t* langevin_count, int32_t* langevin_accepted) {
     if (int rc = check_ready(h)) return rc;
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = finish_stream(h)) return rc;
     const int Rl = h->cfg.n_replicas_local, P = h->P, PS = h->PS;
     std::vector<float> st((size_t)Rl * PS), sf((size_t)Rl * SF_COUNT);
     std::vector<int> si((size_t)Rl * SI_COUNT);
@@ -1199,7 +1291,7 @@ int ptnn_checkpoint_save(ptnn_handle* h, void* buf, int64_t bytes) {
     if (int rc = check_ready(h)) return rc;
     if (!buf || bytes < (int64_t)ck_bytes(h)) return fail(-1, "checkpoint buffer too small: %lld < %zu", (long long)bytes, ck_bytes(h));
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = finish_stream(h)) return rc;
     const size_t Rl = h->cfg.n_replicas_local, R = h->cfg.n_replicas_global, PS = h->PS;
     CkHeader hd{};
     hd.magic = CK_MAGIC; hd.version = 2; hd.cfg = h->cfg; hd.P = h->P; hd.PS = h->PS; hd.cur = h->cur;
@@ -1241,7 +1333,7 @@ int ptnn_checkpoint_load(ptnn_handle* h, const void* buf, int64_t bytes) {
     if (!same_chain(hd.cfg, h->cfg) || hd.P != h->P || hd.PS != h->PS)
         return fail(-1, "the checkpoint was written by chains with a different configuration (topology, replicas, samples, seed ...)");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = wait_stream(h)) return rc;
     const size_t Rl = h->cfg.n_replicas_local, R = h->cfg.n_replicas_global, PS = h->PS;
     const size_t need = sizeof(CkHeader) + sizeof(float) * (3 * Rl * PS + Rl * SF_COUNT + Rl + 5 * R) +
                         sizeof(int) * (Rl + Rl * SI_COUNT + (size_t)hd.log_rounds * R + 2 * R);
@@ -1274,6 +1366,9 @@ int ptnn_checkpoint_load(ptnn_handle* h, const void* buf, int64_t bytes) {
     HIP_TRY(hipMemcpy(h->d_counters, hd.counters, sizeof(hd.counters), hipMemcpyHostToDevice));
     h->cur = hd.cur; h->rounds_done = hd.rounds_done; h->finalized = hd.finalized != 0; h->have_ladder = hd.have_ladder != 0;
     h->drained = hd.cur; h->first_row = hd.cur + 1;
+    HIP_TRY(hipMemset(h->d_error, 0, sizeof(int)));
+    if (!h->comm.failed) { h->failed = false; h->failure.clear(); }
+    *h->h_progress = hd.rounds_done;
     h->have_state = true;
     return 0;
 }
@@ -1299,7 +1394,7 @@ static int run_model(ptnn_handle* h, int mode, const float* w_in, const float* t
     hipLaunchKernelGGL(h->wide ? h->shape->model_wide : h->shape->model, dim3(n), dim3(h->model_threads), h->model_lds, h->stream, p,
                        mode, d_w, d_tau, d_out, a0, a1);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = wait_stream(h)) return rc;
     HIP_TRY(hipMemcpy(out, d_out, out_floats * sizeof(float), hipMemcpyDeviceToHost));
     if (d_w) (void)hipFree(d_w);
     if (d_tau) (void)hipFree(d_tau);
@@ -1358,7 +1453,7 @@ int ptnn_describe(ptnn_handle* h, char* buf, int nbytes) {
 int ptnn_kernel_time(ptnn_handle* h, int reset, int64_t* launches, double* total_ms) {
     if (!h) return fail(-1, "null handle");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = wait_stream(h)) return rc;
     collect_timing(h);
     if (launches) *launches = h->timed_launches;
     if (total_ms) *total_ms = h->timed_ms;
@@ -1369,7 +1464,7 @@ int ptnn_kernel_time(ptnn_handle* h, int reset, int64_t* launches, double* total
 int ptnn_debug_stamps(ptnn_handle* h, uint64_t* out16) {   // 160 entries: 16 phase sums + 64 x (cycles, rounds)
     if (!h || !out16) return fail(-1, "null argument");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = wait_stream(h)) return rc;
     HIP_TRY(hipMemcpy(out16, h->d_stamps, 160 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(h->d_stamps, 0, 160 * sizeof(unsigned long long)));
     const unsigned long long big = ~0ull;

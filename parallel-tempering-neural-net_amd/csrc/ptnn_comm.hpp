@@ -8,21 +8,95 @@
 #include <rccl/rccl.h>      // types and prototypes only: the library itself is dlopen'ed by the first ptnn_comm_init
 #include <dlfcn.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <cstdarg>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+#include <unistd.h>
 
 #include "../../include/ptnn.h"
 
 namespace ptnn {
+
+// ---- progress stamps and bounded waits --------------------------------------------------------------------------------
+// Every step of bringing a communicator up (dlopen of the 570 MB librccl, ncclGetUniqueId, ncclCommInitRank) and every wait
+// behind a collective is stamped and bounded, so that a stall names its stage instead of hanging the caller: the reference's
+// parent at least polls is_alive() every round (REG:721-727).  $PTNN_COMM_TRACE=1 prints the stamps to stderr as they happen;
+// the last one is always kept and goes into the error text of a timeout (and ptnn_comm_last_stage).
+inline double comm_clock() {
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+struct CommStageLog {
+    std::mutex mu;
+    char last[192] = "none";
+    double t_last = 0.0;
+};
+inline CommStageLog& comm_stage_log() { static CommStageLog l; return l; }
+inline void comm_stage(const char* fmt, ...) {
+    char buf[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    const double t = comm_clock();
+    static const bool trace = [] { const char* e = std::getenv("PTNN_COMM_TRACE"); return e && *e && *e != '0'; }();
+    CommStageLog& l = comm_stage_log();
+    {
+        std::lock_guard<std::mutex> lock(l.mu);
+        snprintf(l.last, sizeof l.last, "%s", buf);
+        l.t_last = t;
+    }
+    if (trace) { fprintf(stderr, "[ptnn comm %9.3f s pid %d] %s\n", t, (int)getpid(), buf); fflush(stderr); }
+}
+inline std::string comm_last_stage() {
+    CommStageLog& l = comm_stage_log();
+    std::lock_guard<std::mutex> lock(l.mu);
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s (entered %.1f s ago)", l.last, comm_clock() - l.t_last);
+    return buf;
+}
+// seconds a communicator stage may take before the call gives up with error -7: $PTNN_COMM_TIMEOUT_S, default 120 (a cold
+// dlopen + ncclCommInitRank takes 2 - 6 s on the MI355X boxes, profiles/r03_rccl_init_timeline.txt)
+inline double comm_timeout_s() {
+    if (const char* e = std::getenv("PTNN_COMM_TIMEOUT_S")) { const double v = std::atof(e); if (v > 0.0) return v; }
+    return 120.0;
+}
+// Runs f() on a helper thread and waits for it at most timeout_s.  Returns true when f finished (its value in *result).
+// On a timeout the helper is left behind (a blocked dlopen / ncclCommInitRank cannot be cancelled from outside) and the
+// caller reports the stage; the process is expected to end soon after such an error.
+template <class F>
+inline bool run_bounded(F f, double timeout_s, int* result) {
+    struct St { std::mutex mu; std::condition_variable cv; bool done = false; int value = 0; };
+    auto st = std::make_shared<St>();
+    std::thread t([st, f]() mutable {
+        const int v = f();
+        std::lock_guard<std::mutex> lock(st->mu);
+        st->value = v; st->done = true;
+        st->cv.notify_all();
+    });
+    std::unique_lock<std::mutex> lock(st->mu);
+    const bool ok = st->cv.wait_for(lock, std::chrono::duration<double>(timeout_s), [&] { return st->done; });
+    if (ok) { *result = st->value; lock.unlock(); t.join(); return true; }
+    lock.unlock();
+    t.detach();
+    return false;
+}
 
 struct RcclApi {
     void* lib = nullptr;
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
@@ -31,8 +105,25 @@ struct RcclApi {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
-// dlopen once per process; returns nullptr and fills `why` when the library or a symbol is missing
+// A test may install its own function table (tests/native/comm_mock.cpp fills one with in-process fakes that record the call
+// order): every later rccl_api() returns it and librccl is never opened.
+inline const RcclApi*& rccl_api_override() { static const RcclApi* o = nullptr; return o; }
+
+// The ladder is sharded over the GPUs of ONE node (north_star), so the bootstrap of a communicator never needs a routable
+// interface or an InfiniBand probe: unless the caller has chosen otherwise, RCCL is told to bootstrap over loopback and to
+// leave the verbs devices alone -- two stages of ncclGetUniqueId / ncclCommInitRank whose duration depends on the box's
+// network set-up rather than on anything this library does.  $PTNN_COMM_KEEP_ENV=1 leaves the environment untouched.
+inline void rccl_single_node_env() {
+    if (const char* k = std::getenv("PTNN_COMM_KEEP_ENV")) if (*k && *k != '0') return;
+    setenv("NCCL_SOCKET_IFNAME", "lo", 0);
+    setenv("NCCL_IB_DISABLE", "1", 0);
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);      // dmabuf IPC is all this pool's driver offers (no effect once HIP is up)
+}
+
+// dlopen once per process; returns nullptr and fills `why` when the library or a symbol is missing or the load does not finish
+// within comm_timeout_s()
 inline const RcclApi* rccl_api(std::string& why) {
+    if (const RcclApi* o = rccl_api_override()) return o;
     static std::mutex mu;
     static RcclApi api;
     static bool tried = false;
@@ -40,13 +131,26 @@ inline const RcclApi* rccl_api(std::string& why) {
     std::lock_guard<std::mutex> lock(mu);
     if (!tried) {
         tried = true;
+        rccl_single_node_env();
         const char* env = std::getenv("PTNN_RCCL_LIBRARY");
         const char* names[] = {env, "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
         for (const char* n : names) {
             if (!n || !*n) continue;
-            api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-            if (api.lib) break;
-            err = dlerror();
+            comm_stage("dlopen(%s)", n);
+            int rc = 0;
+            // static storage: the helper may outlive this call when the load is abandoned
+            static void* loaded = nullptr;
+            static std::string dl_err;
+            const std::string name = n;
+            const bool finished = run_bounded([name]() -> int {
+                void* l = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
+                if (!l) { const char* e = dlerror(); dl_err = e ? e : "dlopen failed"; return 1; }
+                loaded = l;
+                return 0;
+            }, comm_timeout_s(), &rc);
+            if (!finished) { err = "dlopen(" + name + ") did not return within " + std::to_string((int)comm_timeout_s()) + " s"; break; }
+            if (rc == 0) { api.lib = loaded; comm_stage("dlopen(%s) done", n); break; }
+            err = dl_err;
         }
         if (api.lib) {
             bool ok = true;
@@ -56,6 +160,7 @@ inline const RcclApi* rccl_api(std::string& why) {
             PTNN_RCCL_SYM(GetUniqueId, "ncclGetUniqueId")
             PTNN_RCCL_SYM(CommInitRank, "ncclCommInitRank")
             PTNN_RCCL_SYM(CommDestroy, "ncclCommDestroy")
+            PTNN_RCCL_SYM(CommAbort, "ncclCommAbort")
             PTNN_RCCL_SYM(AllGather, "ncclAllGather")
             PTNN_RCCL_SYM(Send, "ncclSend")
             PTNN_RCCL_SYM(Recv, "ncclRecv")
@@ -101,7 +206,7 @@ struct Comm {
     void* h_ctx = nullptr;
     char* stage = nullptr;                  // pinned host staging (host transport)
     size_t stage_bytes = 0;
-    int64_t bytes_sent = 0, bytes_received = 0, rounds = 0;
+    int64_t bytes_sent = 0, bytes_received = 0, rounds = 0, calls = 0;
     std::string err;
 
     bool fail(const std::string& m) { err = m; return false; }
@@ -126,6 +231,7 @@ struct Comm {
     bool all_gather(void* buf, size_t bytes_per_rank, hipStream_t stream) {
         char* base = static_cast<char*>(buf);
         if (kind == COMM_RCCL) {
+            comm_stage("ncclAllGather #%lld (%zu B per rank, rank %d of %d)", (long long)calls++, bytes_per_rank, rank, nranks);
             if (!nccl_ok(api->AllGather(base + (size_t)rank * bytes_per_rank, base, bytes_per_rank, ncclChar, nccl, stream), "ncclAllGather"))
                 return false;
         } else if (kind == COMM_HOST) {
@@ -148,6 +254,7 @@ struct Comm {
     bool exchange_rows(const std::vector<RowMsg>& msgs, size_t row_bytes, hipStream_t stream, SendPtr send_ptr, RecvPtr recv_ptr) {
         if (msgs.empty()) return true;
         if (kind == COMM_RCCL) {
+            comm_stage("ncclGroupStart/Send/Recv/GroupEnd #%lld (%zu rows of %zu B, rank %d of %d)", (long long)calls++, msgs.size(), row_bytes, rank, nranks);
             if (!nccl_ok(api->GroupStart(), "ncclGroupStart")) return false;
             bool ok = true;
             for (const RowMsg& m : msgs) {
@@ -181,8 +288,14 @@ struct Comm {
         return true;
     }
 
+    bool failed = false;                    // a collective did not complete: the communicator is aborted, not drained
     void release() {
-        if (kind == COMM_RCCL && nccl && api) (void)api->CommDestroy(nccl);
+        if (kind == COMM_RCCL && nccl && api) {
+            comm_stage(failed ? "ncclCommAbort" : "ncclCommDestroy");
+            if (failed && api->CommAbort) (void)api->CommAbort(nccl);
+            else (void)api->CommDestroy(nccl);
+            comm_stage("communicator released");
+        }
         nccl = nullptr;
         if (stage) (void)hipHostFree(stage);
         stage = nullptr; stage_bytes = 0;

@@ -3003,6 +3003,8 @@ struct SwapParams {
     int* label_next;           // [R]
     int* slot_next;            // [R]
     float* temps_local;        // [Rl] temperature of the local slots (what the segment kernels read)
+    int* progress;             // pinned host word (or null): block 0 stores round + 1 when the round is through -- what the bounded
+                               // waits of a communicator handle watch (ptnn.hip: wait_stream)
 };
 __host__ __device__ inline int xchg_row_floats(int PS) { return (2 * PS + 4 + 3) & ~3; }
 
@@ -3174,6 +3176,7 @@ __global__ void swap_kernel(const SwapParams sp, const int round, const int mode
                 sp.counters[1] += (sp.rule == 1) ? (sp.R - 1 - (round & 1) + 1) / 2 : sp.R - 1;      // pairs proposed
             }
         }
+        if (threadIdx.x == 0 && sp.progress) __hip_atomic_store(sp.progress, round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -3215,7 +3218,6 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_tree_kernel(const SegPara
     const int node = g + 1, depth = 31 - __clz(node);      // heap index, level (root: 0)
     const int gid = p.first_global + r;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int wave = uni_i(tid >> 6);
     const int Nall = p.Ntr + p.Nte;
     const int P = p.P, PS = p.PS, H = p.H;
     const bool mfma = p.fw_mfma != 0;

@@ -473,6 +473,10 @@ STATS = [  # key, module, topo, dataset, use_lg, lr, R, maxtemp, S per replica, 
     ("iris_rw_r8", "CLS", [4, 12, 3], "iris", False, 0.01, 8, 10, 5000, 0.02, (1, 2, 3, 4, 5)),
     ("mackey_lg_r8", "REG", [4, 10, 1], "mackey", True, 0.1, 8, 2, 2500, 0.01, (1, 2, 3, 4, 5)),
     ("ions_rw_r8", "CLS", [34, 50, 2], "ions", False, 0.01, 8, 10, 1500, 0.02, (1, 2, 3, 4, 5)),
+    # the BASELINE metric's own shape (bench.py's default workload): 64 chains x 10 000 samples, swap interval 100.  64 forked
+    # chains on 8 cores: about 16 min (Langevin) / 6 min (random walk) per run, so `--stats --only sunspot_lg_r64 sunspot_rw_r64`
+    ("sunspot_lg_r64", "REG", [4, 5, 1], "sunspot", True, 0.1, 64, 2, 10000, 0.01, (1, 2, 3, 4, 5)),
+    ("sunspot_rw_r64", "REG", [4, 5, 1], "sunspot", False, 0.1, 64, 2, 10000, 0.01, (1, 2, 3, 4, 5)),
 ]
 
 

@@ -235,6 +235,133 @@ def check_run_against_oracle(s, tr, o, label="", limit=None):
     return firsts
 
 
+def follow_cascade(L, u, src_dev, label=""):
+    """One round of the reference's bubble pass (REG:659-690) walked pair by pair along the DEVICE's permutation: at
+    every pair the oracle's decision (from its own float64 scalars and the carried state the device's history implies) must equal
+    the device's, or differ inside the fp32 error of the two posted scalars it compares.  Returns the number of such pairs."""
+    R = len(L)
+    c, forced = 0, 0
+    for j in range(R - 1):
+        d = L[j + 1] - L[c]
+        d = 709.0 if not (d < 709.0) else d
+        nat = np.log(u[j]) < np.log(0.5) + d
+        dev = int(src_dev[j]) == j + 1
+        if not dev:
+            assert int(src_dev[j]) == c, f"{label}pair {j}: slot receives {src_dev[j]}, not the carried state {c}"
+        if bool(nat) != dev:
+            margin = abs(np.log(u[j]) - (np.log(0.5) + d))
+            bound = SWAP_L_REL * (abs(L[j + 1]) + abs(L[c])) + LOGALPHA_ABS
+            assert margin <= bound, f"{label}pair {j}: swap decision differs with margin {margin:.3g} > {bound:.3g}"
+            forced += 1
+        if not dev:
+            c = j + 1
+    assert int(src_dev[R - 1]) == c, f"{label}last slot receives {src_dev[R - 1]}, not the carried state {c}"
+    return forced
+
+
+def follow_device_run(s, tr, pt, label="", threads=8, row_rtol=2e-4, row_atol=2e-4):
+    """EVERY step of a whole run against the oracle, not only the prefix up to the first fp32 coin flip: the oracle FOLLOWS the
+    device.  `pt` is a PTOracle whose chains are C chains (ptnn_oracle_c.adopt) started from the device's initial weights.  It
+    is advanced interval by interval with the device's own MH decisions imposed (from the accept counters of the trace) and the
+    device's swap permutations imposed (from the swap log); at every step it records what it WOULD have decided.  Held:
+
+      * the kernel's log alpha within the measured fp32 bound of the oracle's on every step of every chain (inputs now stay
+        comparable to the end of the run);
+      * every MH decision the two sides take differently lies inside that bound (check_divergence), every cascade pair decision
+        they take differently inside the bound of the two posted scalars (follow_cascade);
+      * every trace row (pos_w, likeh, rmse, accuracy) of the whole run within row_rtol / row_atol -- wider than the prefix
+        tolerances because fp32 round-off now accumulates over thousands of accepted steps instead of fifty;
+      * the swap counters.
+
+    swap_rule 0 without label swapping.  Returns a report: steps, forced MH decisions, forced cascade pairs, max log-alpha
+    error / scale by class of step."""
+    from concurrent.futures import ThreadPoolExecutor
+    assert pt.swap_rule == 0 and not pt.label_swap
+    R, S, si, task = pt.R, pt.S, pt.si, pt.task
+    acc = tr["accept"].astype(np.int64)
+    dec = np.empty((R, S - 1), dtype=np.int8)
+    dec[:, :S - 2] = acc[:, 2:] - acc[:, 1:S - 1]
+    dec[:, S - 2] = np.asarray(s.state()["num_accepted"], dtype=np.int64) - acc[:, S - 1]
+    assert set(np.unique(dec).tolist()) <= {0, 1}, "accept counters of the device are not a step function"
+    lag = s.log_alpha().astype(np.float64)
+    log = s.swap_log()
+    la, lu, sc = (np.empty((R, S - 1)) for _ in range(3))
+    stale, nat = (np.empty((R, S - 1), dtype=np.int8) for _ in range(2))
+    forced_pairs, k, i0 = 0, 0, 0
+    with ThreadPoolExecutor(threads) as ex:
+        while i0 < S - 1:
+            i1 = i0
+            while i1 < S - 1 and not orc.swap_trigger(task, i1, si):
+                i1 += 1
+            handoff = i1 < S - 1
+            i1 = i1 + 1 if handoff else S - 1
+
+            def run(r, a=i0, b=i1):
+                return pt.replicas[r].run(a, b, dec[r, a:b])
+            for r, rec in enumerate(ex.map(run, range(R))):
+                la[r, i0:i1], lu[r, i0:i1], sc[r, i0:i1] = rec["logalpha"], rec["logu"], rec["scale"]
+                stale[r, i0:i1], nat[r, i0:i1] = rec["stale"], rec["natural"]
+            pt._steps_done = i1
+            if handoff:
+                L = [rep.posted_L() for rep in pt.replicas]
+                forced_pairs += follow_cascade(L, pt.tape.swap_uniforms(k, R - 1), log[k], f"{label}swap round {k} ")
+                pt.swap_round(L=L, force_src=[int(v) for v in log[k]])
+                k += 1
+            i0 = i1
+    if int(S / si) > pt.rounds_done:                          # Q13 phantom round: counted, result discarded
+        L = [rep.likelihood for rep in pt.replicas]
+        forced_pairs += follow_cascade(L, pt.tape.swap_uniforms(k, R - 1), log[k], f"{label}phantom round ")
+        pt.swap_round(L=L, apply=False, force_src=[int(v) for v in log[k]])
+    nsw, tot, rounds = s.swap_stats()
+    assert (nsw, tot, rounds) == (pt.num_swap, pt.total_swap_proposals, pt.rounds_done), (nsw, tot, rounds, pt.num_swap, pt.total_swap_proposals)
+    # ---- every step's log alpha
+    coupled = pt.rounds_done > 0
+    rel = np.where(stale != 0, LOGALPHA_REL_STALE, LOGALPHA_REL_COUPLED if coupled else LOGALPHA_REL)
+    ok = np.isfinite(la) & np.isfinite(lag)
+    err = np.abs(lag - la)
+    ratio = np.where(ok, err / np.maximum(sc, 1e-300), 0.0)
+    over = ok & (err > rel * sc + LOGALPHA_ABS)
+    report = dict(steps=int(R * (S - 1)), forced_mh=int((nat != dec).sum()), forced_swap_pairs=int(forced_pairs),
+                  swap_pairs=int(pt.total_swap_proposals), accepted=int(dec.sum()),
+                  max_ratio_fresh=float(ratio[stale == 0].max()), max_ratio_stale=float(ratio[stale != 0].max()) if (stale != 0).any() else 0.0,
+                  max_abs_err=float(err[ok].max()), steps_over_bound=int(over.sum()))
+    if os.environ.get("PTNN_PARITY_PROBE"):
+        import json
+        with open(os.environ["PTNN_PARITY_PROBE"], "a") as f:
+            f.write(json.dumps(dict(label=label + "follow", test=os.environ.get("PYTEST_CURRENT_TEST", ""), **report)) + "\n")
+    else:
+        assert not over.any(), (f"{label}log alpha outside the fp32 bound on {int(over.sum())} of {report['steps']} steps; worst "
+                                f"{float(ratio.max()):.3g} of the scale at (replica, step) {np.unravel_index(int(np.argmax(np.where(over, ratio, 0))), ratio.shape)}")
+    # ---- every decision taken differently is a coin flip inside the bound
+    for r, i in zip(*np.nonzero(nat != dec)):
+        check_divergence(la[r, i], lu[r, i], sc[r, i], lag[r, i], f"{label}r{r} step {i}: ", rel=float(rel[r, i]))
+    # ---- every trace row of the run
+    probing = bool(os.environ.get("PTNN_PARITY_PROBE"))
+
+    def rows_close(got, want, rtol, atol, what):
+        got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+        both_nan = np.isnan(got) & np.isnan(want)
+        excess = np.where(both_nan, 0.0, np.abs(got - want) - rtol * np.abs(want))
+        worst = float(np.nanmax(excess)) if excess.size else 0.0
+        report[what] = max(report.get(what, 0.0), worst)
+        if not probing:
+            assert not np.isnan(excess).any() and worst <= atol, f"{label}{what}: off by {worst:.3g} beyond rtol {rtol} (atol {atol})"
+    for r, rep in enumerate(pt.replicas):
+        rows_close(tr["pos_w"][r], rep.pos_w, row_rtol, row_atol, "pos_w_abs_excess")
+        rows_close(tr["likeh"][r], rep.likeh[:, 0], row_rtol, 2e-2, "likeh_abs_excess")
+        for nm in ("rmse_train", "rmse_test"):
+            rows_close(tr[nm][r], getattr(rep, nm), 5e-4, 2e-6, "rmse_abs_excess")
+        for nm in ("acc_train", "acc_test"):
+            # a classification of one data row may flip where two outputs agree to fp32 round-off: one row of the set
+            n_rows = (pt.train if nm == "acc_train" else pt.test).shape[0]
+            rows_close(tr[nm][r], getattr(rep, nm), 0.0, 100.0 / n_rows + 1e-3, "acc_abs_excess")
+    if probing:
+        import json
+        with open(os.environ["PTNN_PARITY_PROBE"], "a") as f:
+            f.write(json.dumps(dict(label=label + "follow rows", **report)) + "\n")
+    return report
+
+
 def run_smoke_check():
     """Sunspot, FNN 4-5-1, 4 replicas, Langevin p=0.5, S=60, swaps every 10: HIP vs oracle on the same tape."""
     ds = datasets()
