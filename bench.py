@@ -95,7 +95,7 @@ def switch_step(S):
 class Ladder:
     """The sampler of one rank (one GPU): a contiguous block of the temperature ladder."""
 
-    def __init__(self, wl, a, train, test, rank, world, device):
+    def __init__(self, wl, a, train, test, rank, world, device, shared_noise=None):
         import ptnn_amd  # noqa: F401
         from ptnn_amd import _lib, ladder, philox
         topo, R = wl["topo"], wl["R"]
@@ -107,7 +107,7 @@ class Ladder:
                               swap_interval=wl["si"], pt_switch_step=switch_step(self.S), use_langevin=int(wl["lg"]),
                               waves_per_replica=a.waves, schedule=a.schedule, groups_per_replica=a.groups, l_prob=0.5,
                               learn_rate=wl["lr"], step_w=0.025, step_eta=0.2, sigma_squared=25.0, nu_1=0.0, nu_2=0.0, seed=SEED,
-                              forward_bf16=int(a.bf16))
+                              forward_bf16=int(a.bf16), shared_noise=int(a.shared_noise if shared_noise is None else shared_noise))
         self.s.set_data(train, test)
         scale = 0.3 if topo[1] > 64 else 1.0      # wide nets: N(0,1) weights saturate every hidden unit of a 512-unit layer
         self.w0 = scale * np.stack([philox.initial_weights(SEED, first + r, self.P) for r in range(R)])
@@ -139,7 +139,7 @@ def _cpu_chain(args):
     t0 = time.perf_counter()
     for i in range(n_steps):
         rep.step(i)
-    return time.perf_counter() - t0
+    return time.perf_counter() - t0, rep.posted_L()
 
 
 def usable_cores():
@@ -166,10 +166,17 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(wl, train, test, n_steps=40):
+# The port against the reference itself, measured where both can run (the survey container, 8 cores):
+# Sunspot [4,5,1], one chain in-process, the reference takes 3.81 / 10.47 ms per random-walk / Langevin step, the faithful oracle
+# 2.79 / 7.53 ms -- reference time = port time x 1.38, i.e. reference samples/s = port samples/s / 1.38 on the same cores.
+PORT_OVER_REFERENCE = 1.38
+
+
+def cpu_baseline(wl, train, test, n_steps=101):
     """The oracle (float64 numpy restatement, per-row loops like the reference: faithful=True) on the host cores: the same
-    64-replica Langevin workload, the first n_steps MH steps of every replica, one process per core.  A bounded sample: the
-    CPU cost of a step does not depend on where in the chain it lies."""
+    64-replica Langevin workload -- the first swap interval of the run: MH steps 0 .. 100 of every replica, one process per core
+    (the reference forks one per chain, REG:709-712), then the swap round of that interval in the parent (REG:741-748).  A
+    bounded sample: the CPU cost of a step does not depend on where in the chain it lies."""
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ptnn_oracle as orc
@@ -180,11 +187,17 @@ def cpu_baseline(wl, train, test, n_steps=40):
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
-        busy = pool.map(_cpu_chain, jobs, chunksize=1)
+        res = pool.map(_cpu_chain, jobs, chunksize=1)
+    src, nsw = orc.swap_cascade([L for _, L in res], orc.PhiloxTape(SEED).swap_uniforms(0, R - 1))
     wall = time.perf_counter() - t0
-    return {"value": R * n_steps / wall, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{R} replicas x the first {n_steps} MH steps (Langevin p=0.5), oracle faithful mode, "
-                      f"{cores} processes, {sum(busy):.1f} s of CPU work, no swap rounds"}
+    value = R * n_steps / wall
+    return {"value": value, "unit": "samples/s", "cores": cores, "kind": "port",
+            "port_over_reference": PORT_OVER_REFERENCE,
+            "reference_equivalent": value / PORT_OVER_REFERENCE,
+            "port_over_reference_source": "BASELINE.md 3.2 / DESIGN.md 8: the reference and the faithful oracle timed on identical work in "
+                                          "the survey container (3.81 / 10.47 ms vs 2.79 / 7.53 ms per RW / Langevin step)",
+            "sample": f"{R} replicas x MH steps 0..{n_steps - 1} (the first swap interval, Langevin p=0.5) + its swap round "
+                      f"({nsw} of {R - 1} pairs swapped), oracle faithful mode, {cores} processes, {sum(t for t, _ in res):.1f} s of CPU work"}
 
 
 # ------------------------------------------------------------------------------------------------ diagnostics
@@ -209,6 +222,8 @@ def dependent_chain(tr_accept, si, slots, epoch_ms):
         per_rounds.append(rr)
     per_acc, per_rounds = np.array(per_acc), np.array(per_rounds)
     return {"slots_per_round": slots, "sgd_epoch_ms": epoch_ms,
+            "sgd_epoch_source": "measured in this process: ptnn_time_sgd_epoch, 200 epochs back to back on one wavefront, in-kernel "
+                                "constant-rate counter",
             "chain_floor_ms_per_interval": float(per_acc.max(axis=1).mean()) * epoch_ms,
             "accepted_steps_per_interval_mean": float(per_acc.mean()),
             "accepted_steps_per_interval_max_over_replicas_mean": float(per_acc.max(axis=1).mean()),
@@ -242,6 +257,9 @@ def main():
     ap.add_argument("--rw", action="store_true", help="random-walk proposals only (extra data point)")
     ap.add_argument("--replicas", type=int, default=0, help="replicas per GPU instead of the workload's own count (extra data point)")
     ap.add_argument("--bf16", action="store_true", help="synthetic512: forward GEMM operands in bf16 (tolerance study mode)")
+    ap.add_argument("--shared-noise", type=int, default=1, choices=[0, 1],
+                    help="1 (default, the drop-in classes' default): every chain reads ONE noise tape, as the reference's forked chains "
+                         "do (REG:709-712, SURVEY Q14); 0: independent Philox streams per chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra legs (kept-half split run, dependent-chain "
                     "analysis): under rocprofv3 every launch of the process then belongs to a warm-up or a timed run")
@@ -349,10 +367,27 @@ def main():
         extras["first_half"] = {"value": R * half / (tm - tb), "unit": "samples/s", "mh_steps": f"1..{half}"}
         extras["kept_half"] = {"value": R * (S - 1 - half) / (te - tm), "unit": "samples/s", "mh_steps": f"{half + 1}..{S - 1}",
                                "note": "the samples the reference keeps (burn_in 0.5, REG:949,1004)"}
-        if info["slots_per_round"] > 1 and wl["lg"] and wl["topo"][0] == 4 and wl["topo"][2] == 1 and S * R * 4 < (1 << 28):   # the 4-H-1 nets of the stamped epoch
-            # 298 rows x 143 cycles per row measured with in-kernel stamps at the 2.4 GHz shader clock
-            epoch_ms = train.shape[0] * 143 / 2.4e9 * 1e3
+        if info["slots_per_round"] > 1 and wl["lg"] and wl["topo"][1] <= 64 and S * R * 4 < (1 << 28):
+            # what ONE sequential SGD epoch costs here and now: timed inside a kernel of this process (no stamp count from another
+            # build, no assumed clock)
+            epoch_ms = s.time_sgd_epoch(lad.w0[0], reps=200)
             extras["dependent_chain"] = dependent_chain(s.traces(pos_w=False)["accept"], si, info["slots_per_round"], epoch_ms)
+        if a.workload == "sunspot64" and not a.rw and not a.replicas:
+            # the other noise mode on the same workload: a few whole runs, timed the same way
+            other = 1 - a.shared_noise
+            lad2 = Ladder(wl, a, train, test, rank, N, device, shared_noise=other)
+            lad2.whole_run()
+            t2 = time.perf_counter()
+            for _ in range(5):
+                lad2.whole_run()
+            d2 = time.perf_counter() - t2
+            n2, tot2, _ = lad2.s.swap_stats()
+            extras["other_noise_mode"] = {"shared_noise": other, "value": R * (S - 1) * 5 / d2, "unit": "samples/s", "runs": 5,
+                                          "swap_accept_pct": 100.0 * n2 / max(tot2, 1),
+                                          "mh_accept_pct": float(100.0 * np.mean(lad2.s.state()["num_accepted"]) / max(S - 1, 1)),
+                                          "note": "shared_noise 1 = the reference's behaviour (its forked chains inherit one RNG state, "
+                                                  "REG:709-712) and the drop-in's default; 0 = independent Philox streams per chain"}
+            lad2.s.close()
 
     if rank == 0:
         mh_steps = S - 1                                        # per replica and run
@@ -375,6 +410,16 @@ def main():
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
         roof["valu_frac"] = roof["valu_tflops"] / VALU_PEAK_TFLOPS
         roof["valu_frac_of_busy_cus"] = roof["valu_frac"] * info["num_cus"] / max(roof["busy_cus"], 1)
+        roof["traffic_measured_in_run"] = False if traffic else None      # recorded by profiles/collect.sh (rocprofv3 PMC passes), not by this run
+        dc = extras.get("dependent_chain")
+        if dc and launches:
+            intervals_per_launch = max(1.0, steps_per_launch / si)
+            measured = avg_launch_s * 1e3 / intervals_per_launch
+            roof["chain"] = {"floor_ms": dc["chain_floor_ms_per_interval"], "measured_ms": measured,
+                             "frac": dc["chain_floor_ms_per_interval"] / measured if measured else None, "unit": "ms per swap interval",
+                             "sgd_epoch_ms": dc["sgd_epoch_ms"],
+                             "note": "floor = (accepted steps of the slowest replica of an interval, mean over the run's intervals) x one "
+                                     "sequential SGD epoch timed in this process; measured = dominant kernel time per swap interval"}
         roof["note"] = ("instruction-issue / dependent-chain bound by construction (sequential SGD rows, arithmetic intensity far "
                         "above the machine balance); the HBM fraction is reported because BASELINE.json asks for it")
         if wl["topo"][1] > 64:
@@ -392,13 +437,19 @@ def main():
             "config": {"workload": wl["desc"] + f"; swap every {si} MH steps; 1 bench step = 1 WHOLE RUN from the chain start: "
                                                 f"S = {S} samples per replica ({S - 1} MH steps, {S // si} swap rounds, chain start-up included)",
                        "replicas": R * N, "replicas_per_gpu": R, "samples_per_replica": S, "swap_interval": si,
-                       "proposals": "langevin p=0.5" if wl["lg"] else "random-walk", "schedule": info["schedule"],
+                       "proposals": "langevin p=0.5" if wl["lg"] else "random-walk",
+                       "noise": "shared tape (shared_noise=1: the reference's forked chains all inherit one RNG state, REG:709-712; the "
+                                "drop-in's default)" if a.shared_noise else "independent Philox streams per chain (shared_noise=0)",
+                       "schedule": info["schedule"],
                        "slots_per_round": info["slots_per_round"], "groups_per_replica": info["groups_per_replica"],
                        "block_threads": info["block_threads"], "lds_bytes": info["lds_bytes"], "exchange": info.get("exchange", "none"),
                        "transport": a.transport if sharded else "none"},
             "swap_accept_pct": 100.0 * nsw / max(tot, 1), "swap_rounds_per_run": rounds,
             "mh_accept_pct": float(100.0 * np.mean(st["num_accepted"]) / max(S - 1, 1)),
             "roofline": roof,
+            "timed_region": "W warm-up runs, then K whole runs back to back: chain restart (ptnn_set_state), all MH steps, all swap rounds, "
+                            "trace rows written to HBM; NOT in it: the device-to-host copy of the traces and the result files "
+                            "(ParallelTempering.timings reports those; DESIGN.md 8)",
         }
         out.update(extras)
         if cpu is not None:

@@ -252,6 +252,11 @@ int ptnn_checkpoint_load(ptnn_handle *h, const void *buf, int64_t bytes);
 int ptnn_evaluate(ptnn_handle *h, const float *w, const float *tau_sq, int n, float *out);
 /* Network.langevin_gradient(train, w, depth=1) for n weight vectors (REG:99-118, CLS:114-132) */
 int ptnn_langevin_gradient(ptnn_handle *h, const float *w_in, int n, float *w_out);
+/* What ONE sequential SGD epoch (langevin_gradient of one chain, REG:99-118) costs on this device, in milliseconds: `reps` epochs
+ * back to back on one wavefront, timed inside the kernel with the constant-rate counter (s_memrealtime; the rate comes from
+ * hipDeviceAttributeWallClockRate).  An accepted Langevin step makes the next proposal wait for a fresh epoch, so accepted steps x
+ * this number is the floor of a swap interval whatever the number of speculative slots (bench.py: roofline.chain).  n_hidden <= 64. */
+int ptnn_time_sgd_epoch(ptnn_handle *h, const float *w, int reps, double *ms_per_epoch);
 /* the random tape of MH step `step` of global replica `replica`: noise [P] normals, scal[3] = {lx, u, n_eta} */
 int ptnn_tape(ptnn_handle *h, int replica, int step, float *noise, float *scal);
 

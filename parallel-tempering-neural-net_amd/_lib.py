@@ -85,6 +85,7 @@ SYMBOLS = {
     "ptnn_checkpoint_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "ptnn_evaluate": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, _fp]),
     "ptnn_langevin_gradient": (C.c_int, [C.c_void_p, _fp, C.c_int, _fp]),
+    "ptnn_time_sgd_epoch": (C.c_int, [C.c_void_p, _fp, C.c_int, C.POINTER(C.c_double)]),
     "ptnn_tape": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp]),
     "ptnn_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "ptnn_kernel_time": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -377,6 +378,13 @@ class Sampler:
         out = np.empty_like(w)
         self._check(self.lib.ptnn_langevin_gradient(self.h, _ptr(w), w.shape[0], _ptr(out)))
         return out
+
+    def time_sgd_epoch(self, w, reps=200):
+        """Milliseconds one sequential SGD epoch of one chain takes on the device (in-kernel constant-rate counter)."""
+        w = _f32(w).reshape(-1)
+        ms = C.c_double()
+        self._check(self.lib.ptnn_time_sgd_epoch(self.h, _ptr(w), int(reps), C.byref(ms)))
+        return ms.value
 
     def tape(self, replica, step):
         noise, scal = np.empty(self.P, np.float32), np.empty(3, np.float32)

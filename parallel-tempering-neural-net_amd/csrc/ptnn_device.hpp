@@ -3100,6 +3100,15 @@ __global__ void xchg_pack_kernel(const SwapParams sp) {
     }
 }
 
+// Row 0 of every trace (Q7: pos_w = ones, REG:240; likeh = -100, REG:292-293; the rest zero), one block per local replica.
+// (These rows were two hipMemcpy2D calls with the trace ring's pitch; for Ionosphere's 74 MB pitch the runtime took 25 ms over
+// them -- a fifth of a whole 256-replica run, profiles/r03_gap_probe.json.)
+__global__ void trace_row0_kernel(float* __restrict__ pos_w, float* __restrict__ scal, int P, int PW, size_t cap) {
+    float* row = pos_w + (size_t)blockIdx.x * cap * PW;
+    for (int j = threadIdx.x; j < PW; j += blockDim.x) row[j] = (j < P) ? 1.0f : 0.0f;
+    if (threadIdx.x == 0) store_trace_row(scal + (size_t)blockIdx.x * cap * TR_COUNT, -100.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0, 0.0f);
+}
+
 __global__ void swap_kernel(const SwapParams sp, const int round, const int mode) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sL = smem;
@@ -3499,6 +3508,21 @@ __global__ void __launch_bounds__(MAX_THREADS) model_kernel(const SegParams p, c
         if (tid < WAVE) sgd_sweep_dispatch<TASK, I, O>(l.w_cur, l.w_gd, l.xy, p.data, p.Ntr, p.H, p.lr);
         __syncthreads();
         for (int j = tid; j < p.P; j += nthr) out[(size_t)b * p.P + j] = l.w_gd[j];
+        return;
+    }
+    if (mode == 3) {
+        // a0 SGD epochs back to back on wave 0, timed with the constant-rate counter (s_memrealtime): what ONE sequential epoch of
+        // this net on this data costs on this device -- the unit of the dependent-chain floor bench.py reports (ptnn_time_sgd_epoch)
+        unsigned long long ticks = 0;
+        if (tid < WAVE) {
+            const unsigned long long t0 = wall_clock64();
+            for (int rep = 0; rep < a0; ++rep) {
+                sgd_sweep_dispatch<TASK, I, O>(l.w_cur, l.w_gd, l.xy, p.data, p.Ntr, p.H, p.lr);
+                gsync<true>();
+            }
+            ticks = wall_clock64() - t0;
+        }
+        if (tid == 0) { out[0] = __uint_as_float((unsigned)(ticks & 0xffffffffull)); out[1] = __uint_as_float((unsigned)(ticks >> 32)); out[2] = l.w_gd[0]; }
         return;
     }
     build_fw<I, O>(l.w_cur, l.fw, p.H, p.FWS);

@@ -27,32 +27,70 @@ import numpy as np
 from . import _lib
 
 
+class TransportAborted(RuntimeError):
+    """A block of the ladder failed: the collective this block was waiting in can never complete."""
+
+
 class ThreadTransport:
     """Host-staged transport between n handles of one process.  all_gather is a collective (every rank calls it each round);
-    send_recv is called only by ranks that have messages, so rows travel through per-pair mailboxes."""
+    send_recv is called only by ranks that have messages, so rows travel through per-pair mailboxes.
 
-    def __init__(self, n):
+    No wait is unbounded: when one block fails (its ptnn_run returns an error, or an exception leaves its callback) it calls
+    `abort()`, which breaks the barrier and poisons the mailboxes, so the blocks waiting for it raise `TransportAborted` at once
+    instead of hanging; independently every wait gives up after `timeout` seconds (the reference's parent would block for ever in
+    queue.get() when a replica dies, REG:661 -- SURVEY section 5)."""
+
+    def __init__(self, n, timeout=120.0):
         self.n = n
+        self.timeout = float(timeout)
         self._barrier = threading.Barrier(n)
         self._blocks = [None] * n
         self._mail = {(a, b): queue.Queue() for a in range(n) for b in range(n) if a != b}
+        self.failed = None                                   # why the transport was aborted
+
+    def abort(self, why="a block of the ladder failed"):
+        if self.failed is None:
+            self.failed = str(why)
+        self._barrier.abort()
+        for q in self._mail.values():
+            q.put(None)                                      # wakes a receiver; None = aborted
+
+    def _wait(self):
+        try:
+            self._barrier.wait(self.timeout)
+        except threading.BrokenBarrierError:
+            if self.failed is None:
+                self.failed = f"a block did not reach the all-gather of this swap round within {self.timeout:g} s"
+                self.abort(self.failed)
+            raise TransportAborted(self.failed) from None
 
     def callbacks(self, rank):
         def all_gather(buf):                                 # buf: uint8 [n, bytes_per_rank], own block filled
+            if self.failed is not None:
+                raise TransportAborted(self.failed)
             self._blocks[rank] = buf[rank].copy()
-            self._barrier.wait()
+            self._wait()
             for r in range(self.n):
                 if r != rank:
                     buf[r] = self._blocks[r]
-            self._barrier.wait()                             # nobody overwrites its block before everyone has read it
+            self._wait()                                     # nobody overwrites its block before everyone has read it
 
         def send_recv(msgs):                                 # [(peer, is_send, uint8 row)]
+            if self.failed is not None:
+                raise TransportAborted(self.failed)
             for peer, is_send, row in msgs:
                 if is_send:
                     self._mail[(rank, peer)].put(row.copy())
             for peer, is_send, row in msgs:
                 if not is_send:
-                    row[:] = self._mail[(peer, rank)].get(timeout=120)
+                    try:
+                        got = self._mail[(peer, rank)].get(timeout=self.timeout)
+                    except queue.Empty:
+                        self.abort(f"block {rank} waited {self.timeout:g} s for a row from block {peer}")
+                        raise TransportAborted(self.failed) from None
+                    if got is None:
+                        raise TransportAborted(self.failed)
+                    row[:] = got
         return all_gather, send_recv
 
 
@@ -96,6 +134,7 @@ class LadderGroup:
         self.transport = transport
         self._pool = ThreadPoolExecutor(max_workers=n)
         self.shards = [None] * n
+        self._tt = None                                      # ThreadTransport of a host-staged group
 
         shared_gpu = len(set(self.devices)) < n
         def create(k):
@@ -113,15 +152,40 @@ class LadderGroup:
         self.cfg, self.P, self.S = s0.cfg, s0.P, s0.S
         if n > 1:
             if transport == "rccl":
+                # ncclCommInitRank is a collective: all threads at once, all with the same id.  libptnn bounds it (a rank that
+                # fails before joining makes the others return error -7 after $PTNN_COMM_TIMEOUT_S instead of blocking), and
+                # _each() collects every thread before the first error is raised.
                 uid = _lib.comm_unique_id()
-                self._each(lambda k: self.shards[k].comm_init(uid, k, n))       # collective: all threads at once
+                self._each(lambda k: self.shards[k].comm_init(uid, k, n))
             else:
-                tt = ThreadTransport(n)
-                self._each(lambda k: self.shards[k].comm_init_host(k, n, *tt.callbacks(k)))
+                self._tt = ThreadTransport(n)
+                self._each(lambda k: self.shards[k].comm_init_host(k, n, *self._tt.callbacks(k)))
             self._each(lambda k: self.shards[k].comm_set_mode(exchange))
 
     def _each(self, fn):
-        return list(self._pool.map(fn, range(self.n)))
+        """fn(k) on every block's own thread.  One failing block must not leave the others inside a collective: its error
+        aborts the host-staged transport at once (RCCL collectives are bounded inside libptnn), every thread is waited for, and
+        only then the first error is raised -- the pool is never left with stuck workers, so close() can always run."""
+        def guarded(k):
+            try:
+                return fn(k)
+            except BaseException as e:                       # noqa: BLE001
+                if self._tt is not None:
+                    self._tt.abort(f"block {k}: {e}")
+                raise
+        futures = [self._pool.submit(guarded, k) for k in range(self.n)]
+        results, first = [], None
+        for f in futures:
+            try:
+                results.append(f.result())
+            except BaseException as e:                       # noqa: BLE001
+                results.append(None)
+                if first is None or (isinstance(first, TransportAborted) and not isinstance(e, TransportAborted)):
+                    first = e                                # the cause, not the blocks that were woken by the abort
+        if first is not None:
+            self.failed = True
+            raise first
+        return results
 
     # ---- configuration
     def set_data(self, train, test):
@@ -187,9 +251,11 @@ class LadderGroup:
 
     def close(self):
         if self.shards:
-            self._each(lambda k: self.shards[k].close() if self.shards[k] is not None else None)
-            self.shards = []
-            self._pool.shutdown(wait=True)
+            shards, self.shards = self.shards, []
+            try:
+                self._each(lambda k: shards[k].close() if shards[k] is not None else None)
+            finally:
+                self._pool.shutdown(wait=True)
 
     def __del__(self):
         try:

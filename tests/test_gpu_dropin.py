@@ -23,6 +23,7 @@ def _run(key, tmp_path, **kw):
     args = (bool(g["use_lg"]), float(g["lr"]), d[dname + "_train"], d[dname + "_test"], topo, int(g["R"]), int(g["maxtemp"]),
             int(g["NumSample"]), int(g["si"]))
     path = str(tmp_path)
+    kw.setdefault("shared_noise", False)     # the F6 fixtures were made with one Philox tape PER chain (make_fixtures.py: gen_swap_trajectories)
     if int(g["task"]) == 0:
         from ptnn_amd.pt_timeseries_regression import ParallelTempering
         pt = ParallelTempering(*args, 0.5, path, seed=int(g["seed"]), **kw)

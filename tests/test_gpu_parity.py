@@ -386,12 +386,14 @@ def test_statistics_match_long_reference_runs(key, shared_noise):
     the same initial weights with its Philox tape.  Bounds (parity.posterior_parity states how each is applied):
     per-weight posterior mean within 0.1 posterior sd + 3 MCSE, posterior variance ratio 0.8 .. 1.25, MH acceptance per
     temperature within 3 points + 3 MCSE, swap percentage within 5 points + 3 MCSE, RMSE / accuracy within 3 MCSE + 5 %.
-    shared_noise = 1 is the reference's actual behaviour (Q14: its forked chains all inherit one RNG state, REG:709-712) and
-    must pass every bound.  The default (independent Philox streams per replica, the statistically sound choice SURVEY 8a
-    sanctions) is held to the same bounds except the within-slot variance: chains that share one noise tape drift in parallel,
-    so the states a slot receives through swaps lie closer to the one it had -- with independent noise the within-slot variance
-    of the high-acceptance classification chains comes out 1.4-1.8 x the reference's (measured with the float64 oracle, which is
-    pinned to the reference bit for bit, under both settings)."""
+    shared_noise = 1 is the reference's actual behaviour (Q14: its forked chains all inherit one RNG state, REG:709-712), the
+    default of the drop-in classes and of bench.py, and must pass every bound.  shared_noise = 0 (independent Philox streams per
+    replica, the statistically sounder choice SURVEY 8a sanctions, opt-in) is held to the same bounds with ONE stated exception,
+    checked rather than switched off: the posterior variance ratio may reach 2.0 instead of 1.25.  Chains that share one noise
+    tape drift in parallel, so the states a slot receives through swaps lie closer to the one it had; with independent noise the
+    within-slot variance of the high-acceptance classification chains comes out 1.3 - 1.8 x the reference's -- measured with the
+    float64 oracle, which is pinned to the reference bit for bit, under both settings, i.e. a property of the
+    deviation Q14, not of the kernels."""
     task, topo, name, lg, lr, maxtemp = STATS[key]
     f = json.load(open(os.path.join(parity.GOLDEN, f"stats_{key}.json")))
     R, S, si = f["R"], f["S"], f["swap_interval"]
@@ -416,7 +418,7 @@ def test_statistics_match_long_reference_runs(key, shared_noise):
                          rmse_train_mean=float(tr["rmse_train"][:, b:].mean()), rmse_test_mean=float(tr["rmse_test"][:, b:].mean()),
                          acc_train_mean=float(tr["acc_train"][:, b:].mean()), acc_test_mean=float(tr["acc_test"][:, b:].mean())))
         s.close()
-    report = parity.posterior_parity(f["runs"], runs, task, check_variance=bool(shared_noise))
+    report = parity.posterior_parity(f["runs"], runs, task, var_ratio_hi=1.25 if shared_noise else 2.0)
     print(key, "shared_noise", shared_noise, json.dumps(report))
     assert report["ok"], report
 

@@ -249,3 +249,71 @@ def test_sharded_ladder_over_thread_transport_matches_single_process(datasets, w
         t.join()
     assert not errs, errs
     _check([r.result() for r in ranks], ref, world, mode)
+
+
+def test_rccl_call_pattern_with_mock_library(tmp_path):
+    """The RCCL code path of csrc/ptnn_comm.hpp (Comm::all_gather, Comm::exchange_rows, route_rows) against an in-process fake of
+    librccl (tests/native/comm_mock.cpp): 8 ranks as threads, R = 256 with Ionosphere's rows and R = 1024 with config 5's, hundreds
+    of random cascades -- in-place all-gathers with equal counts, sends / receives only inside one group per rank and round and
+    matched FIFO per pair, at most one row in from below and one from above, the ladder equal to the permutation applied directly,
+    and an injected collective failure reported by its rank without hanging the others.  Never run on N > 1 GPUs; this is the
+    rehearsal of that call sequence a one-GPU pool allows."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "comm_mock")
+    subprocess.check_call([hipcc, "-O1", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "native", "comm_mock.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK all" in r.stdout and r.stdout.count("\nOK R=") + r.stdout.startswith("OK R=") == 5 and "OK failure-injection" in r.stdout
+    shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+def test_one_failing_block_aborts_the_group_instead_of_hanging():
+    """distributed.ThreadTransport / LadderGroup._each: when one block of a ladder fails inside a swap round, the blocks
+    waiting for it in the all-gather or for one of its rows are woken with TransportAborted, the cause (not the wake-ups) is what
+    the caller sees, the worker pool is left without stuck threads, and nothing waits longer than the transport's timeout."""
+    import time
+    import ptnn_amd  # noqa: F401
+    from ptnn_amd import distributed as dm
+    n = 4
+    tt = dm.ThreadTransport(n, timeout=30.0)
+    cbs = [tt.callbacks(k) for k in range(n)]
+
+    class Boom(RuntimeError):
+        pass
+
+    grp = dm.LadderGroup.__new__(dm.LadderGroup)            # the part of LadderGroup under test needs no GPU: pool + transport
+    from concurrent.futures import ThreadPoolExecutor
+    grp.n, grp._pool, grp._tt, grp.shards = n, ThreadPoolExecutor(max_workers=n), tt, []
+
+    def round_(k):
+        buf = np.zeros((n, 8), dtype=np.uint8)
+        buf[k] = k + 1
+        cbs[k][0](buf)                                       # round 0: everybody arrives
+        assert [int(buf[r, 0]) for r in range(n)] == [1, 2, 3, 4]
+        if k == 2:
+            raise Boom("device error on block 2")            # e.g. ptnn_run returned -2 on this rank
+        if k == 3:
+            cbs[k][1]([(2, 0, np.zeros(4, dtype=np.uint8))])  # waits for a row block 2 will never send
+        else:
+            cbs[k][0](buf)                                   # next all-gather: block 2 never comes
+        return k
+    t0 = time.time()
+    with pytest.raises(Boom, match="block 2"):
+        grp._each(round_)
+    assert time.time() - t0 < 10.0                           # woken by the abort, not by the 30 s timeout
+    assert tt.failed and "block 2" in tt.failed
+    with pytest.raises(dm.TransportAborted):                 # the transport stays failed: a later round cannot half-run
+        cbs[0][0](np.zeros((n, 8), dtype=np.uint8))
+    assert grp._each(lambda k: k * k) == [0, 1, 4, 9]        # the pool has no stuck workers
+    grp._pool.shutdown(wait=True)
+    # a block that silently never arrives: bounded by the timeout, reported
+    tt2 = dm.ThreadTransport(2, timeout=0.5)
+    ag0 = tt2.callbacks(0)[0]
+    t0 = time.time()
+    with pytest.raises(dm.TransportAborted, match="did not reach the all-gather"):
+        ag0(np.zeros((2, 4), dtype=np.uint8))
+    assert time.time() - t0 < 5.0
