@@ -75,6 +75,8 @@ struct ptnn_handle {
     int model_threads = 64;
     bool speculative = false;
     bool wide = false;              // 64 < H: vectors in HBM, one thread per hidden unit
+    bool wide_res = false;          // ... with the state and the proposal resident in LDS (matrix-core layout, 2 vectors fit)
+    bool compact = false;           // wide nets with all trace rows resident: rejected steps record a row index, no pos_w row
     bool packed = false;            // H <= 16: packed speculative schedule on one CU
     bool tree = false;              // prefetching tree schedule: groups = 2^depth - 1 work-groups per replica
     bool tree_ahead = false;        // ... with room in LDS for two sets of tapes
@@ -89,6 +91,7 @@ struct ptnn_handle {
     int num_cus = 0;
     unsigned long long *d_xslots = nullptr, *d_xw = nullptr, *d_xverdict = nullptr;
     int* d_error = nullptr;
+    float *h_stage = nullptr, *d_stage = nullptr;   // initial weights + temperatures on their way to the device (ptnn_set_state)
     int* h_progress = nullptr;      // pinned host word: swap rounds the device has completed (swap_kernel stores it)
     bool failed = false;            // a run on this handle ended in an error (-5 / -7): results are refused until the chains restart
     std::string failure;
@@ -150,7 +153,7 @@ struct ptnn_handle {
         p.L_handoff = d_L_handoff; p.L_final = d_L_final;
         p.L_raw = (cfg.swap_rule == 1) ? d_L_raw : nullptr; p.prior_post = d_prior_post;
         p.tr_pos_w = d_pos_w; p.tr_scal = d_scal; p.PW = PW;
-        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.xverdict = d_xverdict; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.noise_shared = cfg.shared_noise ? 1 : 0; p.pk_nred = pk_nred; p.xt = d_xt; p.Npad = Npad; p.fw_mfma = fw_mfma ? 1 : 0; p.forward_bf16 = cfg.forward_bf16; p.tree_ahead = tree_ahead ? 1 : 0;
+        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.xverdict = d_xverdict; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.noise_shared = cfg.shared_noise ? 1 : 0; p.pk_nred = pk_nred; p.xt = d_xt; p.Npad = Npad; p.fw_mfma = fw_mfma ? 1 : 0; p.forward_bf16 = cfg.forward_bf16; p.tree_ahead = tree_ahead ? 1 : 0; p.compact = compact ? 1 : 0;
         // wide nets over several work-groups: a window of 8 steps lets the groups balance Langevin (5 units) against random-walk (1)
         // steps; random-walk-only runs have nothing to balance and a longer window only wastes what follows an accepted step
         p.wide_window = cfg.use_langevin ? 8 : groups;
@@ -169,6 +172,15 @@ inline int tree_depth(int groups) { int d = 0; while ((1 << (d + 1)) - 1 <= grou
 inline bool swap_trigger(const ptnn_config& c, int i) {
     if (c.task == PTNN_TASK_REG) return (i % c.swap_interval == 0) && i != 0;
     return ((i + 1) % c.swap_interval) == 0;
+}
+
+// the segment kernel the schedule resolved to
+seg_fn segment_function(const ptnn_handle* h) {
+    const Shape* sh = h->shape;
+    if (h->wide) return h->wide_res ? sh->seg_wide_res : sh->seg_wide;
+    if (h->tree) return sh->tree;
+    if (h->packed) return sh->pack;
+    return h->speculative ? sh->spec : sh->seg;
 }
 
 void collect_timing(ptnn_handle* h) {
@@ -190,8 +202,7 @@ int launch_segment(ptnn_handle* h, int begin, int n) {
     if (!timed) {
         const SegParams p = h->seg_params();
         const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
-        hipLaunchKernelGGL(h->wide ? h->shape->seg_wide : (h->tree ? h->shape->tree : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg))),
-                           dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
+        hipLaunchKernelGGL(segment_function(h), dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
         h->epoch_base += (unsigned)n + 1u;
         HIP_TRY(hipGetLastError());
         return 0;
@@ -211,8 +222,7 @@ int launch_segment(ptnn_handle* h, int begin, int n) {
     const SegParams p = h->seg_params();
     HIP_TRY(hipEventRecord(ev.first, h->stream));
     const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
-    hipLaunchKernelGGL(h->wide ? h->shape->seg_wide : (h->tree ? h->shape->tree : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg))),
-                       dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
+    hipLaunchKernelGGL(segment_function(h), dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
     h->epoch_base += (unsigned)n + 1u;                    // granule tags never repeat across launches
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, h->stream));
@@ -374,6 +384,8 @@ int create_buffers(ptnn_handle* h, const ptnn_config* cfg, const Shape* sh, cons
     HIP_TRY(hipMalloc(&h->d_src_log, (size_t)h->max_rounds * R * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_counters, 2 * sizeof(long long)));
     HIP_TRY(hipMalloc(&h->d_error, sizeof(int)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), (Rl * h->P + Rl) * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&h->d_stage, (Rl * h->P + Rl) * sizeof(float)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_progress), sizeof(int), hipHostMallocDefault));
     *h->h_progress = 0;
     HIP_TRY(hipMalloc(&h->d_stamps, 160 * sizeof(unsigned long long)));
@@ -457,6 +469,8 @@ int ptnn_destroy(ptnn_handle* h) {
         if (p) (void)hipFree(p);
     if (h->h_src) (void)hipHostFree(h->h_src);
     if (h->h_progress) (void)hipHostFree(h->h_progress);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->d_stage) (void)hipFree(h->d_stage);
     if (h->d_xchg) (void)hipFree(h->d_xchg);
     for (auto& ev : h->timing) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -501,8 +515,17 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
     h->fw_mfma = false;
     if (H > WAVE) {
         // wide net: one thread per hidden unit, vectors in HBM, only the packed forward image + scratch in LDS
-        const size_t lds = wide_lds_floats(H, h->FWS, h->cfg.n_out, h->PS) * sizeof(float);
+        // matrix-core layout (H a multiple of 32): the state vector joins the proposal in LDS when both fit (ceilings just below
+        // 160 KiB are refused by the runtime); $PTNN_WIDE_RES=0 keeps the streaming kernel (A/B measurements)
+        const size_t lds_res = wide_lds_floats(H, h->FWS, h->cfg.n_out, h->PS, true) * sizeof(float);
+        const char* res_env = std::getenv("PTNN_WIDE_RES");
+        h->wide_res = (H % 32 == 0) && lds_res <= 152 * 1024 && !(res_env && res_env[0] == '0');
+        const size_t lds = h->wide_res ? lds_res : wide_lds_floats(H, h->FWS, h->cfg.n_out, h->PS) * sizeof(float);
         if (lds > 160 * 1024) return fail(-3, "wide net needs %zu B of LDS (> 160 KiB)", lds);
+        {
+            const char* ce = std::getenv("PTNN_COMPACT_TRACES");
+            h->compact = h->cap == h->cfg.n_samples && !(ce && ce[0] == '0');
+        }
         if (h->cfg.schedule == PTNN_SCHED_SPECULATIVE || h->cfg.schedule == PTNN_SCHED_PACKED || h->cfg.schedule == PTNN_SCHED_TREE)
             return fail(-3, "schedules 2-4 are built for n_hidden <= 64; a wide net speculates over work-groups through groups_per_replica");
         h->wide = true; h->speculative = false; h->groups = 1;
@@ -513,7 +536,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         if (h->d_data) { HIP_TRY(hipFree(h->d_data)); h->d_data = nullptr; }
         HIP_TRY(hipMalloc(&h->d_data, packed.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(h->d_data, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
-        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(h->shape->seg_wide), lds)) return rc;
+        if (int rc = raise_lds_limit(reinterpret_cast<const void*>(segment_function(h)), lds)) return rc;
         if (int rc = raise_lds_limit(reinterpret_cast<const void*>(h->shape->model_wide), lds)) return rc;
         {
             // Speculation over work-groups (one per CU): group g computes step i + g; all Rl x G groups must be resident (they wait
@@ -522,7 +545,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
             const int want = h->cfg.groups_per_replica;
             if (want != 0 && want != 1 && want != 2 && want != 4) return fail(-1, "wide nets: groups_per_replica must be 0 (auto), 1, 2 or 4");
             int per_cu = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(h->shape->seg_wide), h->nthreads, lds));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(segment_function(h)), h->nthreads, lds));
             h->blocks_per_cu = per_cu;
             const long long cap = (long long)per_cu * h->num_cus;
             int G = 1;
@@ -733,40 +756,27 @@ int ptnn_set_state(ptnn_handle* h, const float* w0, const float* temperatures) {
     if (!h || !w0 || !temperatures) return fail(-1, "null argument");
     if (!h->have_data) return fail(-1, "call ptnn_set_data before ptnn_set_state");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    if (int rc = wait_stream(h)) return rc;                // a restart must not overtake a run still in flight
-    const int Rl = h->cfg.n_replicas_local, P = h->P, PS = h->PS, S = h->cap;
-    std::vector<float> st((size_t)Rl * PS, 0.0f), ones((size_t)Rl * PS, 1.0f);
-    for (int r = 0; r < Rl; ++r) std::memcpy(&st[(size_t)r * PS], w0 + (size_t)r * P, P * sizeof(float));
-    HIP_TRY(hipMemcpy(h->d_state[0], st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->d_state[1], st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->d_rec_w, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));   // pos_w row 0 = ones (REG:240)
-    for (int b = 0; b < 2; ++b) {
-        HIP_TRY(hipMemset(h->d_gd_w[b], 0, (size_t)Rl * PS * sizeof(float)));
-        HIP_TRY(hipMemset(h->d_gd_valid[b], 0, (size_t)Rl * sizeof(int)));
-    }
-    HIP_TRY(hipMemset(h->d_st_f, 0, (size_t)Rl * SF_COUNT * sizeof(float)));
-    HIP_TRY(hipMemset(h->d_st_i, 0, (size_t)Rl * SI_COUNT * sizeof(int)));
-    HIP_TRY(hipMemcpy(h->d_temps, temperatures, Rl * sizeof(float), hipMemcpyHostToDevice));
-    // row 0 of every trace (Q7): pos_w = 1, likeh = -100, the rest 0 -- written by a kernel on the handle's stream, ahead of the
-    // run's first segment (a whole-run restart is part of the benchmark's timed region).  Rows 1 .. S-1 need no clearing: every
-    // one of them is written by the MH step it belongs to before ptnn_get_traces lets anybody read it.
-    hipLaunchKernelGGL(trace_row0_kernel, dim3(Rl), dim3(256), 0, h->stream, h->d_pos_w, h->d_scal, P, h->PW, (size_t)S);
+    if (int rc = wait_stream(h)) return rc;                // a restart must not overtake a run still in flight (nor the staging buffer)
+    const int Rl = h->cfg.n_replicas_local, P = h->P;
+    // one pinned staging buffer, one asynchronous copy, one kernel -- all on the handle's stream (a whole-run restart is part of
+    // the benchmark's timed region).  Trace rows 1 .. S-1 need no clearing: every one of them is written by the MH step it
+    // belongs to before ptnn_get_traces lets anybody read it.
+    std::memcpy(h->h_stage, w0, (size_t)Rl * P * sizeof(float));
+    std::memcpy(h->h_stage + (size_t)Rl * P, temperatures, (size_t)Rl * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(h->d_stage, h->h_stage, ((size_t)Rl * P + Rl) * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    ResetParams q{};
+    q.R = h->cfg.n_replicas_global; q.Rl = Rl; q.P = P; q.PS = h->PS; q.PW = h->PW; q.cap = (size_t)h->cap;
+    q.w0 = h->d_stage; q.temps_in = h->d_stage + (size_t)Rl * P;
+    q.state0 = h->d_state[0]; q.state1 = h->d_state[1]; q.rec_w = h->d_rec_w; q.gd0 = h->d_gd_w[0]; q.gd1 = h->d_gd_w[1];
+    q.st_f = h->d_st_f; q.temps = h->d_temps; q.pos_w = h->d_pos_w; q.scal = h->d_scal;
+    q.gd_valid0 = h->d_gd_valid[0]; q.gd_valid1 = h->d_gd_valid[1]; q.st_i = h->d_st_i; q.error = h->d_error;
+    q.label0 = h->d_label[0]; q.label1 = h->d_label[1]; q.slot0 = h->d_slot_of[0]; q.slot1 = h->d_slot_of[1];
+    q.counters = h->d_counters;
+    hipLaunchKernelGGL(chain_reset_kernel, dim3(Rl), dim3(256), 0, h->stream, q);
     HIP_TRY(hipGetLastError());
-    h->flip = 0; h->cur = 0; h->rounds_done = 0; h->finalized = false; h->drained = 0; h->first_row = 0;
-    HIP_TRY(hipMemset(h->d_counters, 0, 2 * sizeof(long long)));
-    HIP_TRY(hipMemset(h->d_error, 0, sizeof(int)));           // a restart clears a failed run (a failed communicator stays failed)
-    if (!h->comm.failed) { h->failed = false; h->failure.clear(); }
+    h->flip = 0; h->cur = 0; h->rounds_done = 0; h->finalized = false; h->drained = 0; h->first_row = 0; h->lflip = 0;
+    if (!h->comm.failed) { h->failed = false; h->failure.clear(); }   // a restart clears a failed run (a failed communicator stays failed)
     *h->h_progress = 0;
-    {
-        std::vector<int> ident(h->cfg.n_replicas_global);
-        for (size_t k = 0; k < ident.size(); ++k) ident[k] = (int)k;
-        for (int b = 0; b < 2; ++b) {
-            HIP_TRY(hipMemcpy(h->d_label[b], ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(h->d_slot_of[b], ident.data(), ident.size() * sizeof(int), hipMemcpyHostToDevice));
-        }
-        h->lflip = 0;
-    }
-    HIP_TRY(hipStreamSynchronize(nullptr));                  // the fills above ran on the null stream: done before anything is launched
     h->have_state = true;
     return 0;
 }
@@ -1141,7 +1151,32 @@ int ptnn_get_traces(ptnn_handle* h, int step0, int nsteps, float* pos_w, float* 
         }
         return hipSuccess;
     };
-    if (pos_w) {
+    std::vector<float> rows;
+    const bool want_scalars = likeh || rmse_train || rmse_test || acc_train || acc_test || accept_count;
+    if (want_scalars || (pos_w && h->compact)) {
+        // the scalars of a step sit in one 32-byte row on the device (one sector per step instead of seven); the per-file
+        // arrays of the reference's layout (REG:454-481) are split out below
+        rows.resize((size_t)Rl * nsteps * TR_COUNT);
+        HIP_TRY(copy2d(rows.data(), h->d_scal, sizeof(float), TR_COUNT));
+    }
+    if (pos_w && h->compact) {
+        // compact traces (wide nets, every row resident): a rejected step wrote no pos_w row, only the index of the row it
+        // repeats (pos_w[i+1] = pos_w[i], REG:417).  Fetch every distinct source row once and fill the repeats in on the host.
+        const size_t PW = h->PW;
+        for (int r = 0; r < Rl; ++r) {
+            int prev = -1;
+            for (int t = 0; t < nsteps; ++t) {
+                int32_t src;
+                std::memcpy(&src, &rows[((size_t)r * nsteps + t) * TR_COUNT + TR_SRC], sizeof src);
+                if (src < 0 || src > step0 + t || src < h->first_row - 1)
+                    return fail(-2, "trace row %d of replica %d refers to row %d (internal error)", step0 + t, r, src);
+                float* dst = pos_w + ((size_t)r * nsteps + t) * P;
+                if (t > 0 && src == prev) std::memcpy(dst, dst - P, (size_t)P * sizeof(float));
+                else HIP_TRY(hipMemcpy(dst, h->d_pos_w + ((size_t)r * cap + (size_t)(src % cap)) * PW, (size_t)P * sizeof(float), hipMemcpyDeviceToHost));
+                prev = src;
+            }
+        }
+    } else if (pos_w) {
         // device rows are padded to PW floats (whole sectors); the caller's array is dense: one strided copy per replica
         // and ring piece
         const size_t PW = h->PW;
@@ -1157,11 +1192,7 @@ int ptnn_get_traces(ptnn_handle* h, int step0, int nsteps, float* pos_w, float* 
             }
         }
     }
-    if (likeh || rmse_train || rmse_test || acc_train || acc_test || accept_count) {
-        // the scalars of a step sit in one 32-byte row on the device (one sector per step instead of seven); the per-file
-        // arrays of the reference's layout (REG:454-481) are split out here
-        std::vector<float> rows((size_t)Rl * nsteps * TR_COUNT);
-        HIP_TRY(copy2d(rows.data(), h->d_scal, sizeof(float), TR_COUNT));
+    if (want_scalars) {
         float* outs[5] = {likeh, rmse_train, rmse_test, acc_train, acc_test};
         const int cols[5] = {TR_LIKEH, TR_RMSE_TR, TR_RMSE_TE, TR_ACC_TR, TR_ACC_TE};
         const size_t n = (size_t)Rl * nsteps;
@@ -1360,6 +1391,16 @@ int ptnn_checkpoint_load(ptnn_handle* h, const void* buf, int64_t bytes) {
     if (int rc = put(h->d_label[0], sizeof(int) * R)) return rc;
     if (int rc = put(h->d_slot_of[0], sizeof(int) * R)) return rc;
     HIP_TRY(hipMemcpy(h->d_state[1], h->d_state[0], sizeof(float) * Rl * PS, hipMemcpyDeviceToDevice));
+    if (h->compact) {
+        // compact traces: the rows a later rejected step may repeat are not on this device -- put the recorded row of every chain
+        // into trace row hd.cur (the last one before the checkpoint) and point the chains at it
+        HIP_TRY(hipMemcpy2D(h->d_pos_w + (size_t)(hd.cur % h->cap) * h->PW, (size_t)h->cap * h->PW * sizeof(float), h->d_rec_w,
+                            PS * sizeof(float), (size_t)h->P * sizeof(float), Rl, hipMemcpyDeviceToDevice));
+        std::vector<int> si(Rl * SI_COUNT);
+        HIP_TRY(hipMemcpy(si.data(), h->d_st_i, si.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (size_t r = 0; r < Rl; ++r) si[r * SI_COUNT + SI_REC_ROW] = hd.cur;
+        HIP_TRY(hipMemcpy(h->d_st_i, si.data(), si.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemcpy(h->d_counters, hd.counters, sizeof(hd.counters), hipMemcpyHostToDevice));
     h->cur = hd.cur; h->rounds_done = hd.rounds_done; h->finalized = hd.finalized != 0; h->have_ladder = hd.have_ladder != 0;
     h->drained = hd.cur; h->first_row = hd.cur + 1;
@@ -1439,8 +1480,8 @@ int ptnn_tape(ptnn_handle* h, int replica, int step, float* noise, float* scal) 
 int ptnn_describe(ptnn_handle* h, char* buf, int nbytes) {
     if (!h || !buf || nbytes < 1) return fail(-1, "bad argument");
     if (!h->have_data) return fail(-1, "ptnn_set_data has not been called (the schedule depends on the data set)");
-    const char* kern = h->wide ? "segment_wide_kernel" : (h->tree ? "segment_tree_kernel" : (h->packed ? "segment_pack_kernel" : (h->speculative ? "segment_spec_kernel" : "segment_kernel")));
-    const void* fn = reinterpret_cast<const void*>(h->wide ? h->shape->seg_wide : (h->tree ? h->shape->tree : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg))));
+    const char* kern = h->wide ? (h->wide_res ? "segment_wide_res_kernel" : "segment_wide_kernel") : (h->tree ? "segment_tree_kernel" : (h->packed ? "segment_pack_kernel" : (h->speculative ? "segment_spec_kernel" : "segment_kernel")));
+    const void* fn = reinterpret_cast<const void*>(segment_function(h));
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, h->nthreads, h->seg_lds));
@@ -1452,12 +1493,13 @@ int ptnn_describe(ptnn_handle* h, char* buf, int nbytes) {
     const int n = std::snprintf(buf, (size_t)nbytes,
                                 "{\"kernel\": \"ptnn::%s<%d,%d,%d>\", \"schedule\": \"%s\", \"grid_blocks\": %d, \"block_threads\": %d, "
                                 "\"lds_bytes\": %zu, \"groups_per_replica\": %d, \"slots_per_round\": %d, \"num_cus\": %d, "
-                                "\"blocks_per_cu\": %d, \"vgprs\": %d, \"scratch_bytes\": %zu, \"forward_mfma\": %d, \"exchange\": \"%s\"}",
+                                "\"blocks_per_cu\": %d, \"vgprs\": %d, \"scratch_bytes\": %zu, \"forward_mfma\": %d, \"exchange\": \"%s\", \"lds_resident_state\": %d, \"compact_traces\": %d}",
                                 kern, h->cfg.task, h->cfg.n_in, h->cfg.n_out,
                                 h->wide ? (h->groups > 1 ? "speculative-wide" : "cooperative-wide") : (h->tree ? "prefetching-tree" : (h->packed ? "packed-speculative" : (h->speculative ? "speculative" : "cooperative"))),
                                 grid, h->nthreads, h->seg_lds, h->groups, slots, h->num_cus, per_cu, fa.numRegs, (size_t)fa.localSizeBytes,
                                 (h->fw_mfma || (h->wide && h->cfg.n_hidden % 32 == 0)) ? 1 : 0,
-                                h->comm.kind == COMM_NONE ? "none" : (h->cfg.label_swap ? "labels" : (resolved_xchg_mode(h) == PTNN_XCHG_GATHER ? "gather" : "boundary")));
+                                h->comm.kind == COMM_NONE ? "none" : (h->cfg.label_swap ? "labels" : (resolved_xchg_mode(h) == PTNN_XCHG_GATHER ? "gather" : "boundary")),
+                                h->wide_res ? 1 : 0, h->compact ? 1 : 0);
     if (n < 0 || n >= nbytes) return fail(-1, "buffer of %d bytes is too small for the description", nbytes);
     return n;
 }

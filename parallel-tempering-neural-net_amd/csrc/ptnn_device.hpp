@@ -35,18 +35,20 @@ constexpr uint32_t STREAM_STEP = 0, STREAM_WNOISE = 1, STREAM_SWAP = 2, STREAM_I
 
 // per-replica float state (st_f) and int state (st_i) slots
 enum { SF_LIK = 0, SF_PRIOR, SF_TAU_LAST, SF_REC_RMSE_TR, SF_REC_RMSE_TE, SF_REC_ACC_TR, SF_REC_ACC_TE, SF_COUNT = 8 };
-enum { SI_NACC = 0, SI_UNUSED, SI_LG_COUNT, SI_LG_ACC, SI_COUNT = 4 };   // accepted steps, -, Langevin steps proposed / accepted
+enum { SI_NACC = 0, SI_REC_ROW, SI_LG_COUNT, SI_LG_ACC, SI_COUNT = 4 };   // accepted steps, trace row holding the last recorded pos_w (compact traces), Langevin steps proposed / accepted
 // scalar trace row of MH step i (row i + 1): what the per-chain result files need beside pos_w (REG:454-481) -- likeh_list
 // column 0 (REG:391 / CLS:404), rmse_train, rmse_test, acc_train, acc_test, accept_list (the count BEFORE the step, REG:380, as
 // int bits) -- plus the step's log alpha as the kernel computed it (diagnostic: the parity tests measure its fp32 error with it)
-enum { TR_LIKEH = 0, TR_RMSE_TR, TR_RMSE_TE, TR_ACC_TR, TR_ACC_TE, TR_ACCEPT, TR_LOGALPHA, TR_PAD, TR_COUNT = 8 };
+// TR_SRC (int bits): compact traces only -- the trace row that holds this step's pos_w values (the step's own row when it was
+// accepted, else the row of the last accepted step: pos_w[i+1] = pos_w[i] on a reject, REG:417); 0 in the full layout
+enum { TR_LIKEH = 0, TR_RMSE_TR, TR_RMSE_TE, TR_ACC_TR, TR_ACC_TE, TR_ACCEPT, TR_LOGALPHA, TR_SRC, TR_COUNT = 8 };
 
 // one lane writes the whole row: two 16-byte stores into one 32-byte sector
 __device__ __forceinline__ void store_trace_row(float* __restrict__ row, float likeh, float rm_tr, float rm_te, float ac_tr, float ac_te,
-                                                int accept_before, float logalpha) {
+                                                int accept_before, float logalpha, int src_row = 0) {
     float4* q = reinterpret_cast<float4*>(row);
     q[0] = make_float4(likeh, rm_tr, rm_te, ac_tr);
-    q[1] = make_float4(ac_te, __int_as_float(accept_before), logalpha, 0.0f);
+    q[1] = make_float4(ac_te, __int_as_float(accept_before), logalpha, __int_as_float(src_row));
 }
 
 struct SegParams {
@@ -90,6 +92,8 @@ struct SegParams {
     const float* xt;         // wide nets: transposed data image Xt[k][Npad] (B operand of the MFMA forward pass), or null
     int Npad;                // rows of Xt, Nall rounded up to 32
     int forward_bf16;        // 1: forward GEMM operands rounded to bf16 (fp32 accumulate); 0: exact fp32 MFMA
+    int compact;             // wide nets, all rows resident (trace_cap == S): a REJECTED step writes no pos_w row, only the index of the
+                             // row it repeats (TR_SRC); ptnn_get_traces fills the rows in.  A 70 KB copy per rejected step otherwise.
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -2241,9 +2245,10 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
 // the proposal and the reduction scratch; the data set is read through the scalar cache (wave-uniform rows) in the sweep
 // and through L2 in the forward pass.  All waves of a work-group share one MH step; several work-groups per replica speculate over steps (segment_wide_kernel).
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ inline size_t wide_lds_floats(int H, int FWS, int O, int PS) {
+// res: the current state vector is kept in LDS next to the proposal (matrix-core layout only: there the flat image IS the proposal)
+__host__ __device__ inline size_t wide_lds_floats(int H, int FWS, int O, int PS, bool res = false) {
     const size_t img = (fw_floats(H, FWS) > (size_t)PS) ? fw_floats(H, FWS) : (size_t)PS;   // packed or flat image
-    return img + MAX_WAVES * 8 + 2 * MAX_WAVES * (size_t)((O + 3) & ~3) + 16 + 6 * 8;   // + per-slot scalars of a window (WIDE_WINDOW = 8)
+    return img + (res ? (size_t)PS : 0) + MAX_WAVES * 8 + 2 * MAX_WAVES * (size_t)((O + 3) & ~3) + 16 + 6 * 8;   // + per-slot scalars of a window (WIDE_WINDOW = 8)
 }
 __host__ __device__ inline size_t wide_img_floats(int H, int FWS, int PS) {
     return (fw_floats(H, FWS) > (size_t)PS) ? fw_floats(H, FWS) : (size_t)PS;
@@ -2264,10 +2269,12 @@ __host__ __device__ inline size_t wide_img_floats(int H, int FWS, int PS) {
 // register copies (the plain chain spent 136 issue slots per row: 32 dependent v_fmac, 16 v_pk_fma, 16 v_mov_b64 of row
 // buffers, 10 flat loads).  Called out of line: inlined twice into the segment kernel next to the two MFMA forward variants
 // it pushed 312 VGPRs of the kernel into scratch (1236 B per lane for the 32-H-1 shape).
+// w_ref (optional): returns this thread's share of |w_ref - w_out|^2, summed from the registers the result is written from -- the
+// first term of the Langevin proposal ratio (REG:336-340) without reading the 70 KB result back.
 template <int TASK, int I, int O>
-__device__ __attribute__((noinline, aligned(256))) void sgd_sweep_wide(const float* __restrict__ w_in, float* __restrict__ w_out,
-                                                         const float* __restrict__ data, int IPY, int Ntr, int H, float lr,
-                                                         float* __restrict__ part) {
+__device__ __attribute__((noinline, aligned(256))) float sgd_sweep_wide(const float* __restrict__ w_in, float* __restrict__ w_out,
+                                                          const float* __restrict__ data, int IPY, int Ntr, int H, float lr,
+                                                          float* __restrict__ part, const float* w_ref = nullptr) {
     constexpr float C = -LOG2E, IC = -LN2;
     constexpr int OP = (O + 3) & ~3;
     constexpr int IP = (I + 1) / 2;                                   // input pairs (an odd I is padded with a zero weight)
@@ -2395,18 +2402,24 @@ __device__ __attribute__((noinline, aligned(256))) void sgd_sweep_wide(const flo
         for (int i = 0; i < IP; ++i) w1[i] = __builtin_elementwise_fma(l2, xu[i], w1[i]);
         nb1 += lhd_p;
     }
+    float d1 = 0.0f;
+    auto put = [&](int idx, float v) {
+        w_out[idx] = v;
+        if (w_ref) { const float d = w_ref[idx] - v; d1 = fmaf(d, d, d1); }
+    };
     if (act) {
 #pragma unroll
-        for (int i = 0; i < I; ++i) w_out[i * H + t] = IC * w1[i >> 1][i & 1];
+        for (int i = 0; i < I; ++i) put(i * H + t, IC * w1[i >> 1][i & 1]);
 #pragma unroll
-        for (int o = 0; o < O; ++o) w_out[oW2 + t * O + o] = IC * w2[o];
-        w_out[oB1 + t] = -IC * nb1;
+        for (int o = 0; o < O; ++o) put(oW2 + t * O + o, IC * w2[o]);
+        put(oB1 + t, -IC * nb1);
     }
     if (t == 0) {
 #pragma unroll
-        for (int o = 0; o < O; ++o) w_out[oB2 + o] = -IC * cl[o];
+        for (int o = 0; o < O; ++o) put(oB2 + o, -IC * cl[o]);
     }
     __syncthreads();
+    return d1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2590,9 +2603,15 @@ __device__ __forceinline__ EvalSums wide_forward(const SegParams& p, const float
 // Every group keeps its own copy of the chain vectors (group 0 the canonical rows, the others rows of the scratch buffer) and
 // applies the same commits; what crosses CUs are {tag, value} granules: one verdict per step, and -- only from the group whose step
 // was accepted -- its record and its vectors (proposal, SGD epoch).
+//
+// RES (matrix-core forward only, where the flat LDS image the MFMAs read IS the proposal): the CURRENT state lives in LDS too
+// (2 x 70 KB of the 160 KB for the 32-512-1 net), the proposal is never written to global memory, the SGD epoch of a Langevin
+// step reads it from LDS and hands back its share of |w - w_prop_gd|^2 from registers.  With compact traces (p.compact) a
+// rejected step moves no vector at all: per step a random-walk proposal touches global memory for nothing but the shared data
+// image, a Langevin one reads the cached epoch (70 KB) and writes its own (70 KB).  It was 280 - 560 KB per step and group.
 constexpr int WIDE_WINDOW = 8;
-template <int TASK, int I, int O>
-__global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegParams p, const int step_begin, const int n_steps) {
+template <int TASK, int I, int O, bool RES>
+__device__ __forceinline__ void segment_wide_body(const SegParams& p, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int OP = (O + 3) & ~3;
     const int G = p.G;
@@ -2601,7 +2620,8 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int P = p.P, PS = p.PS, H = p.H;
     float* fw = smem;
-    float* red = fw + wide_img_floats(H, p.FWS, PS);
+    float* wc = fw + wide_img_floats(H, p.FWS, PS);             // RES: the current state (w, eta)
+    float* red = wc + (RES ? PS : 0);
     float* part = red + MAX_WAVES * 8;
     float* scal = part + 2 * MAX_WAVES * OP;                    // 16 floats: staging of an accepted foreign record; then per window slot:
     float* s_u = scal + 16;                                     // the step's uniform
@@ -2612,17 +2632,20 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
     float* s_v = s_la + WIDE_WINDOW;                            // verdicts of the window: 0 rejected, 1 accepted, 2 never computed
     const float* xy = p.data;                                   // global (L2 / scalar cache)
     float* const mine = p.wide_scratch + (size_t)(r * G + grp) * 5 * PS;
-    float* w_prop = mine;
+    float* w_prop = RES ? fw : mine;                            // RES: the flat LDS image is the proposal
     float* w_pgd = mine + PS;
-    float* w_cur = (grp == 0) ? p.w_state + (size_t)r * PS : mine + 2 * (size_t)PS;   // chain state row (group 0: updated in place)
+    float* w_cur = RES ? wc : ((grp == 0) ? p.w_state + (size_t)r * PS : mine + 2 * (size_t)PS);   // chain state row (group 0: the canonical one)
     float* w_gd = (grp == 0) ? p.gd_w + (size_t)r * PS : mine + 3 * (size_t)PS;
     float* rec_w = (grp == 0) ? p.rec_w + (size_t)r * PS : mine + 4 * (size_t)PS;
-    if (grp > 0) {
+    const bool compact = p.compact != 0;
+    if (grp > 0 || RES) {
         // (group 0 touches the canonical rows at its first commit, which needs this group's first verdicts)
         for (int q = tid; q < PS / 4; q += nthr) {
-            reinterpret_cast<float4*>(w_cur)[q] = reinterpret_cast<const float4*>(p.w_state + (size_t)r * PS)[q];
-            reinterpret_cast<float4*>(w_gd)[q] = reinterpret_cast<const float4*>(p.gd_w + (size_t)r * PS)[q];
-            reinterpret_cast<float4*>(rec_w)[q] = reinterpret_cast<const float4*>(p.rec_w + (size_t)r * PS)[q];
+            if (grp > 0 || RES) reinterpret_cast<float4*>(w_cur)[q] = reinterpret_cast<const float4*>(p.w_state + (size_t)r * PS)[q];
+            if (grp > 0) {
+                reinterpret_cast<float4*>(w_gd)[q] = reinterpret_cast<const float4*>(p.gd_w + (size_t)r * PS)[q];
+                reinterpret_cast<float4*>(rec_w)[q] = reinterpret_cast<const float4*>(p.rec_w + (size_t)r * PS)[q];
+            }
         }
         __syncthreads();
     }
@@ -2635,18 +2658,18 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
     float* sf = p.st_f + (size_t)r * SF_COUNT;
     int* si = p.st_i + (size_t)r * SI_COUNT;
     float lik, prior_cur, tau_eta_last, rec_rmse_tr, rec_rmse_te, rec_acc_tr, rec_acc_te;
-    int nacc, gd_valid, lg_count;
+    int nacc, gd_valid, lg_count, rec_row;
     if (step_begin == 0) {
         chain_startup<TASK, I, O>(p, xy, w_cur, fw, red, T, eta, lik, prior_cur);
         tau_eta_last = eta;
         rec_rmse_tr = rec_rmse_te = rec_acc_tr = rec_acc_te = 0.f;
-        nacc = 0; gd_valid = 0; lg_count = 0;
+        nacc = 0; gd_valid = 0; lg_count = 0; rec_row = 0;
         __syncthreads();
     } else {
         lik = sf[SF_LIK]; prior_cur = sf[SF_PRIOR]; tau_eta_last = sf[SF_TAU_LAST];
         rec_rmse_tr = sf[SF_REC_RMSE_TR]; rec_rmse_te = sf[SF_REC_RMSE_TE];
         rec_acc_tr = sf[SF_REC_ACC_TR]; rec_acc_te = sf[SF_REC_ACC_TE];
-        nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT];
+        nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT]; rec_row = si[SI_REC_ROW];
     }
 
     const size_t trow = (size_t)r * p.trace_cap;        // traces are rings of trace_cap rows per replica (== S unless streaming)
@@ -2722,10 +2745,9 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
             // layout) and in its global row, and add up |proposal|^2 (prior) and |noise|^2 (Langevin ratio) on the way.  The
             // noise itself is never stored.  (It used to be five passes through global memory: tape, proposal, image copy and
             // the two norms.)
-            const bool img_direct = wide_mfma(p);
+            const bool img_direct = RES || wide_mfma(p);
             float ssq_part = 0.0f, nsq_part = 0.0f;
-            {
-                const float* base = lg ? w_gd : w_cur;
+            auto propose = [&](const float* __restrict__ base) {
                 for (int q = tid; q < nv; q += nthr) {
                     uint32_t x[4];
                     philox4x32_10((uint32_t)q, (uint32_t)j, p.noise_shared ? 0u : (uint32_t)gid, STREAM_WNOISE, p.seed_lo, p.seed_hi, x);
@@ -2737,7 +2759,7 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
                         const float4 b = *reinterpret_cast<const float4*>(base + j0);
                         const float4 v = make_float4(fmaf(p.step_w, n[0], b.x), fmaf(p.step_w, n[1], b.y), fmaf(p.step_w, n[2], b.z),
                                                      fmaf(p.step_w, n[3], b.w));
-                        *reinterpret_cast<float4*>(w_prop + j0) = v;
+                        if (!RES) *reinterpret_cast<float4*>(w_prop + j0) = v;
                         if (img_direct) *reinterpret_cast<float4*>(fw + j0) = v;
                         ssq_part = fmaf(v.x, v.x, ssq_part); ssq_part = fmaf(v.y, v.y, ssq_part);
                         ssq_part = fmaf(v.z, v.z, ssq_part); ssq_part = fmaf(v.w, v.w, ssq_part);
@@ -2748,18 +2770,26 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
                         for (int e = 0; e < 4; ++e)
                             if (j0 + e < P) {
                                 const float v = fmaf(p.step_w, n[e], base[j0 + e]);
-                                w_prop[j0 + e] = v;
+                                if (!RES) w_prop[j0 + e] = v;
                                 if (img_direct) fw[j0 + e] = v;
                                 ssq_part = fmaf(v, v, ssq_part);
                                 nsq_part = fmaf(n[e], n[e], nsq_part);
                             }
                     }
                 }
-            }
+            };
+            // (two calls, not one pointer picked at run time: with RES the random-walk base is in LDS and the cached epoch in
+            // global memory, and a pointer that may be either costs flat accesses in the one loop every step runs)
+            if (lg) propose(w_gd);
+            else propose(w_cur);
             __syncthreads();
             if (lg) {
-                sgd_sweep_wide<TASK, I, O>(w_prop, w_pgd, xy, p.IPY, p.Ntr, H, p.lr, part);
-                const float d1 = block_sumsq_diff(w_cur, w_pgd, P, red);
+                float d1;
+                if constexpr (RES) d1 = block_sum(sgd_sweep_wide<TASK, I, O>(w_prop, w_pgd, xy, p.IPY, p.Ntr, H, p.lr, part, w_cur), red);
+                else {
+                    sgd_sweep_wide<TASK, I, O>(w_prop, w_pgd, xy, p.IPY, p.Ntr, H, p.lr, part);
+                    d1 = block_sumsq_diff(w_cur, w_pgd, P, red);
+                }
                 const float d2 = block_sum(nsq_part, red);
                 diff_prop = langevin_ratio(d1, d2, p.step_w, adapttemp);
             }
@@ -2837,27 +2867,33 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
             if (!((my_steps >> s_) & 1u)) continue;
             const bool acc_row = acc_me && (s_ == m);
             const size_t tpos = trow + (size_t)((i + s_ + 1) % p.trace_cap);
-            float* prow = p.tr_pos_w + tpos * (size_t)p.PW;
-            for (int e = 4 * nv + tid; e < p.PW; e += nthr) prow[e] = 0.0f;
-            const float* src = acc_row ? w_prop : rec_w;
-            for (int q = tid; q < nv; q += nthr) {
-                float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
-                if (4 * q + 3 >= P) {                        // the last, partial quad: nothing past P
-                    if (4 * q + 1 >= P) v.y = 0.0f;
-                    if (4 * q + 2 >= P) v.z = 0.0f;
-                    v.w = 0.0f;
-                }
-                *reinterpret_cast<float4*>(prow + 4 * q) = v;
+            if (acc_row || !compact) {                          // compact traces: a rejected step repeats row rec_row, no vector moves
+                float* prow = p.tr_pos_w + tpos * (size_t)p.PW;
+                for (int e = 4 * nv + tid; e < p.PW; e += nthr) prow[e] = 0.0f;
+                auto copy_row = [&](const float* __restrict__ src) {
+                    for (int q = tid; q < nv; q += nthr) {
+                        float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+                        if (4 * q + 3 >= P) {                    // the last, partial quad: nothing past P
+                            if (4 * q + 1 >= P) v.y = 0.0f;
+                            if (4 * q + 2 >= P) v.z = 0.0f;
+                            v.w = 0.0f;
+                        }
+                        *reinterpret_cast<float4*>(prow + 4 * q) = v;
+                    }
+                };
+                if (acc_row) copy_row(w_prop);
+                else copy_row(rec_w);
             }
             if (tid == 0) {
                 const float lp = s_lik[s_];
                 store_trace_row(p.tr_scal + tpos * TR_COUNT, (TASK == TASK_REG) ? lp : lp * adapttemp,
                                 acc_row ? a_rm_tr : rec_rmse_tr, acc_row ? a_rm_te : rec_rmse_te, acc_row ? a_ac_tr : rec_acc_tr,
-                                acc_row ? a_ac_te : rec_acc_te, acc_before, s_la[s_]);
+                                acc_row ? a_ac_te : rec_acc_te, acc_before, s_la[s_], compact ? (acc_row ? i + s_ + 1 : rec_row) : 0);
             }
         }
         if (m < k) {
             nacc += 1;
+            rec_row = i + m + 1;
             gd_valid = lg_m ? 1 : 0;
             __syncthreads();                                    // the trace rows above have read rec_w
             if (acc_me) {
@@ -2911,16 +2947,33 @@ __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegPara
         if (tid == 0) atomicAdd(p.error_flag, 1);           // a bounded spin ran out: the host reports it
         return;
     }
+    if (RES && grp == 0) {                                      // the state back to its canonical row: swap rounds and the next launch read it
+        __syncthreads();
+        float* row = p.w_state + (size_t)r * PS;
+        for (int q = tid; q < PS / 4; q += nthr) reinterpret_cast<float4*>(row)[q] = reinterpret_cast<const float4*>(w_cur)[q];
+        __syncthreads();
+        w_cur = row;
+    }
     if (grp == 0 && tid == 0) {
         w_cur[P] = eta;
         sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur; sf[SF_TAU_LAST] = tau_eta_last;
         sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;
         sf[SF_REC_ACC_TR] = rec_acc_tr; sf[SF_REC_ACC_TE] = rec_acc_te;
-        si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count;
+        si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count; si[SI_REC_ROW] = rec_row;
         p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;
         p.L_final[gid] = lik;
         post_raw(p, gid, lik, prior_cur, T, step_begin + n_steps - 1);
     }
+}
+
+template <int TASK, int I, int O>
+__global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegParams p, const int step_begin, const int n_steps) {
+    segment_wide_body<TASK, I, O, false>(p, step_begin, n_steps);
+}
+// state and proposal resident in LDS (host: matrix-core layout and 2 vectors + scratch fit in 160 KB)
+template <int TASK, int I, int O>
+__global__ void __launch_bounds__(MAX_THREADS) segment_wide_res_kernel(const SegParams p, const int step_begin, const int n_steps) {
+    segment_wide_body<TASK, I, O, true>(p, step_begin, n_steps);
 }
 
 // stand-alone model functions for wide nets: mode 0 = evaluate, 1 = langevin_gradient (mode 2, the tape, is shape
@@ -3100,13 +3153,43 @@ __global__ void xchg_pack_kernel(const SwapParams sp) {
     }
 }
 
-// Row 0 of every trace (Q7: pos_w = ones, REG:240; likeh = -100, REG:292-293; the rest zero), one block per local replica.
-// (These rows were two hipMemcpy2D calls with the trace ring's pitch; for Ionosphere's 74 MB pitch the runtime took 25 ms over
-// them -- a fifth of a whole 256-replica run, profiles/r03_gap_probe.json.)
-__global__ void trace_row0_kernel(float* __restrict__ pos_w, float* __restrict__ scal, int P, int PW, size_t cap) {
-    float* row = pos_w + (size_t)blockIdx.x * cap * PW;
-    for (int j = threadIdx.x; j < PW; j += blockDim.x) row[j] = (j < P) ? 1.0f : 0.0f;
-    if (threadIdx.x == 0) store_trace_row(scal + (size_t)blockIdx.x * cap * TR_COUNT, -100.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0, 0.0f);
+// Restart of the chains (ptnn_set_state), one block per local replica, everything a run starts from in ONE kernel on the handle's
+// stream: the initial weights into both state buffers (REG:649), the recorded row = ones and row 0 of every trace (Q7: pos_w =
+// ones, REG:240; likeh = -100, REG:292-293; the rest zero), the cached-gradient rows and flags, the per-chain scalars and
+// counters, the temperatures, the error flag, the swap counters and the identity slot <-> temperature maps.  (It was some twenty
+// blocking copies and fills on the null stream, two of them hipMemcpy2D calls with the trace ring's pitch -- 74 MB for Ionosphere,
+// where a restart cost 25 ms: a fifth of a whole 256-replica run, profiles/r03a_gap_probe_before.json.)
+struct ResetParams {
+    int R, Rl, P, PS, PW;
+    size_t cap;
+    const float* w0;          // [Rl][P]  staged initial weights
+    const float* temps_in;    // [Rl]
+    float *state0, *state1, *rec_w, *gd0, *gd1, *st_f, *temps, *pos_w, *scal;
+    int *gd_valid0, *gd_valid1, *st_i, *error, *label0, *label1, *slot0, *slot1;
+    long long* counters;
+};
+__global__ void chain_reset_kernel(const ResetParams q) {
+    const int r = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const size_t row = (size_t)r * q.PS;
+    for (int j = tid; j < q.PS; j += nthr) {
+        const float v = (j < q.P) ? q.w0[(size_t)r * q.P + j] : 0.0f;
+        q.state0[row + j] = v; q.state1[row + j] = v;
+        q.rec_w[row + j] = 1.0f;
+        q.gd0[row + j] = 0.0f; q.gd1[row + j] = 0.0f;
+    }
+    float* prow = q.pos_w + (size_t)r * q.cap * q.PW;
+    for (int j = tid; j < q.PW; j += nthr) prow[j] = (j < q.P) ? 1.0f : 0.0f;
+    if (tid == 0) {
+        store_trace_row(q.scal + (size_t)r * q.cap * TR_COUNT, -100.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0, 0.0f);
+        q.gd_valid0[r] = 0; q.gd_valid1[r] = 0;
+        q.temps[r] = q.temps_in[r];
+    }
+    if (tid < SF_COUNT) q.st_f[(size_t)r * SF_COUNT + tid] = 0.0f;
+    if (tid < SI_COUNT) q.st_i[(size_t)r * SI_COUNT + tid] = 0;
+    if (r == 0) {
+        if (tid == 0) { q.counters[0] = 0; q.counters[1] = 0; *q.error = 0; }
+        for (int k = tid; k < q.R; k += nthr) { q.label0[k] = k; q.label1[k] = k; q.slot0[k] = k; q.slot1[k] = k; }
+    }
 }
 
 __global__ void swap_kernel(const SwapParams sp, const int round, const int mode) {

@@ -25,5 +25,6 @@ struct Shape {
     model_fn model_wide;
     seg_fn pack;            // H <= 8: packed speculative schedule
     seg_fn tree;            // prefetching tree schedule (random-walk classification), H <= 64
+    seg_fn seg_wide_res;    // 64 < H <= 512, H % 32 == 0, state + proposal resident in LDS
 };
 }  // namespace ptnn

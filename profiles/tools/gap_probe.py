@@ -20,7 +20,7 @@ def child(workload, chunk):
     import bench
     wl = dict(bench.WORKLOADS[workload])
     train, test, _ = bench.load_data(wl["data"])
-    a = argparse.Namespace(waves=0, schedule=0, groups=0, bf16=False)
+    a = argparse.Namespace(waves=0, schedule=0, groups=0, bf16=False, shared_noise=1)
     lad = bench.Ladder(wl, a, train, test, 0, 1, 0)
     s = lad.s
     out = {"stride": os.environ.get("PTNN_TIMING_STRIDE", "1"), "runs": []}
