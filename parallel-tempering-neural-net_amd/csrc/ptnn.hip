@@ -77,6 +77,8 @@ struct ptnn_handle {
     bool wide = false;              // 64 < H: vectors in HBM, one thread per hidden unit
     bool wide_res = false;          // ... with the state and the proposal resident in LDS (matrix-core layout, 2 vectors fit)
     bool compact = false;           // wide nets with all trace rows resident: rejected steps record a row index, no pos_w row
+    bool persistent = false;        // all work-groups of the grid are resident: ptnn_run queues ONE launch, swap rounds inside
+    unsigned* d_barrier = nullptr;  // grid barrier counter of the persistent launch
     bool packed = false;            // H <= 16: packed speculative schedule on one CU
     bool tree = false;              // prefetching tree schedule: groups = 2^depth - 1 work-groups per replica
     bool tree_ahead = false;        // ... with room in LDS for two sets of tapes
@@ -194,46 +196,7 @@ void collect_timing(ptnn_handle* h) {
     h->timing_used = 0;
 }
 
-int launch_segment(ptnn_handle* h, int begin, int n) {
-    if (n <= 0) return 0;
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
-    // event pairs around a launch cost a pipeline bubble each; time every timing_stride-th launch only
-    const bool timed = h->timing_stride > 0 && (h->launch_count++ % h->timing_stride) == 0;
-    if (!timed) {
-        const SegParams p = h->seg_params();
-        const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
-        hipLaunchKernelGGL(segment_function(h), dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
-        h->epoch_base += (unsigned)n + 1u;
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-    if (h->timing_used == h->timing.size()) {
-        if (h->timing.size() >= 4096) {               // keep the pool bounded: drain it (synchronises)
-            if (int rc = wait_stream(h)) return rc;
-            collect_timing(h);
-        } else {
-            hipEvent_t a, b;
-            HIP_TRY(hipEventCreate(&a));
-            HIP_TRY(hipEventCreate(&b));
-            h->timing.emplace_back(a, b);
-        }
-    }
-    auto& ev = h->timing[h->timing_used++];
-    const SegParams p = h->seg_params();
-    HIP_TRY(hipEventRecord(ev.first, h->stream));
-    const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
-    hipLaunchKernelGGL(segment_function(h), dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream, p, begin, n);
-    h->epoch_base += (unsigned)n + 1u;                    // granule tags never repeat across launches
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev.second, h->stream));
-    return 0;
-}
-
-// mode bit 0 = apply moves (and flip), bit 1 = count + log, bit 2 = L and the source rows come from the gathered exchange
-// buffer; src_out optional.  mode -1 = pack the exchange rows of the local replicas.
-int launch_swap(ptnn_handle* h, bool phantom, int mode, bool want_src) {
-    HIP_TRY(hipSetDevice(h->cfg.device_id));
-    SwapParams sp{};
+void fill_swap_params(ptnn_handle* h, bool phantom, SwapParams& sp) {
     sp.R = h->cfg.n_replicas_global; sp.Rl = h->cfg.n_replicas_local; sp.first_global = h->cfg.first_global_replica;
     sp.PS = h->PS;
     sp.seed_lo = (uint32_t)(h->cfg.seed & 0xffffffffull); sp.seed_hi = (uint32_t)(h->cfg.seed >> 32);
@@ -241,7 +204,7 @@ int launch_swap(ptnn_handle* h, bool phantom, int mode, bool want_src) {
     sp.cur = h->d_state[h->flip]; sp.next = h->d_state[h->flip ^ 1];
     sp.gd_cur = h->d_gd_w[h->flip]; sp.gd_next = h->d_gd_w[h->flip ^ 1];
     sp.gd_valid_cur = h->d_gd_valid[h->flip]; sp.gd_valid_next = h->d_gd_valid[h->flip ^ 1];
-    sp.src_out = want_src ? h->d_src : nullptr;
+    sp.src_out = nullptr;
     sp.counters = h->d_counters; sp.src_log = h->d_src_log; sp.log_capacity = h->max_rounds;
     sp.rule = h->cfg.swap_rule; sp.L_raw = h->d_L_raw; sp.prior_post = h->d_prior_post; sp.temps_global = h->d_temps_global;
     sp.st_f = h->d_st_f;
@@ -251,7 +214,59 @@ int launch_swap(ptnn_handle* h, bool phantom, int mode, bool want_src) {
     sp.label_cur = h->d_label[h->lflip]; sp.slot_cur = h->d_slot_of[h->lflip];
     sp.label_next = h->d_label[h->lflip ^ 1]; sp.slot_next = h->d_slot_of[h->lflip ^ 1];
     sp.temps_local = h->d_temps;
-    sp.progress = (mode & 2) ? h->h_progress : nullptr;     // the counting pass of a round is its last kernel
+    sp.progress = nullptr;
+}
+
+// MH steps [begin, end) in one launch.  swap_inside: the swap rounds between the intervals run inside it (persistent launch:
+// every work-group resident, grid barriers); otherwise [begin, end) is one interval and the caller queues swap_kernel behind it.
+int launch_segment(ptnn_handle* h, int begin, int end, bool swap_inside = false) {
+    if (end <= begin) return 0;
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    const SegParams p = h->seg_params();
+    PersistParams pp{};
+    pp.end = end; pp.swap_inside = swap_inside ? 1 : 0; pp.task = h->cfg.task; pp.si = h->cfg.swap_interval;
+    pp.round0 = h->rounds_done; pp.flip0 = h->flip; pp.lflip0 = h->lflip;
+    const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
+    pp.nblocks = grid; pp.barrier = h->d_barrier;
+    for (int b = 0; b < 2; ++b) {
+        pp.state[b] = h->d_state[b]; pp.gd[b] = h->d_gd_w[b]; pp.gd_valid[b] = h->d_gd_valid[b];
+        pp.label[b] = h->d_label[b]; pp.slot_of[b] = h->d_slot_of[b];
+    }
+    fill_swap_params(h, false, pp.sp);
+    if (swap_inside) HIP_TRY(hipMemsetAsync(h->d_barrier, 0, sizeof(unsigned), h->stream));
+    // event pairs around a launch cost a pipeline bubble each; time every timing_stride-th launch only
+    const bool timed = h->timing_stride > 0 && (h->launch_count++ % h->timing_stride) == 0;
+    std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+    if (timed) {
+        if (h->timing_used == h->timing.size()) {
+            if (h->timing.size() >= 4096) {               // keep the pool bounded: drain it (synchronises)
+                if (int rc = wait_stream(h)) return rc;
+                collect_timing(h);
+            } else {
+                hipEvent_t a, b;
+                HIP_TRY(hipEventCreate(&a));
+                HIP_TRY(hipEventCreate(&b));
+                h->timing.emplace_back(a, b);
+            }
+        }
+        ev = &h->timing[h->timing_used++];
+        HIP_TRY(hipEventRecord(ev->first, h->stream));
+    }
+    hipLaunchKernelGGL(segment_function(h), dim3(grid), dim3(h->nthreads), h->seg_lds, h->stream, p, pp, begin);
+    h->epoch_base += (unsigned)(end - begin) + 1u + (swap_inside ? (unsigned)((end - begin) / h->cfg.swap_interval + 2) : 0u);   // granule tags never repeat across launches
+    HIP_TRY(hipGetLastError());
+    if (ev) HIP_TRY(hipEventRecord(ev->second, h->stream));
+    return 0;
+}
+
+// mode bit 0 = apply moves (and flip), bit 1 = count + log, bit 2 = L and the source rows come from the gathered exchange
+// buffer; src_out optional.  mode -1 = pack the exchange rows of the local replicas.
+int launch_swap(ptnn_handle* h, bool phantom, int mode, bool want_src) {
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    SwapParams sp{};
+    fill_swap_params(h, phantom, sp);
+    sp.src_out = want_src ? h->d_src : nullptr;
+    sp.progress = (mode >= 0 && (mode & 2)) ? h->h_progress : nullptr;     // the counting pass of a round is its last kernel
     if (mode == -1) {
         hipLaunchKernelGGL(xchg_pack_kernel, dim3(sp.Rl), dim3(64), 0, h->stream, sp);
         HIP_TRY(hipGetLastError());
@@ -330,6 +345,25 @@ int finish_stream(ptnn_handle* h) {
     return 0;
 }
 
+// One launch per run needs every work-group of the grid resident at once (they meet at grid barriers) and room in LDS for the
+// cascade of a swap round.  Decided per handle once the schedule is known; $PTNN_PERSISTENT=0 keeps one launch per interval.
+int resolve_persistent(ptnn_handle* h) {
+    h->persistent = false;
+    if (const char* e = std::getenv("PTNN_PERSISTENT")) if (e[0] == '0') return 0;
+    const size_t swap_lds = (size_t)(3 * h->cfg.n_replicas_global + 1) * sizeof(float);
+    if (swap_lds > h->seg_lds) {
+        if (swap_lds > 152 * 1024) return 0;
+        h->seg_lds = swap_lds;
+    }
+    const void* fn = reinterpret_cast<const void*>(segment_function(h));
+    if (int rc = raise_lds_limit(fn, h->seg_lds)) return rc;
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, h->nthreads, h->seg_lds));
+    const long long grid = (long long)h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
+    h->persistent = grid <= (long long)per_cu * h->num_cus;
+    return 0;
+}
+
 int check_ready(ptnn_handle* h) {
     if (!h) return fail(-1, "null handle");
     if (!h->have_data) return fail(-1, "ptnn_set_data has not been called");
@@ -384,6 +418,7 @@ int create_buffers(ptnn_handle* h, const ptnn_config* cfg, const Shape* sh, cons
     HIP_TRY(hipMalloc(&h->d_src_log, (size_t)h->max_rounds * R * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_counters, 2 * sizeof(long long)));
     HIP_TRY(hipMalloc(&h->d_error, sizeof(int)));
+    HIP_TRY(hipMalloc(&h->d_barrier, sizeof(unsigned)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), (Rl * h->P + Rl) * sizeof(float), hipHostMallocDefault));
     HIP_TRY(hipMalloc(&h->d_stage, (Rl * h->P + Rl) * sizeof(float)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_progress), sizeof(int), hipHostMallocDefault));
@@ -464,7 +499,7 @@ int ptnn_destroy(ptnn_handle* h) {
         if (hipStreamQuery(h->stream) == hipErrorNotReady) return fail(-7, "the stream of a failed communicator did not drain: handle leaked");
     }
     void* ptrs[] = {h->d_data, h->d_state[0], h->d_state[1], h->d_rec_w, h->d_gd_w[0], h->d_gd_w[1], h->d_gd_valid[0], h->d_gd_valid[1], h->d_st_f, h->d_st_i, h->d_temps,
-                    h->d_L_handoff, h->d_L_final, h->d_L_raw, h->d_prior_post, h->d_temps_global, h->d_pos_w, h->d_scal, h->d_src, h->d_label[0], h->d_label[1], h->d_slot_of[0], h->d_slot_of[1], h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_xverdict, h->d_stamps, h->d_wide_scratch, h->d_xt};
+                    h->d_L_handoff, h->d_L_final, h->d_L_raw, h->d_prior_post, h->d_temps_global, h->d_pos_w, h->d_scal, h->d_src, h->d_label[0], h->d_label[1], h->d_slot_of[0], h->d_slot_of[1], h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_xverdict, h->d_stamps, h->d_wide_scratch, h->d_xt, h->d_barrier};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_src) (void)hipHostFree(h->h_src);
@@ -575,6 +610,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
                 h->epoch_base = 1;                              // tag 0 = never written
             }
         }
+        if (int rc = resolve_persistent(h)) return rc;
         h->have_data = true;
         return 0;
     }
@@ -748,6 +784,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
     if (int rc = raise_lds_limit(reinterpret_cast<const void*>(h->tree ? h->shape->tree : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg))),
                                  h->seg_lds)) return rc;
     if (int rc = raise_lds_limit(reinterpret_cast<const void*>(h->shape->model), h->model_lds)) return rc;
+    if (int rc = resolve_persistent(h)) return rc;
     h->have_data = true;
     return 0;
 }
@@ -865,12 +902,27 @@ int ptnn_run(ptnn_handle* h, int n_steps) {
     if (h->cap < S && end - h->drained > h->cap - 1)
         return fail(-6, "trace ring of %d rows would overflow: rows from %d on have not been fetched; call ptnn_get_traces "
                         "first or run fewer steps", h->cap, h->drained + 1);
+    if (h->persistent && !sharded && h->cur < end) {
+        // every work-group of the grid is resident: ONE launch runs all the intervals up to `end`, the swap rounds between them
+        // inside the kernel (persistent_loop in ptnn_device.hpp); what is left to do here is the bookkeeping of those rounds
+        int n_ho = 0;
+        for (int c = h->cur; c < end;) {
+            int seg_end = c;
+            while (seg_end < end && !swap_trigger(h->cfg, seg_end)) ++seg_end;
+            if (seg_end >= end) break;
+            ++n_ho;
+            c = seg_end + 1;
+        }
+        if (int rc = launch_segment(h, h->cur, end, true)) return rc;
+        h->cur = end;
+        for (int k = 0; k < n_ho; ++k) round_queued(h, false);
+    }
     while (h->cur < end) {
         int seg_end = h->cur;
         while (seg_end < end && !swap_trigger(h->cfg, seg_end)) ++seg_end;
         const bool handoff = seg_end < end;                  // step seg_end triggers a hand-off
         const int stop = handoff ? seg_end + 1 : end;
-        if (int rc = launch_segment(h, h->cur, stop - h->cur)) return rc;
+        if (int rc = launch_segment(h, h->cur, stop)) return rc;
         h->cur = stop;
         if (handoff) {
             if (sharded) {
@@ -1035,7 +1087,7 @@ int ptnn_run_segment(ptnn_handle* h, int* handoff) {
         if (h->cap < S && stop - h->drained > h->cap - 1)
             return fail(-6, "trace ring of %d rows would overflow: fetch rows from %d on with ptnn_get_traces first", h->cap,
                         h->drained + 1);
-        if (int rc = launch_segment(h, h->cur, stop - h->cur)) return rc;
+        if (int rc = launch_segment(h, h->cur, stop)) return rc;
         h->cur = stop;
         if (ho) { *handoff = 1; return 0; }
     }
@@ -1493,13 +1545,14 @@ int ptnn_describe(ptnn_handle* h, char* buf, int nbytes) {
     const int n = std::snprintf(buf, (size_t)nbytes,
                                 "{\"kernel\": \"ptnn::%s<%d,%d,%d>\", \"schedule\": \"%s\", \"grid_blocks\": %d, \"block_threads\": %d, "
                                 "\"lds_bytes\": %zu, \"groups_per_replica\": %d, \"slots_per_round\": %d, \"num_cus\": %d, "
-                                "\"blocks_per_cu\": %d, \"vgprs\": %d, \"scratch_bytes\": %zu, \"forward_mfma\": %d, \"exchange\": \"%s\", \"lds_resident_state\": %d, \"compact_traces\": %d}",
+                                "\"blocks_per_cu\": %d, \"vgprs\": %d, \"scratch_bytes\": %zu, \"forward_mfma\": %d, \"exchange\": \"%s\", \"lds_resident_state\": %d, \"compact_traces\": %d, \"launches\": \"%s\"}",
                                 kern, h->cfg.task, h->cfg.n_in, h->cfg.n_out,
                                 h->wide ? (h->groups > 1 ? "speculative-wide" : "cooperative-wide") : (h->tree ? "prefetching-tree" : (h->packed ? "packed-speculative" : (h->speculative ? "speculative" : "cooperative"))),
                                 grid, h->nthreads, h->seg_lds, h->groups, slots, h->num_cus, per_cu, fa.numRegs, (size_t)fa.localSizeBytes,
                                 (h->fw_mfma || (h->wide && h->cfg.n_hidden % 32 == 0)) ? 1 : 0,
                                 h->comm.kind == COMM_NONE ? "none" : (h->cfg.label_swap ? "labels" : (resolved_xchg_mode(h) == PTNN_XCHG_GATHER ? "gather" : "boundary")),
-                                h->wide_res ? 1 : 0, h->compact ? 1 : 0);
+                                h->wide_res ? 1 : 0, h->compact ? 1 : 0,
+                                (h->persistent && h->comm.kind == COMM_NONE) ? "one per ptnn_run (swap rounds inside)" : "one per swap interval");
     if (n < 0 || n >= nbytes) return fail(-1, "buffer of %d bytes is too small for the description", nbytes);
     return n;
 }

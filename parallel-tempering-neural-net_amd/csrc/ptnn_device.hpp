@@ -1255,7 +1255,7 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_coop(const float* __restrict_
 #endif
 
 template <int TASK, int I, int O>
-__global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p, const int step_begin, const int n_steps) {
+__device__ __forceinline__ void segment_body(const SegParams& p, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int r = blockIdx.x;
     const int gid = p.first_global + r;
@@ -1503,7 +1503,7 @@ __device__ __forceinline__ bool granule_wait(const granule_t* g, unsigned epoch,
 // Every work-group keeps its own LDS copy of the chain state and applies the same commits, so the copies never
 // diverge; only the per-slot results (and the accepted proposal) cross CUs.
 template <int TASK, int I, int O>
-__global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegParams p, const int step_begin, const int n_steps) {
+__device__ __forceinline__ void segment_spec_body(const SegParams& p, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef PTNN_STAMPS
     const unsigned long long stamp_entry = __builtin_amdgcn_s_memrealtime();
@@ -2228,11 +2228,6 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
 
 // ------------------------------------------------------------------------------------------------
 
-template <int TASK, int I, int O>
-__global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const SegParams p, const int step_begin, const int n_steps) {
-    if (p.pk_nred == 4) segment_pack_body<TASK, I, O, 4>(p, step_begin, n_steps);
-    else segment_pack_body<TASK, I, O, 3>(p, step_begin, n_steps);
-}
 
 // The wide-net section is compared with nothing but itself and the float64 oracle: here the compiler may fuse as it likes
 // (5 % on config 5); the policy of the top of the file returns after model_wide_kernel.
@@ -2966,15 +2961,6 @@ __device__ __forceinline__ void segment_wide_body(const SegParams& p, const int 
     }
 }
 
-template <int TASK, int I, int O>
-__global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegParams p, const int step_begin, const int n_steps) {
-    segment_wide_body<TASK, I, O, false>(p, step_begin, n_steps);
-}
-// state and proposal resident in LDS (host: matrix-core layout and 2 vectors + scratch fit in 160 KB)
-template <int TASK, int I, int O>
-__global__ void __launch_bounds__(MAX_THREADS) segment_wide_res_kernel(const SegParams p, const int step_begin, const int n_steps) {
-    segment_wide_body<TASK, I, O, true>(p, step_begin, n_steps);
-}
 
 // stand-alone model functions for wide nets: mode 0 = evaluate, 1 = langevin_gradient (mode 2, the tape, is shape
 // independent and served by model_kernel)
@@ -3134,71 +3120,13 @@ __device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, floa
     return sSrc[R];
 }
 
-#ifndef PTNN_SHAPE_TU      // non-template kernel: defined in the main translation unit only
-// mode bit 0: apply the local moves; bit 1: count the round and log it
-// exchange row of every local replica: state, cached gradient, its valid flag and the posted scalar, ready for the all-gather
-__global__ void xchg_pack_kernel(const SwapParams sp) {
-    const int b = blockIdx.x;
-    float* row = sp.xchg + (size_t)(sp.first_global + b) * sp.XS;
-    const float* from = sp.cur + (size_t)b * sp.PS;
-    const float* gfrom = sp.gd_cur + (size_t)b * sp.PS;
-    for (int j = threadIdx.x; j < sp.PS; j += blockDim.x) { row[j] = from[j]; row[sp.PS + j] = gfrom[j]; }
-    if (threadIdx.x == 0) {
-        row[2 * sp.PS] = sp.gd_valid_cur[b] ? 1.0f : 0.0f;
-        row[2 * sp.PS + 1] = sp.L[sp.first_global + b];
-        if (sp.rule == 1) {
-            row[2 * sp.PS + 2] = sp.L_raw[sp.first_global + b];
-            row[2 * sp.PS + 3] = sp.prior_post[sp.first_global + b];
-        }
-    }
-}
-
-// Restart of the chains (ptnn_set_state), one block per local replica, everything a run starts from in ONE kernel on the handle's
-// stream: the initial weights into both state buffers (REG:649), the recorded row = ones and row 0 of every trace (Q7: pos_w =
-// ones, REG:240; likeh = -100, REG:292-293; the rest zero), the cached-gradient rows and flags, the per-chain scalars and
-// counters, the temperatures, the error flag, the swap counters and the identity slot <-> temperature maps.  (It was some twenty
-// blocking copies and fills on the null stream, two of them hipMemcpy2D calls with the trace ring's pitch -- 74 MB for Ionosphere,
-// where a restart cost 25 ms: a fifth of a whole 256-replica run, profiles/r03a_gap_probe_before.json.)
-struct ResetParams {
-    int R, Rl, P, PS, PW;
-    size_t cap;
-    const float* w0;          // [Rl][P]  staged initial weights
-    const float* temps_in;    // [Rl]
-    float *state0, *state1, *rec_w, *gd0, *gd1, *st_f, *temps, *pos_w, *scal;
-    int *gd_valid0, *gd_valid1, *st_i, *error, *label0, *label1, *slot0, *slot1;
-    long long* counters;
-};
-__global__ void chain_reset_kernel(const ResetParams q) {
-    const int r = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-    const size_t row = (size_t)r * q.PS;
-    for (int j = tid; j < q.PS; j += nthr) {
-        const float v = (j < q.P) ? q.w0[(size_t)r * q.P + j] : 0.0f;
-        q.state0[row + j] = v; q.state1[row + j] = v;
-        q.rec_w[row + j] = 1.0f;
-        q.gd0[row + j] = 0.0f; q.gd1[row + j] = 0.0f;
-    }
-    float* prow = q.pos_w + (size_t)r * q.cap * q.PW;
-    for (int j = tid; j < q.PW; j += nthr) prow[j] = (j < q.P) ? 1.0f : 0.0f;
-    if (tid == 0) {
-        store_trace_row(q.scal + (size_t)r * q.cap * TR_COUNT, -100.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0, 0.0f);
-        q.gd_valid0[r] = 0; q.gd_valid1[r] = 0;
-        q.temps[r] = q.temps_in[r];
-    }
-    if (tid < SF_COUNT) q.st_f[(size_t)r * SF_COUNT + tid] = 0.0f;
-    if (tid < SI_COUNT) q.st_i[(size_t)r * SI_COUNT + tid] = 0;
-    if (r == 0) {
-        if (tid == 0) { q.counters[0] = 0; q.counters[1] = 0; *q.error = 0; }
-        for (int k = tid; k < q.R; k += nthr) { q.label0[k] = k; q.label1[k] = k; q.slot0[k] = k; q.slot1[k] = k; }
-    }
-}
-
-__global__ void swap_kernel(const SwapParams sp, const int round, const int mode) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// One block's share of a swap round: the cascade (every block recomputes it in LDS), then block b's row.  mode bit 0: apply the
+// local moves; bit 1: count the round and log it (block 0); bit 2: the source rows come from the gathered exchange buffer.
+__device__ __forceinline__ void swap_block(const SwapParams& sp, const int round, const int mode, const int b, float* smem) {
     float* sL = smem;
     float* sU = smem + sp.R;
     int* sSrc = reinterpret_cast<int*>(smem + 2 * sp.R);
     const int nsw = cascade_lds(sp, round, sL, sU, sSrc);
-    const int b = blockIdx.x;
     if (sp.label_mode) {
         // temperature t is handed to the chain that held temperature src[t]: only the maps change
         if (mode & 1) {
@@ -3272,6 +3200,70 @@ __global__ void swap_kernel(const SwapParams sp, const int round, const int mode
     }
 }
 
+
+#ifndef PTNN_SHAPE_TU      // non-template kernels: defined in the main translation unit only
+// mode bit 0: apply the local moves; bit 1: count the round and log it
+// exchange row of every local replica: state, cached gradient, its valid flag and the posted scalar, ready for the all-gather
+__global__ void xchg_pack_kernel(const SwapParams sp) {
+    const int b = blockIdx.x;
+    float* row = sp.xchg + (size_t)(sp.first_global + b) * sp.XS;
+    const float* from = sp.cur + (size_t)b * sp.PS;
+    const float* gfrom = sp.gd_cur + (size_t)b * sp.PS;
+    for (int j = threadIdx.x; j < sp.PS; j += blockDim.x) { row[j] = from[j]; row[sp.PS + j] = gfrom[j]; }
+    if (threadIdx.x == 0) {
+        row[2 * sp.PS] = sp.gd_valid_cur[b] ? 1.0f : 0.0f;
+        row[2 * sp.PS + 1] = sp.L[sp.first_global + b];
+        if (sp.rule == 1) {
+            row[2 * sp.PS + 2] = sp.L_raw[sp.first_global + b];
+            row[2 * sp.PS + 3] = sp.prior_post[sp.first_global + b];
+        }
+    }
+}
+
+// Restart of the chains (ptnn_set_state), one block per local replica, everything a run starts from in ONE kernel on the handle's
+// stream: the initial weights into both state buffers (REG:649), the recorded row = ones and row 0 of every trace (Q7: pos_w =
+// ones, REG:240; likeh = -100, REG:292-293; the rest zero), the cached-gradient rows and flags, the per-chain scalars and
+// counters, the temperatures, the error flag, the swap counters and the identity slot <-> temperature maps.  (It was some twenty
+// blocking copies and fills on the null stream, two of them hipMemcpy2D calls with the trace ring's pitch -- 74 MB for Ionosphere,
+// where a restart cost 25 ms: a fifth of a whole 256-replica run, profiles/r03a_gap_probe_before.json.)
+struct ResetParams {
+    int R, Rl, P, PS, PW;
+    size_t cap;
+    const float* w0;          // [Rl][P]  staged initial weights
+    const float* temps_in;    // [Rl]
+    float *state0, *state1, *rec_w, *gd0, *gd1, *st_f, *temps, *pos_w, *scal;
+    int *gd_valid0, *gd_valid1, *st_i, *error, *label0, *label1, *slot0, *slot1;
+    long long* counters;
+};
+__global__ void chain_reset_kernel(const ResetParams q) {
+    const int r = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const size_t row = (size_t)r * q.PS;
+    for (int j = tid; j < q.PS; j += nthr) {
+        const float v = (j < q.P) ? q.w0[(size_t)r * q.P + j] : 0.0f;
+        q.state0[row + j] = v; q.state1[row + j] = v;
+        q.rec_w[row + j] = 1.0f;
+        q.gd0[row + j] = 0.0f; q.gd1[row + j] = 0.0f;
+    }
+    float* prow = q.pos_w + (size_t)r * q.cap * q.PW;
+    for (int j = tid; j < q.PW; j += nthr) prow[j] = (j < q.P) ? 1.0f : 0.0f;
+    if (tid == 0) {
+        store_trace_row(q.scal + (size_t)r * q.cap * TR_COUNT, -100.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0, 0.0f);
+        q.gd_valid0[r] = 0; q.gd_valid1[r] = 0;
+        q.temps[r] = q.temps_in[r];
+    }
+    if (tid < SF_COUNT) q.st_f[(size_t)r * SF_COUNT + tid] = 0.0f;
+    if (tid < SI_COUNT) q.st_i[(size_t)r * SI_COUNT + tid] = 0;
+    if (r == 0) {
+        if (tid == 0) { q.counters[0] = 0; q.counters[1] = 0; *q.error = 0; }
+        for (int k = tid; k < q.R; k += nthr) { q.label0[k] = k; q.label1[k] = k; q.slot0[k] = k; q.slot1[k] = k; }
+    }
+}
+
+__global__ void swap_kernel(const SwapParams sp, const int round, const int mode) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    swap_block(sp, round, mode, blockIdx.x, smem);
+}
+
 #endif  // PTNN_SHAPE_TU
 
 // ------------------------------------------------------------------------------------------------
@@ -3302,7 +3294,7 @@ __host__ __device__ inline size_t tree_lds_floats(int Nall, int IPY, int PS, int
 }
 
 template <int TASK, int I, int O>
-__global__ void __launch_bounds__(MAX_THREADS) segment_tree_kernel(const SegParams p, const int step_begin, const int n_steps) {
+__device__ __forceinline__ void segment_tree_body(const SegParams& p, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int G = p.G;                                     // 2^D - 1
     const int D = 31 - __clz(G + 1);
@@ -3623,5 +3615,118 @@ __global__ void __launch_bounds__(MAX_THREADS) model_kernel(const SegParams p, c
         o[0] = ll; o[1] = r1; o[2] = r2; o[3] = a_tr; o[4] = a_te; o[5] = pr; o[6] = ll_te; o[7] = 0.f;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// One launch for a whole run (the parent's round loop REG:719-752 inside the kernel).  Every segment
+// kernel runs the MH steps [step_begin, pp.end): swap interval after swap interval, and between two of them -- when pp.swap_inside
+// -- the swap round itself: a grid-wide barrier (every replica has posted its scalar and written its state row back), the cascade
+// + this replica's row move by the work-group that owns the replica (swap_block: the same code swap_kernel runs), a second
+// barrier (the other work-groups of a replica re-stage the moved row), and the next interval.  All R x G work-groups must be
+// resident (the host checks the occupancy of THIS kernel and otherwise launches one interval at a time with pp.swap_inside = 0,
+// pp.end = the end of the interval, followed by swap_kernel: the round-2 shape); the barrier spins are bounded like every other
+// cross-work-group wait and a timeout surfaces through the error flag.  Bit-identical to the per-interval launches by
+// construction: an interval runs the same body from the same global state, the round runs the same swap_block.
+// ------------------------------------------------------------------------------------------------
+struct PersistParams {
+    int end;                 // MH steps are run up to here (exclusive)
+    int swap_inside;         // 1: the swap rounds between the intervals run inside this launch
+    int task, si;            // hand-off rule (Q10): REG after step i when i % si == 0 and i != 0; CLS when (i + 1) % si == 0
+    int round0;              // index of the first swap round of this launch
+    int flip0, lflip0;       // which state / label-map buffers are current at entry
+    int nblocks;             // work-groups of the grid
+    unsigned* barrier;       // zero at launch
+    float* state[2];
+    float* gd[2];
+    int* gd_valid[2];
+    int* label[2];
+    int* slot_of[2];
+    SwapParams sp;           // everything of a round that does not flip
+};
+
+__device__ __forceinline__ bool grid_barrier(unsigned* ctr, unsigned target, int* error_flag) {
+    __syncthreads();
+    int bad = 0;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // this work-group's rows and scalars, visible on every XCD
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > SPIN_LIMIT || __hip_atomic_load(error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bad = 1; break; }
+        }
+    }
+    bad = __syncthreads_or(bad);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");              // nothing cached from before the others arrived
+    return bad == 0;
+}
+
+template <class Body>
+__device__ __forceinline__ void persistent_loop(const SegParams& p0, const PersistParams& pp, const int step_begin, Body body) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    SegParams p = p0;
+    int flip = pp.flip0, lflip = pp.lflip0, round = pp.round0;
+    unsigned arrived = 0;
+    int cur = step_begin;
+    while (cur < pp.end) {
+        // the step that hands off next (Q10), as ptnn_run finds it on the host
+        int seg_end;
+        if (pp.task == TASK_REG) { const int c1 = cur > 1 ? cur : 1; seg_end = ((c1 + pp.si - 1) / pp.si) * pp.si; }
+        else seg_end = ((cur + pp.si) / pp.si) * pp.si - 1;
+        const bool handoff = seg_end < pp.end;
+        const int stop = handoff ? seg_end + 1 : pp.end;
+        p.w_state = pp.state[flip]; p.gd_w = pp.gd[flip]; p.gd_valid = pp.gd_valid[flip];
+        body(p, cur, stop - cur);
+        p.epoch_base += (unsigned)(stop - cur) + 1u;                  // granule tags never repeat across intervals
+        cur = stop;
+        if (!handoff || !pp.swap_inside) break;
+        arrived += (unsigned)pp.nblocks;
+        if (!grid_barrier(pp.barrier, arrived, p.error_flag)) { if (threadIdx.x == 0) atomicAdd(p.error_flag, 1); return; }
+        if ((int)blockIdx.x % p.G == 0) {
+            SwapParams sp = pp.sp;
+            sp.cur = pp.state[flip]; sp.next = pp.state[flip ^ 1];
+            sp.gd_cur = pp.gd[flip]; sp.gd_next = pp.gd[flip ^ 1];
+            sp.gd_valid_cur = pp.gd_valid[flip]; sp.gd_valid_next = pp.gd_valid[flip ^ 1];
+            sp.label_cur = pp.label[lflip]; sp.slot_cur = pp.slot_of[lflip];
+            sp.label_next = pp.label[lflip ^ 1]; sp.slot_next = pp.slot_of[lflip ^ 1];
+            sp.canonical = (p.switch_step >= 0 && cur - 1 >= p.switch_step) ? 1 : 0;
+            swap_block(sp, round, 3, (int)blockIdx.x / p.G, smem);
+        }
+        if (pp.sp.label_mode) lflip ^= 1; else flip ^= 1;
+        round += 1;
+        arrived += (unsigned)pp.nblocks;
+        if (!grid_barrier(pp.barrier, arrived, p.error_flag)) { if (threadIdx.x == 0) atomicAdd(p.error_flag, 1); return; }
+    }
+}
+
+template <int TASK, int I, int O>
+__global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p, const PersistParams pp, const int step_begin) {
+    persistent_loop(p, pp, step_begin, [](const SegParams& q, int b, int n) { segment_body<TASK, I, O>(q, b, n); });
+}
+template <int TASK, int I, int O>
+__global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegParams p, const PersistParams pp, const int step_begin) {
+    persistent_loop(p, pp, step_begin, [](const SegParams& q, int b, int n) { segment_spec_body<TASK, I, O>(q, b, n); });
+}
+template <int TASK, int I, int O>
+__global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const SegParams p, const PersistParams pp, const int step_begin) {
+    persistent_loop(p, pp, step_begin, [](const SegParams& q, int b, int n) {
+        if (q.pk_nred == 4) segment_pack_body<TASK, I, O, 4>(q, b, n);
+        else segment_pack_body<TASK, I, O, 3>(q, b, n);
+    });
+}
+template <int TASK, int I, int O>
+__global__ void __launch_bounds__(MAX_THREADS) segment_tree_kernel(const SegParams p, const PersistParams pp, const int step_begin) {
+    persistent_loop(p, pp, step_begin, [](const SegParams& q, int b, int n) { segment_tree_body<TASK, I, O>(q, b, n); });
+}
+#pragma clang fp contract(fast)     // the wide-net section's policy (see above model_wide_kernel)
+template <int TASK, int I, int O>
+__global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegParams p, const PersistParams pp, const int step_begin) {
+    persistent_loop(p, pp, step_begin, [](const SegParams& q, int b, int n) { segment_wide_body<TASK, I, O, false>(q, b, n); });
+}
+// state and proposal resident in LDS (host: matrix-core layout and 2 vectors + scratch fit in 160 KB)
+template <int TASK, int I, int O>
+__global__ void __launch_bounds__(MAX_THREADS) segment_wide_res_kernel(const SegParams p, const PersistParams pp, const int step_begin) {
+    persistent_loop(p, pp, step_begin, [](const SegParams& q, int b, int n) { segment_wide_body<TASK, I, O, true>(q, b, n); });
+}
+#pragma clang fp contract(off)
 
 }  // namespace ptnn

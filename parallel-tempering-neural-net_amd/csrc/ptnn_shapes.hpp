@@ -13,7 +13,7 @@
 #endif
 
 namespace ptnn {
-typedef void (*seg_fn)(const SegParams, int, int);
+typedef void (*seg_fn)(const SegParams, const PersistParams, int);
 typedef void (*model_fn)(const SegParams, int, const float*, const float*, float*, int, int);
 
 struct Shape {
