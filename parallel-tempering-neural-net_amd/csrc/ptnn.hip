@@ -78,7 +78,8 @@ struct ptnn_handle {
     bool wide_res = false;          // ... with the state and the proposal resident in LDS (matrix-core layout, 2 vectors fit)
     bool compact = false;           // wide nets with all trace rows resident: rejected steps record a row index, no pos_w row
     bool persistent = false;        // all work-groups of the grid are resident: ptnn_run queues ONE launch, swap rounds inside
-    unsigned* d_barrier = nullptr;  // grid barrier counter of the persistent launch
+    unsigned* d_barrier = nullptr;  // grid barrier of the persistent launch: one slot per work-group
+    int barrier_slots = 0;
     bool packed = false;            // H <= 16: packed speculative schedule on one CU
     bool tree = false;              // prefetching tree schedule: groups = 2^depth - 1 work-groups per replica
     bool tree_ahead = false;        // ... with room in LDS for two sets of tapes
@@ -233,7 +234,16 @@ int launch_segment(ptnn_handle* h, int begin, int end, bool swap_inside = false)
         pp.label[b] = h->d_label[b]; pp.slot_of[b] = h->d_slot_of[b];
     }
     fill_swap_params(h, false, pp.sp);
-    if (swap_inside) HIP_TRY(hipMemsetAsync(h->d_barrier, 0, sizeof(unsigned), h->stream));
+    if (swap_inside) {
+        if (grid > h->barrier_slots) {
+            if (h->d_barrier) HIP_TRY(hipFree(h->d_barrier));
+            h->d_barrier = nullptr;
+            HIP_TRY(hipMalloc(&h->d_barrier, (size_t)grid * sizeof(unsigned)));
+            h->barrier_slots = grid;
+            pp.barrier = h->d_barrier;
+        }
+        HIP_TRY(hipMemsetAsync(h->d_barrier, 0, (size_t)grid * sizeof(unsigned), h->stream));
+    }
     // event pairs around a launch cost a pipeline bubble each; time every timing_stride-th launch only
     const bool timed = h->timing_stride > 0 && (h->launch_count++ % h->timing_stride) == 0;
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
@@ -346,10 +356,16 @@ int finish_stream(ptnn_handle* h) {
 }
 
 // One launch per run needs every work-group of the grid resident at once (they meet at grid barriers) and room in LDS for the
-// cascade of a swap round.  Decided per handle once the schedule is known; $PTNN_PERSISTENT=0 keeps one launch per interval.
+// cascade of a swap round.  Decided per handle once the schedule is known.  Taken by default where it is measured to pay: one
+// work-group per replica (packed, cooperative, one-group wide: one barrier per round; Sunspot + 2.6 %, Ionosphere + 0.2 %); with
+// several work-groups per replica a round needs a second rendezvous and the launch boundary it replaces is cheaper (Iris tree
+// - 5 %, Mackey-Glass - 2 %, profiles/r03_persistent_ab.json).  $PTNN_PERSISTENT=0: never; =1: wherever resident.
 int resolve_persistent(ptnn_handle* h) {
     h->persistent = false;
-    if (const char* e = std::getenv("PTNN_PERSISTENT")) if (e[0] == '0') return 0;
+    const char* e = std::getenv("PTNN_PERSISTENT");
+    if (e && e[0] == '0') return 0;
+    const int G = (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
+    if (G > 1 && !(e && e[0] == '1')) return 0;
     const size_t swap_lds = (size_t)(3 * h->cfg.n_replicas_global + 1) * sizeof(float);
     if (swap_lds > h->seg_lds) {
         if (swap_lds > 152 * 1024) return 0;
@@ -418,7 +434,6 @@ int create_buffers(ptnn_handle* h, const ptnn_config* cfg, const Shape* sh, cons
     HIP_TRY(hipMalloc(&h->d_src_log, (size_t)h->max_rounds * R * sizeof(int)));
     HIP_TRY(hipMalloc(&h->d_counters, 2 * sizeof(long long)));
     HIP_TRY(hipMalloc(&h->d_error, sizeof(int)));
-    HIP_TRY(hipMalloc(&h->d_barrier, sizeof(unsigned)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), (Rl * h->P + Rl) * sizeof(float), hipHostMallocDefault));
     HIP_TRY(hipMalloc(&h->d_stage, (Rl * h->P + Rl) * sizeof(float)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_progress), sizeof(int), hipHostMallocDefault));

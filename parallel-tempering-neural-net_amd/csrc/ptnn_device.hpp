@@ -3634,7 +3634,7 @@ struct PersistParams {
     int round0;              // index of the first swap round of this launch
     int flip0, lflip0;       // which state / label-map buffers are current at entry
     int nblocks;             // work-groups of the grid
-    unsigned* barrier;       // zero at launch
+    unsigned* barrier;       // [nblocks] phase every work-group has reached, zero at launch
     float* state[2];
     float* gd[2];
     int* gd_valid[2];
@@ -3643,15 +3643,24 @@ struct PersistParams {
     SwapParams sp;           // everything of a round that does not flip
 };
 
-__device__ __forceinline__ bool grid_barrier(unsigned* ctr, unsigned target, int* error_flag) {
+// Grid barrier without a read-modify-write: every work-group owns one slot and stores the phase it has reached (distinct
+// addresses: nothing serialises -- 256 agent-scope atomic adds on ONE counter cost more than the launch boundary this replaces),
+// wave 0 polls all slots (lane = slot) until every one has reached the phase.  Bounded like every cross-work-group wait.
+__device__ __forceinline__ bool grid_barrier(unsigned* slots, int nblocks, unsigned phase, int* error_flag) {
     __syncthreads();
     int bad = 0;
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // this work-group's rows and scalars, visible on every XCD
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < WAVE) {
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // this work-group's rows and scalars, visible on every XCD
+            __hip_atomic_store(slots + blockIdx.x, phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         unsigned spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
+        for (;;) {
+            bool here = true;
+            for (int j = threadIdx.x; j < nblocks; j += WAVE)
+                here = here && (__hip_atomic_load(slots + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= phase);
+            if (__all(here)) break;
+            __builtin_amdgcn_s_sleep(4);
             if (++spins > SPIN_LIMIT || __hip_atomic_load(error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bad = 1; break; }
         }
     }
@@ -3665,7 +3674,7 @@ __device__ __forceinline__ void persistent_loop(const SegParams& p0, const Persi
     extern __shared__ __attribute__((aligned(16))) float smem[];
     SegParams p = p0;
     int flip = pp.flip0, lflip = pp.lflip0, round = pp.round0;
-    unsigned arrived = 0;
+    unsigned phase = 0;
     int cur = step_begin;
     while (cur < pp.end) {
         // the step that hands off next (Q10), as ptnn_run finds it on the host
@@ -3679,8 +3688,7 @@ __device__ __forceinline__ void persistent_loop(const SegParams& p0, const Persi
         p.epoch_base += (unsigned)(stop - cur) + 1u;                  // granule tags never repeat across intervals
         cur = stop;
         if (!handoff || !pp.swap_inside) break;
-        arrived += (unsigned)pp.nblocks;
-        if (!grid_barrier(pp.barrier, arrived, p.error_flag)) { if (threadIdx.x == 0) atomicAdd(p.error_flag, 1); return; }
+        if (!grid_barrier(pp.barrier, pp.nblocks, ++phase, p.error_flag)) { if (threadIdx.x == 0) atomicAdd(p.error_flag, 1); return; }
         if ((int)blockIdx.x % p.G == 0) {
             SwapParams sp = pp.sp;
             sp.cur = pp.state[flip]; sp.next = pp.state[flip ^ 1];
@@ -3693,8 +3701,10 @@ __device__ __forceinline__ void persistent_loop(const SegParams& p0, const Persi
         }
         if (pp.sp.label_mode) lflip ^= 1; else flip ^= 1;
         round += 1;
-        arrived += (unsigned)pp.nblocks;
-        if (!grid_barrier(pp.barrier, arrived, p.error_flag)) { if (threadIdx.x == 0) atomicAdd(p.error_flag, 1); return; }
+        // the other work-groups of a replica re-stage the row its owner has just moved; a replica of one work-group reads its own
+        // writes (same CU, write-through L1) and needs no second rendezvous
+        if (p.G > 1 && !grid_barrier(pp.barrier, pp.nblocks, ++phase, p.error_flag)) { if (threadIdx.x == 0) atomicAdd(p.error_flag, 1); return; }
+        if (p.G == 1) __syncthreads();
     }
 }
 

@@ -28,7 +28,7 @@ FUNC_CASES = {"reg_sunspot_4_5_1": "sunspot", "reg_mackey_4_10_1": "mackey", "cl
 def test_library_is_the_hip_build():
     import ptnn_amd
     lib = ptnn_amd.load_library()
-    assert lib.ptnn_abi_version() == 2
+    assert lib.ptnn_abi_version() == 3
     assert lib.ptnn_supports(0, 4, 5, 1) == 1 and lib.ptnn_supports(1, 34, 50, 2) == 1
     assert lib.ptnn_supports(0, 4, 65, 1) == 1 and lib.ptnn_supports(0, 32, 512, 1) == 1
     assert lib.ptnn_supports(0, 4, 513, 1) == 0 and lib.ptnn_supports(0, 7, 5, 1) == 0
@@ -700,13 +700,18 @@ def test_shared_noise_option_matches_oracle(schedule):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["reg_packed", "reg_spec", "cls_coop"])
+@pytest.mark.parametrize("case", ["reg_packed", "reg_spec", "cls_coop", "wide_compact"])
 def test_checkpoint_resume_continues_bit_for_bit(case):
     """chains saved mid-run (between swap intervals and in the middle of one) and restored into a fresh handle
-    produce the same trace rows, swap log and counters as the uninterrupted run."""
+    produce the same trace rows, swap log and counters as the uninterrupted run.  wide_compact: a 32-96-1 net on the LDS-resident
+    wide kernel with compact traces -- a rejected step after the restore repeats a pos_w row from before the checkpoint, which the
+    restored handle must still be able to hand out."""
     d = ds()
     from ptnn_amd import ladder, philox
-    if case.startswith("reg"):
+    if case == "wide_compact":
+        task, topo, lg, lr, mt, sched = orc.TASK_REG, (32, 96, 1), True, 0.1, 2, 0
+        train, test = d["synth32_train"], d["synth32_test"]
+    elif case.startswith("reg"):
         task, topo, train, test, lg, lr, mt = orc.TASK_REG, (4, 5, 1), d["sunspot_train"], d["sunspot_test"], True, 0.1, 2
         sched = 0 if case == "reg_packed" else 2
     else:
@@ -717,6 +722,11 @@ def test_checkpoint_resume_continues_bit_for_bit(case):
     def make():
         return parity.make_sampler(task, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=lg, lr=lr, seed=seed,
                                    schedule=sched)
+    if case == "wide_compact":
+        probe = make()
+        info = probe.describe()
+        probe.close()
+        assert info["lds_resident_state"] == 1 and info["compact_traces"] == 1, info
     full = make()
     full.set_state(np.stack([philox.initial_weights(seed, r, Pw) for r in range(R)]), ladder.temperatures(R, mt))
     full.run(-1)
@@ -744,6 +754,62 @@ def test_checkpoint_resume_continues_bit_for_bit(case):
             assert np.array_equal(got, want[k]), (case, stop, k)
         assert np.array_equal(b.swap_log(), want_log) and b.swap_stats() == want_stats
         b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["sunspot_packed", "mackey_spec4", "iris_tree", "ions_coop", "wide_res_g2", "sunspot_labels", "sunspot_evenodd"])
+def test_one_launch_per_run_equals_one_launch_per_interval(case, monkeypatch):
+    """The persistent launch (every segment kernel loops over the swap intervals, grid barriers and the swap round inside:
+    persistent_loop) against the round-2 shape (one launch per interval + swap_kernel, $PTNN_PERSISTENT=0): traces, swap log,
+    counters and final state bit for bit, for every schedule, both swap rules and label swapping, in one piece and in chunks that
+    end inside an interval."""
+    d = ds()
+    from ptnn_amd import ladder, philox
+    kw = {}
+    if case.startswith("sunspot"):
+        task, topo, name, lg, lr, mt, R, S, si = 0, (4, 5, 1), "sunspot", True, 0.1, 2, 16, 163, 20
+        if case == "sunspot_labels":
+            kw = dict(label_swap=1)
+        if case == "sunspot_evenodd":
+            kw = dict(swap_rule=1)
+    elif case == "mackey_spec4":
+        task, topo, name, lg, lr, mt, R, S, si, kw = 0, (4, 10, 1), "mackey", True, 0.1, 2, 8, 123, 20, dict(schedule=2, groups=4)
+    elif case == "iris_tree":
+        task, topo, name, lg, lr, mt, R, S, si, kw = 1, (4, 12, 3), "iris", False, 0.01, 10, 16, 203, 25, dict(schedule=4)
+    elif case == "ions_coop":
+        task, topo, name, lg, lr, mt, R, S, si, kw = 1, (34, 50, 2), "ions", False, 0.01, 10, 12, 83, 20, dict(schedule=1)
+    else:
+        task, topo, name, lg, lr, mt, R, S, si, kw = 0, (32, 96, 1), "synth32", True, 0.1, 2, 6, 53, 10, dict(groups=2)
+    train, test = d[name + "_train"], d[name + "_test"]
+    Pw = topo[0] * topo[1] + topo[1] * topo[2] + topo[1] + topo[2]
+    scale = 0.3 if topo[1] > 64 else 1.0
+    w0 = scale * np.stack([philox.initial_weights(7, r, Pw) for r in range(R)])
+    T = ladder.temperatures(R, mt)
+    out = {}
+    for mode in ("0", "1", "chunks"):
+        monkeypatch.setenv("PTNN_PERSISTENT", "0" if mode == "0" else "1")
+        s = parity.make_sampler(task, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=lg, lr=lr, seed=7, **kw)
+        launches = s.describe()["launches"]
+        assert launches.startswith("one per swap interval" if mode == "0" else "one per ptnn_run"), launches
+        s.set_state(w0, T)
+        if kw.get("swap_rule") or kw.get("label_swap"):
+            s.set_ladder(T)
+        if mode == "chunks":
+            s.run(si + 7)
+            s.run(2 * si)
+        s.run(-1)
+        s.sync()
+        st = s.state()
+        out[mode] = (s.traces(), s.swap_log(), s.swap_stats(), st, s.kernel_time()[0])
+        s.close()
+    assert out["0"][2][0] > 0                                # swaps happened
+    assert out["1"][4] == 1 and out["chunks"][4] == 3 and out["0"][4] > 3      # launches timed: one per run / per chunk / per interval
+    for mode in ("1", "chunks"):
+        for k in out["0"][0]:
+            assert np.array_equal(out[mode][0][k], out["0"][0][k]), (case, mode, k)
+        assert np.array_equal(out[mode][1], out["0"][1]) and out[mode][2] == out["0"][2], (case, mode)
+        for k in out["0"][3]:
+            assert np.array_equal(out[mode][3][k], out["0"][3][k]), (case, mode, k)
 
 
 @pytest.mark.gpu
