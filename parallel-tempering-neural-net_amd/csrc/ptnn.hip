@@ -366,6 +366,10 @@ int resolve_persistent(ptnn_handle* h) {
     if (e && e[0] == '0') return 0;
     const int G = (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
     if (G > 1 && !(e && e[0] == '1')) return 0;
+    // kernels compiled without the interval loop (ptnn_device.hpp: persistent_loop<false>)
+    if ((h->speculative && !h->packed) || h->tree) return 0;
+    if (h->packed && !(h->shape->loops & 2)) return 0;
+    if (!h->wide && !h->packed && !h->speculative && !(h->shape->loops & 1)) return 0;
     const size_t swap_lds = (size_t)(3 * h->cfg.n_replicas_global + 1) * sizeof(float);
     if (swap_lds > h->seg_lds) {
         if (swap_lds > 152 * 1024) return 0;

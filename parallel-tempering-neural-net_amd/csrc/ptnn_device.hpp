@@ -96,6 +96,16 @@ struct SegParams {
                              // row it repeats (TR_SRC); ptnn_get_traces fills the rows in.  A 70 KB copy per rejected step otherwise.
 };
 
+// What changes from one swap interval to the next inside one launch (persistent_loop): which of the two state buffers is
+// current, and where the granule tags continue.  Kept apart from SegParams so that the kernel argument itself stays constant (a
+// modified copy of it, live across the whole interval, cost ~60 scalar registers and pushed two kernels into scratch).
+struct SegDyn {
+    float* w_state;          // current (w, eta) rows [Rl][PS]
+    float* gd_w;             // cached langevin_gradient(w) [Rl][PS]
+    int* gd_valid;           // [Rl]
+    unsigned epoch_base;     // granule tags of this interval are epoch_base + round
+};
+
 // ------------------------------------------------------------------------------------------------
 // scalar math on the hardware transcendental units
 // ------------------------------------------------------------------------------------------------
@@ -1255,7 +1265,7 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_coop(const float* __restrict_
 #endif
 
 template <int TASK, int I, int O>
-__device__ __forceinline__ void segment_body(const SegParams& p, const int step_begin, const int n_steps) {
+__device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& dyn, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int r = blockIdx.x;
     const int gid = p.first_global + r;
@@ -1270,11 +1280,11 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const int step_
         float4* dst = reinterpret_cast<float4*>(l.xy);
         for (int e = tid; e < ((Nall + 2) * p.IPY) >> 2; e += nthr) dst[e] = src[e];
     }
-    float* gw = p.w_state + (size_t)r * PS;
+    float* gw = dyn.w_state + (size_t)r * PS;
     for (int j = tid; j < PS; j += nthr) {
         l.w_cur[j] = gw[j];
         l.rec_w[j] = p.rec_w[(size_t)r * PS + j];
-        if (p.use_lg) l.w_gd[j] = p.gd_w[(size_t)r * PS + j];
+        if (p.use_lg) l.w_gd[j] = dyn.gd_w[(size_t)r * PS + j];
     }
     // MFMA forward pass (host decides): transposed data image and per-tile partial sums behind the common LDS block
     float* xt_l = smem + lds_floats(Nall, p.IPY, p.PS, p.H, p.FWS, p.use_lg != 0);
@@ -1300,7 +1310,7 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const int step_
         lik = sf[SF_LIK]; prior_cur = sf[SF_PRIOR]; tau_eta_last = sf[SF_TAU_LAST];
         rec_rmse_tr = sf[SF_REC_RMSE_TR]; rec_rmse_te = sf[SF_REC_RMSE_TE];
         rec_acc_tr = sf[SF_REC_ACC_TR]; rec_acc_te = sf[SF_REC_ACC_TE];
-        nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT];
+        nacc = si[SI_NACC]; gd_valid = dyn.gd_valid[r]; lg_count = si[SI_LG_COUNT];
     }
 
 #ifdef PTNN_STAMPS
@@ -1450,13 +1460,13 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const int step_
     for (int j = tid; j < PS; j += nthr) {
         gw[j] = (j == P) ? eta : wbuf[o_cur + j];
         p.rec_w[(size_t)r * PS + j] = wbuf[o_rec + j];
-        if (p.use_lg) p.gd_w[(size_t)r * PS + j] = wbuf[o_gd + j];
+        if (p.use_lg) dyn.gd_w[(size_t)r * PS + j] = wbuf[o_gd + j];
     }
     if (tid == 0) {
         sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur; sf[SF_TAU_LAST] = tau_eta_last;
         sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;
         sf[SF_REC_ACC_TR] = rec_acc_tr; sf[SF_REC_ACC_TE] = rec_acc_te;
-        si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count;
+        si[SI_NACC] = nacc; dyn.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count;
         p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;      // Q11
         p.L_final[gid] = lik;
         post_raw(p, gid, lik, prior_cur, T, step_begin + n_steps - 1);
@@ -1503,7 +1513,7 @@ __device__ __forceinline__ bool granule_wait(const granule_t* g, unsigned epoch,
 // Every work-group keeps its own LDS copy of the chain state and applies the same commits, so the copies never
 // diverge; only the per-slot results (and the accepted proposal) cross CUs.
 template <int TASK, int I, int O>
-__device__ __forceinline__ void segment_spec_body(const SegParams& p, const int step_begin, const int n_steps) {
+__device__ __forceinline__ void segment_spec_body(const SegParams& p, const SegDyn& dyn, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef PTNN_STAMPS
     const unsigned long long stamp_entry = __builtin_amdgcn_s_memrealtime();
@@ -1548,11 +1558,11 @@ __device__ __forceinline__ void segment_spec_body(const SegParams& p, const int 
         float4* dst = reinterpret_cast<float4*>(xy);
         for (int e = tid; e < ((Nall + 2) * p.IPY) >> 2; e += nthr) dst[e] = src[e];
     }
-    float* gw = p.w_state + (size_t)r * PS;
+    float* gw = dyn.w_state + (size_t)r * PS;
     for (int j = tid; j < PS; j += nthr) {
         w_cur[j] = gw[j];
         rec_w[j] = p.rec_w[(size_t)r * PS + j];
-        w_gd[j] = p.gd_w[(size_t)r * PS + j];
+        w_gd[j] = dyn.gd_w[(size_t)r * PS + j];
     }
     if (tid < 3 * MAX_WAVES) pready[tid] = 0u;                 // tag 0 is never a round's tag
     __syncthreads();
@@ -1579,7 +1589,7 @@ __device__ __forceinline__ void segment_spec_body(const SegParams& p, const int 
         lik = uni_f(sf[SF_LIK]); prior_cur = uni_f(sf[SF_PRIOR]); tau_eta_last = uni_f(sf[SF_TAU_LAST]);
         rec_rmse_tr = uni_f(sf[SF_REC_RMSE_TR]); rec_rmse_te = uni_f(sf[SF_REC_RMSE_TE]);
         rec_acc_tr = uni_f(sf[SF_REC_ACC_TR]); rec_acc_te = uni_f(sf[SF_REC_ACC_TE]);
-        nacc = uni_i(si[SI_NACC]); gd_valid = uni_i(p.gd_valid[r]); lg_count = uni_i(si[SI_LG_COUNT]); lg_acc = uni_i(si[SI_LG_ACC]);
+        nacc = uni_i(si[SI_NACC]); gd_valid = uni_i(dyn.gd_valid[r]); lg_count = uni_i(si[SI_LG_COUNT]); lg_acc = uni_i(si[SI_LG_ACC]);
     }
 
 #ifdef PTNN_STAMPS
@@ -1595,7 +1605,7 @@ __device__ __forceinline__ void segment_spec_body(const SegParams& p, const int 
     const size_t trow = (size_t)r * p.trace_cap;        // traces are rings of trace_cap rows per replica (== S unless streaming)
     const int end = step_begin + n_steps;
     int i = step_begin;
-    unsigned epoch = p.epoch_base;
+    unsigned epoch = dyn.epoch_base;
     int par = 0;
     bool failed = false;
     STAMP(0);                                             // launch prologue: staging, start-up
@@ -1873,13 +1883,13 @@ __device__ __forceinline__ void segment_spec_body(const SegParams& p, const int 
         for (int j = tid; j < PS; j += nthr) {
             gw[j] = (j == P) ? eta : w_cur[j];
             p.rec_w[(size_t)r * PS + j] = rec_w[j];
-            p.gd_w[(size_t)r * PS + j] = w_gd[j];
+            dyn.gd_w[(size_t)r * PS + j] = w_gd[j];
         }
         if (tid == 0) {
             sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur; sf[SF_TAU_LAST] = tau_eta_last;
             sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;
             sf[SF_REC_ACC_TR] = rec_acc_tr; sf[SF_REC_ACC_TE] = rec_acc_te;
-            si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count; si[SI_LG_ACC] = lg_acc;
+            si[SI_NACC] = nacc; dyn.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count; si[SI_LG_ACC] = lg_acc;
             p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;
             p.L_final[gid] = lik;
             post_raw(p, gid, lik, prior_cur, T, step_begin + n_steps - 1);
@@ -1912,7 +1922,7 @@ __host__ __device__ inline size_t pack_lds_floats(int Nall, int IPY, int PS, int
 }
 
 template <int TASK, int I, int O, int PK_NRED>
-__device__ __forceinline__ void segment_pack_body(const SegParams& p, const int step_begin, const int n_steps) {
+__device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegDyn& dyn, const int step_begin, const int n_steps) {
     constexpr int PK_NG = WAVE >> PK_NRED, PK_SLOTS = pack_slots(PK_NRED);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int r = blockIdx.x;
@@ -1947,11 +1957,11 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
         float4* dst = reinterpret_cast<float4*>(xy);
         for (int e = tid; e < ((Nall + 2) * p.IPY) >> 2; e += nthr) dst[e] = src[e];
     }
-    float* gw = p.w_state + (size_t)r * PS;
+    float* gw = dyn.w_state + (size_t)r * PS;
     for (int j = tid; j < PS; j += nthr) {
         w_cur[j] = gw[j];
         rec_w[j] = p.rec_w[(size_t)r * PS + j];
-        w_gd[j] = p.gd_w[(size_t)r * PS + j];
+        w_gd[j] = dyn.gd_w[(size_t)r * PS + j];
     }
     __syncthreads();
 
@@ -1977,7 +1987,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
         lik = uni_f(sf[SF_LIK]); prior_cur = uni_f(sf[SF_PRIOR]); tau_eta_last = uni_f(sf[SF_TAU_LAST]);
         rec_rmse_tr = uni_f(sf[SF_REC_RMSE_TR]); rec_rmse_te = uni_f(sf[SF_REC_RMSE_TE]);
         rec_acc_tr = uni_f(sf[SF_REC_ACC_TR]); rec_acc_te = uni_f(sf[SF_REC_ACC_TE]);
-        nacc = uni_i(si[SI_NACC]); gd_valid = uni_i(p.gd_valid[r]); lg_count = uni_i(si[SI_LG_COUNT]); lg_acc = uni_i(si[SI_LG_ACC]);
+        nacc = uni_i(si[SI_NACC]); gd_valid = uni_i(dyn.gd_valid[r]); lg_count = uni_i(si[SI_LG_COUNT]); lg_acc = uni_i(si[SI_LG_ACC]);
     }
 
 #ifdef PTNN_STAMPS
@@ -2213,13 +2223,13 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const int 
     for (int j = tid; j < PS; j += nthr) {
         gw[j] = (j == P) ? eta : w_cur[j];
         p.rec_w[(size_t)r * PS + j] = rec_w[j];
-        p.gd_w[(size_t)r * PS + j] = w_gd[j];
+        dyn.gd_w[(size_t)r * PS + j] = w_gd[j];
     }
     if (tid == 0) {
         sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur; sf[SF_TAU_LAST] = tau_eta_last;
         sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;
         sf[SF_REC_ACC_TR] = rec_acc_tr; sf[SF_REC_ACC_TE] = rec_acc_te;
-        si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count; si[SI_LG_ACC] = lg_acc;
+        si[SI_NACC] = nacc; dyn.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count; si[SI_LG_ACC] = lg_acc;
         p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;
         p.L_final[gid] = lik;
         post_raw(p, gid, lik, prior_cur, T, step_begin + n_steps - 1);
@@ -2606,7 +2616,7 @@ __device__ __forceinline__ EvalSums wide_forward(const SegParams& p, const float
 // image, a Langevin one reads the cached epoch (70 KB) and writes its own (70 KB).  It was 280 - 560 KB per step and group.
 constexpr int WIDE_WINDOW = 8;
 template <int TASK, int I, int O, bool RES>
-__device__ __forceinline__ void segment_wide_body(const SegParams& p, const int step_begin, const int n_steps) {
+__device__ __forceinline__ void segment_wide_body(const SegParams& p, const SegDyn& dyn, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int OP = (O + 3) & ~3;
     const int G = p.G;
@@ -2629,16 +2639,16 @@ __device__ __forceinline__ void segment_wide_body(const SegParams& p, const int 
     float* const mine = p.wide_scratch + (size_t)(r * G + grp) * 5 * PS;
     float* w_prop = RES ? fw : mine;                            // RES: the flat LDS image is the proposal
     float* w_pgd = mine + PS;
-    float* w_cur = RES ? wc : ((grp == 0) ? p.w_state + (size_t)r * PS : mine + 2 * (size_t)PS);   // chain state row (group 0: the canonical one)
-    float* w_gd = (grp == 0) ? p.gd_w + (size_t)r * PS : mine + 3 * (size_t)PS;
+    float* w_cur = RES ? wc : ((grp == 0) ? dyn.w_state + (size_t)r * PS : mine + 2 * (size_t)PS);   // chain state row (group 0: the canonical one)
+    float* w_gd = (grp == 0) ? dyn.gd_w + (size_t)r * PS : mine + 3 * (size_t)PS;
     float* rec_w = (grp == 0) ? p.rec_w + (size_t)r * PS : mine + 4 * (size_t)PS;
     const bool compact = p.compact != 0;
     if (grp > 0 || RES) {
         // (group 0 touches the canonical rows at its first commit, which needs this group's first verdicts)
         for (int q = tid; q < PS / 4; q += nthr) {
-            if (grp > 0 || RES) reinterpret_cast<float4*>(w_cur)[q] = reinterpret_cast<const float4*>(p.w_state + (size_t)r * PS)[q];
+            if (grp > 0 || RES) reinterpret_cast<float4*>(w_cur)[q] = reinterpret_cast<const float4*>(dyn.w_state + (size_t)r * PS)[q];
             if (grp > 0) {
-                reinterpret_cast<float4*>(w_gd)[q] = reinterpret_cast<const float4*>(p.gd_w + (size_t)r * PS)[q];
+                reinterpret_cast<float4*>(w_gd)[q] = reinterpret_cast<const float4*>(dyn.gd_w + (size_t)r * PS)[q];
                 reinterpret_cast<float4*>(rec_w)[q] = reinterpret_cast<const float4*>(p.rec_w + (size_t)r * PS)[q];
             }
         }
@@ -2664,14 +2674,14 @@ __device__ __forceinline__ void segment_wide_body(const SegParams& p, const int 
         lik = sf[SF_LIK]; prior_cur = sf[SF_PRIOR]; tau_eta_last = sf[SF_TAU_LAST];
         rec_rmse_tr = sf[SF_REC_RMSE_TR]; rec_rmse_te = sf[SF_REC_RMSE_TE];
         rec_acc_tr = sf[SF_REC_ACC_TR]; rec_acc_te = sf[SF_REC_ACC_TE];
-        nacc = si[SI_NACC]; gd_valid = p.gd_valid[r]; lg_count = si[SI_LG_COUNT]; rec_row = si[SI_REC_ROW];
+        nacc = si[SI_NACC]; gd_valid = dyn.gd_valid[r]; lg_count = si[SI_LG_COUNT]; rec_row = si[SI_REC_ROW];
     }
 
     const size_t trow = (size_t)r * p.trace_cap;        // traces are rings of trace_cap rows per replica (== S unless streaming)
     const int end = step_begin + n_steps;
     const int nv = (P + 3) >> 2;
     const int W = (G > 1) ? min(max(p.wide_window, G), WIDE_WINDOW) : 1;
-    unsigned epoch = p.epoch_base;
+    unsigned epoch = dyn.epoch_base;
     int par = 0;
     bool failed = false;
     int i = step_begin;
@@ -2944,7 +2954,7 @@ __device__ __forceinline__ void segment_wide_body(const SegParams& p, const int 
     }
     if (RES && grp == 0) {                                      // the state back to its canonical row: swap rounds and the next launch read it
         __syncthreads();
-        float* row = p.w_state + (size_t)r * PS;
+        float* row = dyn.w_state + (size_t)r * PS;
         for (int q = tid; q < PS / 4; q += nthr) reinterpret_cast<float4*>(row)[q] = reinterpret_cast<const float4*>(w_cur)[q];
         __syncthreads();
         w_cur = row;
@@ -2954,7 +2964,7 @@ __device__ __forceinline__ void segment_wide_body(const SegParams& p, const int 
         sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur; sf[SF_TAU_LAST] = tau_eta_last;
         sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;
         sf[SF_REC_ACC_TR] = rec_acc_tr; sf[SF_REC_ACC_TE] = rec_acc_te;
-        si[SI_NACC] = nacc; p.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count; si[SI_REC_ROW] = rec_row;
+        si[SI_NACC] = nacc; dyn.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count; si[SI_REC_ROW] = rec_row;
         p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;
         p.L_final[gid] = lik;
         post_raw(p, gid, lik, prior_cur, T, step_begin + n_steps - 1);
@@ -3294,7 +3304,7 @@ __host__ __device__ inline size_t tree_lds_floats(int Nall, int IPY, int PS, int
 }
 
 template <int TASK, int I, int O>
-__device__ __forceinline__ void segment_tree_body(const SegParams& p, const int step_begin, const int n_steps) {
+__device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegDyn& dyn, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int G = p.G;                                     // 2^D - 1
     const int D = 31 - __clz(G + 1);
@@ -3328,7 +3338,7 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const int 
         float4* dst = reinterpret_cast<float4*>(xy);
         for (int e = tid; e < ((Nall + 2) * p.IPY) >> 2; e += nthr) dst[e] = src[e];
     }
-    float* gw = p.w_state + (size_t)r * PS;
+    float* gw = dyn.w_state + (size_t)r * PS;
     for (int j = tid; j < PS; j += nthr) {
         w_cur[j] = gw[j];
         rec_w[j] = p.rec_w[(size_t)r * PS + j];
@@ -3363,7 +3373,7 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const int 
     const size_t trow = (size_t)r * p.trace_cap;
     const int step_end = step_begin + n_steps;
     const int nq1 = ((P + 3) >> 2) + 1;
-    unsigned epoch = p.epoch_base;
+    unsigned epoch = dyn.epoch_base;
     int par = 0;
     bool failed = false;
     int i = step_begin;
@@ -3547,7 +3557,7 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const int 
             sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;
             sf[SF_REC_ACC_TR] = rec_acc_tr; sf[SF_REC_ACC_TE] = rec_acc_te;
             si[SI_NACC] = nacc;
-            if (step_begin == 0) { sf[SF_TAU_LAST] = eta; si[SI_LG_COUNT] = 0; p.gd_valid[r] = 0; }   // what the other schedules leave
+            if (step_begin == 0) { sf[SF_TAU_LAST] = eta; si[SI_LG_COUNT] = 0; dyn.gd_valid[r] = 0; }   // what the other schedules leave
             p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;      // Q11
             p.L_final[gid] = lik;
             post_raw(p, gid, lik, prior_cur, T, step_begin + n_steps - 1);
@@ -3669,73 +3679,135 @@ __device__ __forceinline__ bool grid_barrier(unsigned* slots, int nblocks, unsig
     return bad == 0;
 }
 
-template <class Body>
-__device__ __forceinline__ void persistent_loop(const SegParams& p0, const PersistParams& pp, const int step_begin, Body body) {
+// The PersistParams of the launch, read from the kernel-argument segment where it lies (second argument, behind SegParams) through
+// a pointer the optimiser cannot see through: every use re-loads the few words it needs (scalar loads from the constant cache)
+// instead of keeping ~60 words of it live across the interval body -- hoisted out of the loop they were spilled into vector
+// registers and, in the two kernels closest to the register ceiling, on into scratch.
+typedef __attribute__((address_space(4))) const PersistParams* persist_cptr;
+__device__ __forceinline__ persist_cptr persist_args() {
+    constexpr size_t off = (sizeof(SegParams) + alignof(PersistParams) - 1) & ~(alignof(PersistParams) - 1);
+    unsigned long long a = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + off;
+    asm volatile("" : "+s"(a));
+    return (persist_cptr)(uintptr_t)a;
+}
+
+// LOOP = false: one interval per launch and nothing else (the two schedules with several work-groups per replica and the most
+// registers -- multi-CU speculative, prefetching tree -- where the loop around the body cost 30 - 40 vector registers, i.e. scratch,
+// and where a persistent launch is measured to lose against the launch boundary anyway).
+typedef __attribute__((address_space(4))) const SegParams* seg_cptr;
+__device__ __forceinline__ seg_cptr seg_args() {
+    unsigned long long a = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(a));
+    return (seg_cptr)(uintptr_t)a;
+}
+
+template <bool LOOP, class Body>
+__device__ __forceinline__ void persistent_loop(const SegParams& p0, const int step_begin, Body body) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    SegParams p = p0;
-    int flip = pp.flip0, lflip = pp.lflip0, round = pp.round0;
-    unsigned phase = 0;
-    int cur = step_begin;
-    while (cur < pp.end) {
+    if constexpr (!LOOP) {
+        const SegParams& p = p0;
+        persist_cptr pp = persist_args();
+        SegDyn dyn;
+        const int flip = pp->flip0;
+        dyn.w_state = pp->state[flip]; dyn.gd_w = pp->gd[flip]; dyn.gd_valid = pp->gd_valid[flip];
+        dyn.epoch_base = p.epoch_base;
+        body(p, dyn, step_begin, pp->end - step_begin);
+        return;
+    }
+    // the interval body sees the kernel arguments through an opaque pointer, re-read every interval: nothing the body derives
+    // from them (LDS carving, per-thread addresses) is hoisted out of the loop and kept alive across it -- left to itself the
+    // optimiser did exactly that, at 30 - 45 vector registers per kernel
+    int flip, lflip, round, cur = step_begin;
+    unsigned phase = 0, epoch_add = 0;
+    {
+        persist_cptr pp = persist_args();
+        flip = pp->flip0; lflip = pp->lflip0; round = pp->round0;
+    }
+    for (;;) {
+        persist_cptr pp = persist_args();
+        const int end = pp->end, si = pp->si;
+        if (cur >= end) break;
         // the step that hands off next (Q10), as ptnn_run finds it on the host
         int seg_end;
-        if (pp.task == TASK_REG) { const int c1 = cur > 1 ? cur : 1; seg_end = ((c1 + pp.si - 1) / pp.si) * pp.si; }
-        else seg_end = ((cur + pp.si) / pp.si) * pp.si - 1;
-        const bool handoff = seg_end < pp.end;
-        const int stop = handoff ? seg_end + 1 : pp.end;
-        p.w_state = pp.state[flip]; p.gd_w = pp.gd[flip]; p.gd_valid = pp.gd_valid[flip];
-        body(p, cur, stop - cur);
-        p.epoch_base += (unsigned)(stop - cur) + 1u;                  // granule tags never repeat across intervals
+        if (pp->task == TASK_REG) { const int c1 = cur > 1 ? cur : 1; seg_end = ((c1 + si - 1) / si) * si; }
+        else seg_end = ((cur + si) / si) * si - 1;
+        const bool handoff = seg_end < end;
+        const int stop = handoff ? seg_end + 1 : end;
+        const bool swap_inside = pp->swap_inside != 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const SegParams p = *seg_args();
+#else
+        const SegParams p = p0;                                       // host pass of the compiler: never executed
+#endif
+        {
+            SegDyn dyn;
+            dyn.w_state = pp->state[flip]; dyn.gd_w = pp->gd[flip]; dyn.gd_valid = pp->gd_valid[flip];
+            dyn.epoch_base = p.epoch_base + epoch_add;
+            body(p, dyn, cur, stop - cur);
+        }
+        epoch_add += (unsigned)(stop - cur) + 1u;                     // granule tags never repeat across intervals
         cur = stop;
-        if (!handoff || !pp.swap_inside) break;
-        if (!grid_barrier(pp.barrier, pp.nblocks, ++phase, p.error_flag)) { if (threadIdx.x == 0) atomicAdd(p.error_flag, 1); return; }
+        if (!handoff || !swap_inside) break;
+        pp = persist_args();
+        if (!grid_barrier(pp->barrier, pp->nblocks, ++phase, p.error_flag)) { if (threadIdx.x == 0) atomicAdd(p.error_flag, 1); return; }
         if ((int)blockIdx.x % p.G == 0) {
-            SwapParams sp = pp.sp;
-            sp.cur = pp.state[flip]; sp.next = pp.state[flip ^ 1];
-            sp.gd_cur = pp.gd[flip]; sp.gd_next = pp.gd[flip ^ 1];
-            sp.gd_valid_cur = pp.gd_valid[flip]; sp.gd_valid_next = pp.gd_valid[flip ^ 1];
-            sp.label_cur = pp.label[lflip]; sp.slot_cur = pp.slot_of[lflip];
-            sp.label_next = pp.label[lflip ^ 1]; sp.slot_next = pp.slot_of[lflip ^ 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+            SwapParams sp = pp->sp;
+#else
+            SwapParams sp{};
+#endif
+            sp.cur = pp->state[flip]; sp.next = pp->state[flip ^ 1];
+            sp.gd_cur = pp->gd[flip]; sp.gd_next = pp->gd[flip ^ 1];
+            sp.gd_valid_cur = pp->gd_valid[flip]; sp.gd_valid_next = pp->gd_valid[flip ^ 1];
+            sp.label_cur = pp->label[lflip]; sp.slot_cur = pp->slot_of[lflip];
+            sp.label_next = pp->label[lflip ^ 1]; sp.slot_next = pp->slot_of[lflip ^ 1];
             sp.canonical = (p.switch_step >= 0 && cur - 1 >= p.switch_step) ? 1 : 0;
             swap_block(sp, round, 3, (int)blockIdx.x / p.G, smem);
         }
-        if (pp.sp.label_mode) lflip ^= 1; else flip ^= 1;
+        if (pp->sp.label_mode) lflip ^= 1; else flip ^= 1;
         round += 1;
         // the other work-groups of a replica re-stage the row its owner has just moved; a replica of one work-group reads its own
         // writes (same CU, write-through L1) and needs no second rendezvous
-        if (p.G > 1 && !grid_barrier(pp.barrier, pp.nblocks, ++phase, p.error_flag)) { if (threadIdx.x == 0) atomicAdd(p.error_flag, 1); return; }
+        if (p.G > 1 && !grid_barrier(pp->barrier, pp->nblocks, ++phase, p.error_flag)) { if (threadIdx.x == 0) atomicAdd(p.error_flag, 1); return; }
         if (p.G == 1) __syncthreads();
     }
 }
 
+// Which kernels carry the interval loop.  The loop costs 10 - 40 vector registers (values the optimiser keeps alive around the
+// body); it is compiled in where the kernel stays free of scratch with it -- every shape of the BASELINE configurations that
+// takes one work-group per replica -- and left out where it would add spills (many-class heads, wide-input packed nets); those
+// run one launch per interval as before (Shape::loops tells the host).
+template <int TASK, int I, int O> constexpr bool coop_has_loop() { return O <= 3; }
+template <int TASK, int I, int O> constexpr bool pack_has_loop() { return TASK == TASK_REG && I <= 8; }
+
 template <int TASK, int I, int O>
 __global__ void __launch_bounds__(MAX_THREADS) segment_kernel(const SegParams p, const PersistParams pp, const int step_begin) {
-    persistent_loop(p, pp, step_begin, [](const SegParams& q, int b, int n) { segment_body<TASK, I, O>(q, b, n); });
+    persistent_loop<coop_has_loop<TASK, I, O>()>(p, step_begin, [](const SegParams& q, const SegDyn& d, int b, int n) { segment_body<TASK, I, O>(q, d, b, n); });
 }
 template <int TASK, int I, int O>
 __global__ void __launch_bounds__(MAX_THREADS) segment_spec_kernel(const SegParams p, const PersistParams pp, const int step_begin) {
-    persistent_loop(p, pp, step_begin, [](const SegParams& q, int b, int n) { segment_spec_body<TASK, I, O>(q, b, n); });
+    persistent_loop<false>(p, step_begin, [](const SegParams& q, const SegDyn& d, int b, int n) { segment_spec_body<TASK, I, O>(q, d, b, n); });
 }
 template <int TASK, int I, int O>
 __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const SegParams p, const PersistParams pp, const int step_begin) {
-    persistent_loop(p, pp, step_begin, [](const SegParams& q, int b, int n) {
-        if (q.pk_nred == 4) segment_pack_body<TASK, I, O, 4>(q, b, n);
-        else segment_pack_body<TASK, I, O, 3>(q, b, n);
+    persistent_loop<pack_has_loop<TASK, I, O>()>(p, step_begin, [](const SegParams& q, const SegDyn& d, int b, int n) {
+        if (q.pk_nred == 4) segment_pack_body<TASK, I, O, 4>(q, d, b, n);
+        else segment_pack_body<TASK, I, O, 3>(q, d, b, n);
     });
 }
 template <int TASK, int I, int O>
 __global__ void __launch_bounds__(MAX_THREADS) segment_tree_kernel(const SegParams p, const PersistParams pp, const int step_begin) {
-    persistent_loop(p, pp, step_begin, [](const SegParams& q, int b, int n) { segment_tree_body<TASK, I, O>(q, b, n); });
+    persistent_loop<false>(p, step_begin, [](const SegParams& q, const SegDyn& d, int b, int n) { segment_tree_body<TASK, I, O>(q, d, b, n); });
 }
 #pragma clang fp contract(fast)     // the wide-net section's policy (see above model_wide_kernel)
 template <int TASK, int I, int O>
 __global__ void __launch_bounds__(MAX_THREADS) segment_wide_kernel(const SegParams p, const PersistParams pp, const int step_begin) {
-    persistent_loop(p, pp, step_begin, [](const SegParams& q, int b, int n) { segment_wide_body<TASK, I, O, false>(q, b, n); });
+    persistent_loop<true>(p, step_begin, [](const SegParams& q, const SegDyn& d, int b, int n) { segment_wide_body<TASK, I, O, false>(q, d, b, n); });
 }
 // state and proposal resident in LDS (host: matrix-core layout and 2 vectors + scratch fit in 160 KB)
 template <int TASK, int I, int O>
 __global__ void __launch_bounds__(MAX_THREADS) segment_wide_res_kernel(const SegParams p, const PersistParams pp, const int step_begin) {
-    persistent_loop(p, pp, step_begin, [](const SegParams& q, int b, int n) { segment_wide_body<TASK, I, O, true>(q, b, n); });
+    persistent_loop<true>(p, step_begin, [](const SegParams& q, const SegDyn& d, int b, int n) { segment_wide_body<TASK, I, O, true>(q, d, b, n); });
 }
 #pragma clang fp contract(off)
 

@@ -26,5 +26,6 @@ struct Shape {
     seg_fn pack;            // H <= 8: packed speculative schedule
     seg_fn tree;            // prefetching tree schedule (random-walk classification), H <= 64
     seg_fn seg_wide_res;    // 64 < H <= 512, H % 32 == 0, state + proposal resident in LDS
+    int loops;              // which kernels carry the interval loop of a persistent launch: bit 0 seg, bit 1 pack (wide: always; spec, tree: never)
 };
 }  // namespace ptnn

@@ -67,6 +67,28 @@ def test_whole_run_followed_to_the_end(name):
     assert rep["forced_swap_pairs"] <= max(2, rep["swap_pairs"] // 500), rep
 
 
+def test_config5_at_its_bench_shape_followed_to_the_end():
+    """BASELINE config 5 as bench.py runs it on one GPU -- FNN 32-512-1 (P = 17 409), 1024 / 256 rows, 128 chains, Langevin p = 0.5,
+    the LDS-resident wide kernel with two work-groups per chain and compact traces -- for 13 samples per chain across two swap rounds
+    (the float64 oracle needs 50 ms per step of this net even in C): every step, decision and trace row against the oracle."""
+    train, test = parity.synthetic_regression(1280, 1024, 32, 512, seed=5)
+    topo, R, S, si, seed = (32, 512, 1), 128, 13, 5, 1
+    pt = orc.PTOracle(orc.TASK_REG, topo, train, test, R, 2, R * S, si, use_lg=True, l_prob=0.5, lr=0.1, seed=seed)
+    w0 = (0.3 * np.stack([rep.w for rep in pt.replicas])).astype(np.float32)      # bench.py's scale for wide nets
+    orc_c.adopt(pt, w0=w0.astype(np.float64))
+    s = parity.make_sampler(orc.TASK_REG, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=True, lr=0.1, seed=seed)
+    info = s.describe()
+    assert info["lds_resident_state"] == 1 and info["compact_traces"] == 1 and info["groups_per_replica"] == 2, info
+    s.set_state(w0, np.array(pt.temperatures, dtype=np.float32))
+    s.run(-1)
+    s.sync()
+    tr = s.traces()
+    rep = parity.follow_device_run(s, tr, pt, "config5 ", threads=16, row_rtol=2e-4, row_atol=5e-4)
+    s.close()
+    print("config5", json.dumps(rep))
+    assert rep["steps"] == R * (S - 1) and rep["forced_mh"] <= 2 and rep["forced_swap_pairs"] <= 2, rep
+
+
 @pytest.mark.parametrize("shared_noise", [0, 1])
 def test_headline_run_at_the_bench_size_followed_to_the_end(shared_noise):
     """The BASELINE metric's own run, exactly as bench.py makes it (Sunspot 4-5-1, 64 chains x 10 000 samples, Langevin p = 0.5,
