@@ -112,7 +112,10 @@ int ptnn_set_ladder(ptnn_handle *h, const float *temperatures_global);
  * phantom last round when the chain end is reached.  n_steps < 0 = run to the end.  A handle that owns only a
  * block of the ladder (n_replicas_local < n_replicas_global) needs a communicator (ptnn_comm_init / ptnn_comm_init_host)
  * and every rank calls ptnn_run with the same n_steps: the swap rounds then exchange through it.  Asynchronous: returns
- * once the work is queued (the "boundary" exchange waits once per swap round for the permutation); ptnn_sync waits. */
+ * once the work is queued (the "boundary" exchange waits once per swap round for the permutation); ptnn_sync waits.
+ * Without a communicator, and when every work-group of the grid is resident (ptnn_describe: "launches"), the whole call is ONE
+ * kernel launch: the intervals and the swap rounds between them run inside it (grid barriers); otherwise one launch per swap
+ * interval plus one for the round.  The chains are identical either way. */
 int ptnn_run(ptnn_handle *h, int n_steps);
 int ptnn_sync(ptnn_handle *h);
 /* number of MH steps queued so far (0 .. S-1) */

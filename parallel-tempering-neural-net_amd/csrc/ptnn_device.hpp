@@ -6,6 +6,10 @@
 // the Philox noise pass and the trace-row store).  Weights, the data set and every per-step
 // vector live in LDS; HBM sees only the trace rows the result-file layout requires.
 //
+// Layout of this file: the interval BODIES of the five schedules (segment_body, segment_spec_body, segment_pack_body,
+// segment_wide_body, segment_tree_body: all MH steps of one swap interval), swap_block (one work-group's share of a swap round),
+// and at the end persistent_loop + the __global__ kernels: body, grid barrier, swap_block, next interval -- one launch per run.
+//
 // Written for gfx950 only: wave size 64, DPP row operations, v_permlane{16,32}_swap.
 #pragma once
 #include <type_traits>

@@ -7,8 +7,9 @@ What `main()` touches (REG:995-1007, CLS:1080-1092) is kept: the constructor arg
 `initialize_chains(burn_in)`, `run_chains()` with its 11-tuple, the attributes `num_swap`,
 `total_swap_proposals`, `temperatures`, `NumSamples`, `num_param`, and every file under `path`
 (SURVEY.md section 8b).  What happens in between -- one forked process per replica, queues and events --
-is replaced by libptnn.so: all replicas advance inside one HIP kernel per swap interval and the swap
-cascade is a second kernel; this module only configures the run, fetches the traces and writes the files.
+is replaced by libptnn.so: all replicas advance inside one HIP kernel -- one launch for the whole run with the
+swap cascade inside it where every work-group is resident, else one launch per swap interval with the cascade
+as a second kernel; this module only configures the run, fetches the traces and writes the files.
 """
 import math
 import os
