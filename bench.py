@@ -95,7 +95,7 @@ def switch_step(S):
 class Ladder:
     """The sampler of one rank (one GPU): a contiguous block of the temperature ladder."""
 
-    def __init__(self, wl, a, train, test, rank, world, device, shared_noise=None):
+    def __init__(self, wl, a, train, test, rank, world, device, shared_noise=None, shared_device=0):
         import ptnn_amd  # noqa: F401
         from ptnn_amd import _lib, ladder, philox
         topo, R = wl["topo"], wl["R"]
@@ -107,7 +107,8 @@ class Ladder:
                               swap_interval=wl["si"], pt_switch_step=switch_step(self.S), use_langevin=int(wl["lg"]),
                               waves_per_replica=a.waves, schedule=a.schedule, groups_per_replica=a.groups, l_prob=0.5,
                               learn_rate=wl["lr"], step_w=0.025, step_eta=0.2, sigma_squared=25.0, nu_1=0.0, nu_2=0.0, seed=SEED,
-                              forward_bf16=int(a.bf16), shared_noise=int(a.shared_noise if shared_noise is None else shared_noise))
+                              forward_bf16=int(a.bf16), shared_noise=int(a.shared_noise if shared_noise is None else shared_noise),
+                              shared_device=int(shared_device))
         self.s.set_data(train, test)
         scale = 0.3 if topo[1] > 64 else 1.0      # wide nets: N(0,1) weights saturate every hidden unit of a 512-unit layer
         self.w0 = scale * np.stack([philox.initial_weights(SEED, first + r, self.P) for r in range(R)])
@@ -312,13 +313,8 @@ def main():
         torch.cuda.set_device(device)
     else:
         device = local_rank
-    if sharded and a.transport == "host" and N > 1 and not a.schedule and not a.groups:
-        # the rehearsal puts every rank on GPU 0: schedules whose work-groups wait for each other size themselves for a whole GPU
-        if wl["topo"][1] > 64:
-            a.groups = 1
-        elif wl["task"] == 1 and not wl["lg"]:
-            a.schedule = 1
-    lad = Ladder(wl, a, train, test, rank, N, device)
+    # the host-transport rehearsal puts every rank on GPU 0: libptnn then keeps to schedules whose work-groups never wait for each other
+    lad = Ladder(wl, a, train, test, rank, N, device, shared_device=int(sharded and a.transport == "host" and N > 1))
     s = lad.s
     if sharded:
         from ptnn_amd import _lib

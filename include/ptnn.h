@@ -77,6 +77,13 @@ typedef struct ptnn_config {
                                    * for its new temperature) and prior: no stale values (Q12 does not apply).  Works with both swap
                                    * rules; needs ptnn_set_ladder.  Trace rows are recorded per chain slot: ptnn_get_labels / the swap log
                                    * say which temperature a slot held when (the Python host stitches the per-temperature files). */
+    int32_t shared_device;        /* 1 = other handles or processes run on this GPU at the same time (several blocks of one ladder
+                                   * rehearsing the N > 1 path on one device): automatic choices then avoid every schedule whose
+                                   * work-groups wait for each other -- several work-groups per replica, the persistent launch --
+                                   * because their residency cannot be guaranteed (a non-resident partner is a bounded spin and
+                                   * error -5).  Explicit schedule / groups_per_replica requests are still honoured.  0 = the GPU is
+                                   * this handle's alone (default). */
+    int32_t reserved_;            /* keeps the floats 8-byte aligned with the seed; set 0 */
     float l_prob;                 /* langevin_prob (REG:174); CLS fixes 0.5 (CLS:192) */
     float learn_rate;             /* SGD step of langevin_gradient (REG:33) */
     float step_w;                 /* 0.025 (REG:258) */

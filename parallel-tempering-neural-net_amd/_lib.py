@@ -19,7 +19,7 @@ class Config(C.Structure):
         ("n_in", C.c_int32), ("n_hidden", C.c_int32), ("n_out", C.c_int32),
         ("n_replicas_local", C.c_int32), ("n_replicas_global", C.c_int32), ("first_global_replica", C.c_int32),
         ("n_samples", C.c_int32), ("swap_interval", C.c_int32), ("pt_switch_step", C.c_int32),
-        ("use_langevin", C.c_int32), ("waves_per_replica", C.c_int32), ("schedule", C.c_int32), ("groups_per_replica", C.c_int32), ("trace_capacity", C.c_int32), ("forward_bf16", C.c_int32), ("swap_rule", C.c_int32), ("shared_noise", C.c_int32), ("label_swap", C.c_int32),
+        ("use_langevin", C.c_int32), ("waves_per_replica", C.c_int32), ("schedule", C.c_int32), ("groups_per_replica", C.c_int32), ("trace_capacity", C.c_int32), ("forward_bf16", C.c_int32), ("swap_rule", C.c_int32), ("shared_noise", C.c_int32), ("label_swap", C.c_int32), ("shared_device", C.c_int32), ("reserved_", C.c_int32),
         ("l_prob", C.c_float), ("learn_rate", C.c_float), ("step_w", C.c_float), ("step_eta", C.c_float),
         ("sigma_squared", C.c_float), ("nu_1", C.c_float), ("nu_2", C.c_float),
         ("seed", C.c_uint64),

@@ -363,7 +363,7 @@ int finish_stream(ptnn_handle* h) {
 int resolve_persistent(ptnn_handle* h) {
     h->persistent = false;
     const char* e = std::getenv("PTNN_PERSISTENT");
-    if (e && e[0] == '0') return 0;
+    if ((e && e[0] == '0') || h->cfg.shared_device) return 0;     // grid barriers want every work-group resident: not on a shared GPU
     const int G = (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
     if (G > 1 && !(e && e[0] == '1')) return 0;
     // kernels compiled without the interval loop (ptnn_device.hpp: persistent_loop<false>)
@@ -483,6 +483,7 @@ int ptnn_create(const ptnn_config* cfg, ptnn_handle** out) {
     if (cfg->swap_interval < 1) return fail(-1, "swap_interval must be >= 1 (the reference divides by it, REG:427)");
     if (cfg->swap_rule != 0 && cfg->swap_rule != 1) return fail(-1, "swap_rule must be 0 (reference cascade) or 1 (even/odd Metropolis)");
     if (cfg->label_swap != 0 && cfg->label_swap != 1) return fail(-1, "label_swap must be 0 or 1");
+    if (cfg->shared_device != 0 && cfg->shared_device != 1) return fail(-1, "shared_device must be 0 or 1");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(-2, "device %d not present (%d devices)", cfg->device_id, ndev);
@@ -608,7 +609,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
                     return fail(-3, "%d replicas x %d work-groups cannot all be resident: %d work-group(s) of %d threads with %zu B of LDS fit "
                                     "on each of the %d CUs", Rl, want, per_cu, h->nthreads, lds, h->num_cus);
                 G = want;
-            } else if (want == 0) {
+            } else if (want == 0 && !h->cfg.shared_device) {     // (work-groups that wait for each other want the GPU to themselves)
                 if ((long long)Rl * 4 <= cap) G = 4;
                 else if ((long long)Rl * 2 <= cap) G = 2;
             }
@@ -692,7 +693,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         const int Rl = h->cfg.n_replicas_local;
         int G = 1;
         if (h->cfg.groups_per_replica > 0) G = h->cfg.groups_per_replica;
-        else { while (G < 4 && Rl * (G * 2) <= h->num_cus) G *= 2; }
+        else if (!h->cfg.shared_device) { while (G < 4 && Rl * (G * 2) <= h->num_cus) G *= 2; }
         if (G != 1 && G != 2 && G != 4 && G != 8) return fail(-1, "groups_per_replica must be 0 (auto), 1, 2, 4 or 8");
         int k = nw ? nw : (G > 1 ? 4 : 8);
         while (k > 1 && spec_lds_floats(Nall, IPY, h->PS, H, h->FWS, k, G) * sizeof(float) > LDS_MAX) k >>= 1;
@@ -748,7 +749,8 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         if (h->fw_mfma) h->seg_lds = seg_lds + extra;
     }
     if (sched == PTNN_SCHED_TREE || (sched == PTNN_SCHED_COOPERATIVE && h->cfg.schedule == PTNN_SCHED_AUTO && h->cfg.task == PTNN_TASK_CLS &&
-                                     !h->cfg.use_langevin && h->cfg.groups_per_replica == 0 && h->cfg.waves_per_replica == 0)) {
+                                     !h->cfg.use_langevin && h->cfg.groups_per_replica == 0 && h->cfg.waves_per_replica == 0 &&
+                                     !h->cfg.shared_device)) {
         // Prefetching tree: 2^D - 1 work-groups per replica, all of them resident (they wait for each other's records).
         // Explicit: groups_per_replica = 3, 7, 15 or 31 (0: deepest that fits, up to 15); auto: deepest of 15 / 7 / 3 that fits,
         // none -> the cooperative schedule stays.
@@ -1393,7 +1395,7 @@ int ptnn_checkpoint_save(ptnn_handle* h, void* buf, int64_t bytes) {
     if (int rc = finish_stream(h)) return rc;
     const size_t Rl = h->cfg.n_replicas_local, R = h->cfg.n_replicas_global, PS = h->PS;
     CkHeader hd{};
-    hd.magic = CK_MAGIC; hd.version = 2; hd.cfg = h->cfg; hd.P = h->P; hd.PS = h->PS; hd.cur = h->cur;
+    hd.magic = CK_MAGIC; hd.version = 3; hd.cfg = h->cfg; hd.P = h->P; hd.PS = h->PS; hd.cur = h->cur;
     hd.rounds_done = h->rounds_done; hd.finalized = h->finalized ? 1 : 0; hd.have_ladder = h->have_ladder ? 1 : 0;
     hd.log_rounds = std::min(h->rounds_done, h->max_rounds);
     HIP_TRY(hipMemcpy(hd.counters, h->d_counters, sizeof(hd.counters), hipMemcpyDeviceToHost));
@@ -1428,7 +1430,7 @@ int ptnn_checkpoint_load(ptnn_handle* h, const void* buf, int64_t bytes) {
     if (bytes < (int64_t)sizeof(CkHeader)) return fail(-1, "not a checkpoint (too short)");
     CkHeader hd;
     std::memcpy(&hd, buf, sizeof(hd));
-    if (hd.magic != CK_MAGIC || hd.version != 2) return fail(-1, "not a libptnn checkpoint (magic %08x version %u)", hd.magic, hd.version);
+    if (hd.magic != CK_MAGIC || hd.version != 3) return fail(-1, "not a libptnn checkpoint (magic %08x version %u)", hd.magic, hd.version);
     if (!same_chain(hd.cfg, h->cfg) || hd.P != h->P || hd.PS != h->PS)
         return fail(-1, "the checkpoint was written by chains with a different configuration (topology, replicas, samples, seed ...)");
     HIP_TRY(hipSetDevice(h->cfg.device_id));

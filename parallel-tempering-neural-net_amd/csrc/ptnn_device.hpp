@@ -3695,9 +3695,6 @@ __device__ __forceinline__ persist_cptr persist_args() {
     return (persist_cptr)(uintptr_t)a;
 }
 
-// LOOP = false: one interval per launch and nothing else (the two schedules with several work-groups per replica and the most
-// registers -- multi-CU speculative, prefetching tree -- where the loop around the body cost 30 - 40 vector registers, i.e. scratch,
-// and where a persistent launch is measured to lose against the launch boundary anyway, DESIGN.md section 6).
 typedef __attribute__((address_space(4))) const SegParams* seg_cptr;
 __device__ __forceinline__ seg_cptr seg_args() {
     unsigned long long a = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
@@ -3705,6 +3702,9 @@ __device__ __forceinline__ seg_cptr seg_args() {
     return (seg_cptr)(uintptr_t)a;
 }
 
+// LOOP = false: one interval per launch and nothing else (the two schedules with several work-groups per replica and the most
+// registers -- multi-CU speculative, prefetching tree -- where the loop around the body cost 30 - 40 vector registers, i.e. scratch,
+// and where a persistent launch is measured to lose against the launch boundary anyway, DESIGN.md section 6).
 template <bool LOOP, class Body>
 __device__ __forceinline__ void persistent_loop(const SegParams& p0, const int step_begin, Body body) {
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -139,13 +139,9 @@ class LadderGroup:
         shared_gpu = len(set(self.devices)) < n
         def create(k):
             cfg = dict(config, device_id=self.devices[k], n_replicas_local=self.Rl, first_global_replica=k * self.Rl)
-            # the prefetching tree and the wide nets' speculative schedule size themselves for a GPU they have to themselves (their
-            # work-groups wait for each other): blocks that share one GPU (a rehearsal of the N > 1 path) keep one work-group per replica
-            if shared_gpu and not cfg.get("schedule") and not cfg.get("groups_per_replica"):
-                if int(cfg.get("n_hidden", 0)) > 64:
-                    cfg["groups_per_replica"] = 1
-                elif cfg.get("task") == 1 and not cfg.get("use_langevin"):
-                    cfg["schedule"] = 1
+            # blocks that share one GPU (a rehearsal of the N > 1 path): no schedule whose work-groups wait for each other
+            if shared_gpu:
+                cfg["shared_device"] = 1
             self.shards[k] = _lib.Sampler(**cfg)
         self._each(create)
         s0 = self.shards[0]
