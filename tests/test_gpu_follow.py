@@ -52,6 +52,10 @@ WHOLE = {
     "iris16": (1, (4, 12, 3), "iris", 16, False, 0.01, 10, 3000, 100),
     "mackey64": (0, (4, 10, 1), "mackey", 64, True, 0.1, 2, 1000, 100),
     "ionosphere256": (1, (34, 50, 2), "ions", 256, False, 0.01, 10, 400, 100),
+    # two more problems of the reference's tables on their shipped data: Lazer (REG:881-917, 4-5-1, Langevin) and Cancer
+    # (CLS:950-957: 9 inputs, 12 hidden units, 2 classes, random-walk), 10 chains as in its main()
+    "lazer10": (0, (4, 5, 1), "lazer", 10, True, 0.1, 2, 2000, 20),
+    "cancer10": (1, (9, 12, 2), "cancer", 10, False, 0.01, 10, 2000, 40),
 }
 
 
