@@ -220,10 +220,11 @@ void fill_swap_params(ptnn_handle* h, bool phantom, SwapParams& sp) {
 
 // MH steps [begin, end) in one launch.  swap_inside: the swap rounds between the intervals run inside it (persistent launch:
 // every work-group resident, grid barriers); otherwise [begin, end) is one interval and the caller queues swap_kernel behind it.
-int launch_segment(ptnn_handle* h, int begin, int end, bool swap_inside = false) {
+int launch_segment(ptnn_handle* h, int begin, int end, bool swap_inside = false, bool round_follows = false) {
     if (end <= begin) return 0;
     HIP_TRY(hipSetDevice(h->cfg.device_id));
-    const SegParams p = h->seg_params();
+    SegParams p = h->seg_params();
+    if (round_follows && h->comm.kind == COMM_RCCL) { p.seg_progress = h->h_progress + 1; p.seg_ordinal = h->rounds_done + 1; }
     PersistParams pp{};
     pp.end = end; pp.swap_inside = swap_inside ? 1 : 0; pp.task = h->cfg.task; pp.si = h->cfg.swap_interval;
     pp.round0 = h->rounds_done; pp.flip0 = h->flip; pp.lflip0 = h->lflip;
@@ -318,20 +319,21 @@ int wait_stream(ptnn_handle* h) {
         return 0;
     }
     const double limit = comm_timeout_s();
-    volatile int* prog = h->h_progress;
-    int seen = *prog;
+    volatile int* prog = h->h_progress;      // [0] swap rounds completed, [1] index + 1 of the round whose segment has ended
+    int seen0 = prog[0], seen1 = prog[1];
     double t_seen = comm_clock();
     for (unsigned spins = 0;; ++spins) {
         const hipError_t q = hipStreamQuery(h->stream);
         if (q == hipSuccess) return 0;
         if (q != hipErrorNotReady) return fail(-2, "hipStreamQuery failed: %s", hipGetErrorString(q));
-        const int now = *prog;
-        if (now != seen) { seen = now; t_seen = comm_clock(); }
+        const int now0 = prog[0], now1 = prog[1];
+        // the clock runs only while a collective is at the head of the stream: the segment before round k has ended (prog[1] ==
+        // k + 1) and the round has not (prog[0] == k).  A segment, however long, is bounded by its own kernel spins.
+        if (now0 != seen0 || now1 != seen1 || now1 <= now0) { seen0 = now0; seen1 = now1; t_seen = comm_clock(); }
         else if (comm_clock() - t_seen > limit) {
             h->failed = true; h->comm.failed = true;
-            h->failure = "no progress on the handle's stream for " + std::to_string((int)limit) + " s with " + std::to_string(seen) +
-                         " of " + std::to_string(h->rounds_done) + " queued swap rounds completed on the device; last communicator stage: " +
-                         comm_last_stage();
+            h->failure = "no progress on the handle's stream for " + std::to_string((int)limit) + " s inside swap round " + std::to_string(now0) +
+                         " (" + std::to_string(h->rounds_done) + " queued); last communicator stage: " + comm_last_stage();
             return fail(-7, "%s", h->failure.c_str());
         }
         if (spins < 4096) sched_yield();
@@ -440,8 +442,8 @@ int create_buffers(ptnn_handle* h, const ptnn_config* cfg, const Shape* sh, cons
     HIP_TRY(hipMalloc(&h->d_error, sizeof(int)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_stage), (Rl * h->P + Rl) * sizeof(float), hipHostMallocDefault));
     HIP_TRY(hipMalloc(&h->d_stage, (Rl * h->P + Rl) * sizeof(float)));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_progress), sizeof(int), hipHostMallocDefault));
-    *h->h_progress = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_progress), 2 * sizeof(int), hipHostMallocDefault));
+    h->h_progress[0] = h->h_progress[1] = 0;
     HIP_TRY(hipMalloc(&h->d_stamps, 160 * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(h->d_stamps, 0, 160 * sizeof(unsigned long long), h->stream));
     HIP_TRY(hipMemsetAsync(h->d_error, 0, sizeof(int), h->stream));
@@ -834,7 +836,7 @@ int ptnn_set_state(ptnn_handle* h, const float* w0, const float* temperatures) {
     HIP_TRY(hipGetLastError());
     h->flip = 0; h->cur = 0; h->rounds_done = 0; h->finalized = false; h->drained = 0; h->first_row = 0; h->lflip = 0;
     if (!h->comm.failed) { h->failed = false; h->failure.clear(); }   // a restart clears a failed run (a failed communicator stays failed)
-    *h->h_progress = 0;
+    h->h_progress[0] = h->h_progress[1] = 0;
     h->have_state = true;
     return 0;
 }
@@ -943,7 +945,8 @@ int ptnn_run(ptnn_handle* h, int n_steps) {
         while (seg_end < end && !swap_trigger(h->cfg, seg_end)) ++seg_end;
         const bool handoff = seg_end < end;                  // step seg_end triggers a hand-off
         const int stop = handoff ? seg_end + 1 : end;
-        if (int rc = launch_segment(h, h->cur, stop)) return rc;
+        const bool phantom_next = !handoff && stop == last && !h->finalized && h->cfg.swap_rule == 0 && S / h->cfg.swap_interval > h->rounds_done;
+        if (int rc = launch_segment(h, h->cur, stop, false, sharded && (handoff || phantom_next))) return rc;
         h->cur = stop;
         if (handoff) {
             if (sharded) {
@@ -1479,7 +1482,7 @@ int ptnn_checkpoint_load(ptnn_handle* h, const void* buf, int64_t bytes) {
     h->drained = hd.cur; h->first_row = hd.cur + 1;
     HIP_TRY(hipMemset(h->d_error, 0, sizeof(int)));
     if (!h->comm.failed) { h->failed = false; h->failure.clear(); }
-    *h->h_progress = hd.rounds_done;
+    h->h_progress[0] = h->h_progress[1] = hd.rounds_done;
     h->have_state = true;
     return 0;
 }

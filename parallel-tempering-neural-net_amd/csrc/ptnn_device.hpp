@@ -96,6 +96,8 @@ struct SegParams {
     const float* xt;         // wide nets: transposed data image Xt[k][Npad] (B operand of the MFMA forward pass), or null
     int Npad;                // rows of Xt, Nall rounded up to 32
     int forward_bf16;        // 1: forward GEMM operands rounded to bf16 (fp32 accumulate); 0: exact fp32 MFMA
+    int* seg_progress;       // pinned host word or null (RCCL communicator attached): block 0 stores seg_ordinal when this launch ends
+    int seg_ordinal;         // with a swap round due -- "the collective of round seg_ordinal - 1 is next on the stream" (ptnn.hip: wait_stream)
     int compact;             // wide nets, all rows resident (trace_cap == S): a REJECTED step writes no pos_w row, only the index of the
                              // row it repeats (TR_SRC); ptnn_get_traces fills the rows in.  A 70 KB copy per rejected step otherwise.
 };
@@ -3716,6 +3718,8 @@ __device__ __forceinline__ void persistent_loop(const SegParams& p0, const int s
         dyn.w_state = pp->state[flip]; dyn.gd_w = pp->gd[flip]; dyn.gd_valid = pp->gd_valid[flip];
         dyn.epoch_base = p.epoch_base;
         body(p, dyn, step_begin, pp->end - step_begin);
+        if (p.seg_progress && blockIdx.x == 0 && threadIdx.x == 0)
+            __hip_atomic_store(p.seg_progress, p.seg_ordinal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
     // the interval body sees the kernel arguments through an opaque pointer, re-read every interval: nothing the body derives
@@ -3775,6 +3779,8 @@ __device__ __forceinline__ void persistent_loop(const SegParams& p0, const int s
         if (p.G > 1 && !grid_barrier(pp->barrier, pp->nblocks, ++phase, p.error_flag)) { if (threadIdx.x == 0) atomicAdd(p.error_flag, 1); return; }
         if (p.G == 1) __syncthreads();
     }
+    if (p0.seg_progress && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(p0.seg_progress, p0.seg_ordinal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Which kernels carry the interval loop.  The loop costs 10 - 40 vector registers (values the optimiser keeps alive around the
