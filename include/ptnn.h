@@ -265,7 +265,9 @@ int ptnn_langevin_gradient(ptnn_handle *h, const float *w_in, int n, float *w_ou
 /* What ONE sequential SGD epoch (langevin_gradient of one chain, REG:99-118) costs on this device, in milliseconds: `reps` epochs
  * back to back on one wavefront, timed inside the kernel with the constant-rate counter (s_memrealtime; the rate comes from
  * hipDeviceAttributeWallClockRate).  An accepted Langevin step makes the next proposal wait for a fresh epoch, so accepted steps x
- * this number is the floor of a swap interval whatever the number of speculative slots (bench.py: roofline.chain).  n_hidden <= 64. */
+ * this number is the floor of a swap interval whatever the number of speculative slots (bench.py: roofline.chain).
+ * ms_per_epoch[2]: [0] one epoch; [1] wide nets (n_hidden > 64) only: a PAIR of epochs run through one row loop (what two Langevin
+ * steps of one speculative window cost together), else 0. */
 int ptnn_time_sgd_epoch(ptnn_handle *h, const float *w, int reps, double *ms_per_epoch);
 /* the random tape of MH step `step` of global replica `replica`: noise [P] normals, scal[3] = {lx, u, n_eta} */
 int ptnn_tape(ptnn_handle *h, int replica, int step, float *noise, float *scal);

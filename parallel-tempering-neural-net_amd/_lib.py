@@ -379,12 +379,13 @@ class Sampler:
         self._check(self.lib.ptnn_langevin_gradient(self.h, _ptr(w), w.shape[0], _ptr(out)))
         return out
 
-    def time_sgd_epoch(self, w, reps=200):
-        """Milliseconds one sequential SGD epoch of one chain takes on the device (in-kernel constant-rate counter)."""
+    def time_sgd_epoch(self, w, reps=200, pair=False):
+        """Milliseconds one sequential SGD epoch of one chain takes on the device (in-kernel constant-rate counter); pair=True
+        (wide nets): (one epoch, a pair of epochs through one row loop)."""
         w = _f32(w).reshape(-1)
-        ms = C.c_double()
-        self._check(self.lib.ptnn_time_sgd_epoch(self.h, _ptr(w), int(reps), C.byref(ms)))
-        return ms.value
+        ms = (C.c_double * 2)()
+        self._check(self.lib.ptnn_time_sgd_epoch(self.h, _ptr(w), int(reps), ms))
+        return (ms[0], ms[1]) if pair else ms[0]
 
     def tape(self, replica, step):
         noise, scal = np.empty(self.P, np.float32), np.empty(3, np.float32)

@@ -1529,16 +1529,19 @@ int ptnn_langevin_gradient(ptnn_handle* h, const float* w_in, int n, float* w_ou
 
 int ptnn_time_sgd_epoch(ptnn_handle* h, const float* w, int reps, double* ms_per_epoch) {
     if (!h || !w || !ms_per_epoch || reps < 1) return fail(-1, "bad argument");
-    if (h->wide) return fail(-3, "the epoch timer covers the one-wave sweep (n_hidden <= 64)");
-    float out[3] = {0.f, 0.f, 0.f};
-    if (int rc = run_model(h, 3, w, nullptr, 1, out, 3, reps, 0)) return rc;
-    unsigned lo, hi;
-    std::memcpy(&lo, &out[0], 4); std::memcpy(&hi, &out[1], 4);
+    float out[4] = {0.f, 0.f, 0.f, 0.f};
+    if (int rc = run_model(h, 3, w, nullptr, 1, out, 4, reps, 0)) return rc;
     int khz = 0;
     HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id));
     if (khz <= 0) return fail(-2, "the device reports no wall clock rate");
-    const double ticks = (double)(((unsigned long long)hi << 32) | lo);
-    *ms_per_epoch = ticks / (double)khz / (double)reps;
+    auto ticks = [&](int k) {
+        unsigned lo, hi;
+        std::memcpy(&lo, &out[k], 4); std::memcpy(&hi, &out[k + 1], 4);
+        return (double)(((unsigned long long)hi << 32) | lo);
+    };
+    ms_per_epoch[0] = ticks(0) / (double)khz / (double)reps;
+    // wide nets (n_hidden > 64): [1] = a PAIR of epochs through one row loop (sgd_sweep_wide_pair); narrow nets: 0
+    ms_per_epoch[1] = h->wide ? ticks(2) / (double)khz / (double)reps : 0.0;
     return 0;
 }
 

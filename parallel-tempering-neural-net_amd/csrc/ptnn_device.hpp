@@ -181,6 +181,31 @@ __device__ __forceinline__ float group_allsum(float v) {
     return v;
 }
 __device__ __forceinline__ float wave_allsum(float v) { return group_allsum<6>(v); }
+// N independent wave sums, stage by stage: an in-order wave then always has the other values' stage to issue while one value's
+// DPP result is in flight (same operations per value as wave_allsum)
+template <int N>
+__device__ __forceinline__ void wave_allsum_n(float (&v)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += dpp_mov<0xB1>(v[k]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += dpp_mov<0x4E>(v[k]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += dpp_mov<0x141>(v[k]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += dpp_mov<0x140>(v[k]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const unsigned u = __builtin_bit_cast(unsigned, v[k]);
+        auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v[k] = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const unsigned u = __builtin_bit_cast(unsigned, v[k]);
+        auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v[k] = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    }
+}
 
 // A "group" is either the whole work-group (WL = false: cooperative schedule, all waves work on one MH step) or one
 // wavefront (WL = true: speculative schedule, every wave works on its own MH step).  LDS traffic inside one wave is
@@ -2259,7 +2284,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
 // res: the current state vector is kept in LDS next to the proposal (matrix-core layout only: there the flat image IS the proposal)
 __host__ __device__ inline size_t wide_lds_floats(int H, int FWS, int O, int PS, bool res = false) {
     const size_t img = (fw_floats(H, FWS) > (size_t)PS) ? fw_floats(H, FWS) : (size_t)PS;   // packed or flat image
-    return img + (res ? (size_t)PS : 0) + MAX_WAVES * 8 + 2 * MAX_WAVES * (size_t)((O + 3) & ~3) + 16 + 6 * 8;   // + per-slot scalars of a window (WIDE_WINDOW = 8)
+    return img + (res ? (size_t)PS : 0) + MAX_WAVES * 8 + 4 * MAX_WAVES * (size_t)((O + 3) & ~3) + 16 + 6 * 8;   // partial sums of up to two epochs; + per-slot scalars of a window (WIDE_WINDOW = 8)
 }
 __host__ __device__ inline size_t wide_img_floats(int H, int FWS, int PS) {
     return (fw_floats(H, FWS) > (size_t)PS) ? fw_floats(H, FWS) : (size_t)PS;
@@ -2282,10 +2307,18 @@ __host__ __device__ inline size_t wide_img_floats(int H, int FWS, int PS) {
 // it pushed 312 VGPRs of the kernel into scratch (1236 B per lane for the 32-H-1 shape).
 // w_ref (optional): returns this thread's share of |w_ref - w_out|^2, summed from the registers the result is written from -- the
 // first term of the Langevin proposal ratio (REG:336-340) without reading the 70 KB result back.
-template <int TASK, int I, int O>
-__device__ __attribute__((noinline, aligned(256))) float sgd_sweep_wide(const float* __restrict__ w_in, float* __restrict__ w_out,
-                                                          const float* __restrict__ data, int IPY, int Ntr, int H, float lr,
-                                                          float* __restrict__ part, const float* w_ref = nullptr) {
+//
+// NE = 2: TWO independent epochs (two Langevin proposals of one speculative window, both made on the assumption that the steps
+// before them reject) run through the SAME row loop: one barrier, one set of data rows in scalar registers and one trip through
+// the reduction latency per row serve both; every epoch performs exactly the operations of the NE = 1 code in the same order.
+// MEASURED AND NOT USED by the sampler: a pair costs 1.69 x one epoch (ptnn_time_sgd_epoch: 436 us vs 737 us for 32-512-1; with
+// two waves per SIMD the row loop is mostly issue-bound, not latency-bound), and pairing the Langevin steps of a window in
+// segment_wide_body bought 3 % against 4 % lost to the extra registers of the step loop (profiles/r03_wide_pair.json).  Kept
+// for the timer (model_wide_kernel mode 3), as the record of that experiment.
+template <int TASK, int I, int O, int NE>
+__device__ __forceinline__ void sgd_sweep_wide_n(const float* const (&w_in)[NE], float* const (&w_out)[NE], const float* __restrict__ data,
+                                                 int IPY, int Ntr, int H, float lr, float* __restrict__ part, const float* w_ref,
+                                                 float (&d1_out)[NE]) {
     constexpr float C = -LOG2E, IC = -LN2;
     constexpr int OP = (O + 3) & ~3;
     constexpr int IP = (I + 1) / 2;                                   // input pairs (an odd I is padded with a zero weight)
@@ -2294,21 +2327,25 @@ __device__ __attribute__((noinline, aligned(256))) float sgd_sweep_wide(const fl
     const int hl = act ? t : 0;
     const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
     const float clr = C * lr;
-    f32x2 w1[IP];
-    float w2[O], cl[O];
+    f32x2 w1[NE][IP];
+    float w2[NE][O], cl[NE][O], nb1[NE];
 #pragma unroll
-    for (int i = 0; i < IP; ++i) {
-        w1[i][0] = act ? C * w_in[(2 * i) * H + hl] : 0.0f;
-        w1[i][1] = (act && 2 * i + 1 < I) ? C * w_in[(2 * i + 1) * H + hl] : 0.0f;
+    for (int e = 0; e < NE; ++e) {
+        const float* wi = w_in[e];
+#pragma unroll
+        for (int i = 0; i < IP; ++i) {
+            w1[e][i][0] = act ? C * wi[(2 * i) * H + hl] : 0.0f;
+            w1[e][i][1] = (act && 2 * i + 1 < I) ? C * wi[(2 * i + 1) * H + hl] : 0.0f;
+        }
+#pragma unroll
+        for (int o = 0; o < O; ++o) w2[e][o] = act ? C * wi[oW2 + hl * O + o] : 0.0f;
+        nb1[e] = act ? -C * wi[oB1 + hl] : 1.0e30f;                   // -B1'; inactive threads: exponent +1e30 -> hid == 0 exactly
+#pragma unroll
+        for (int o = 0; o < O; ++o) cl[e][o] = -C * wi[oB2 + o];      // replicated in every thread, updated identically
     }
-#pragma unroll
-    for (int o = 0; o < O; ++o) w2[o] = act ? C * w_in[oW2 + hl * O + o] : 0.0f;
-    float nb1 = act ? -C * w_in[oB1 + hl] : 1.0e30f;                  // -B1'; inactive threads: exponent +1e30 -> hid == 0 exactly
-#pragma unroll
-    for (int o = 0; o < O; ++o) cl[o] = -C * w_in[oB2 + o];          // replicated in every thread, updated identically
     int par = 0;
     static_assert(MAX_WAVES == 8, "the partial sums are read as two float4");
-    for (int e = t; e < 2 * MAX_WAVES * OP; e += blockDim.x) part[e] = 0.0f;
+    for (int e = t; e < 2 * NE * MAX_WAVES * OP; e += blockDim.x) part[e] = 0.0f;
     __syncthreads();
     // rows through the scalar cache: the address is wave-uniform and the image is never written while a kernel runs
     // (a device function receives its arguments in VGPRs: the address is made scalar by hand, or the loads would be vector loads)
@@ -2325,12 +2362,12 @@ __device__ __attribute__((noinline, aligned(256))) float sgd_sweep_wide(const fl
 #pragma unroll
         for (int i = 0; i < IP; ++i) { x[i][0] = row[2 * i]; x[i][1] = row[2 * i + 1]; }
     };
-    auto zpart = [&](const f32x2 (&x)[IP]) {                          // x . W1 - B1 with the weights as they are now
-        f32x2 a0 = {nb1, 0.0f}, a1 = {0.0f, 0.0f};
+    auto zpart = [&](const f32x2 (&x)[IP], int e) {                   // x . W1 - B1 with the weights as they are now
+        f32x2 a0 = {nb1[e], 0.0f}, a1 = {0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < IP; i += 2) {
-            a0 = __builtin_elementwise_fma(x[i], w1[i], a0);
-            if (i + 1 < IP) a1 = __builtin_elementwise_fma(x[i + 1], w1[i + 1], a1);
+            a0 = __builtin_elementwise_fma(x[i], w1[e][i], a0);
+            if (i + 1 < IP) a1 = __builtin_elementwise_fma(x[i + 1], w1[e][i + 1], a1);
         }
         const f32x2 s_ = a0 + a1;
         return s_[0] + s_[1];
@@ -2341,8 +2378,9 @@ __device__ __attribute__((noinline, aligned(256))) float sgd_sweep_wide(const fl
     // that has to wait for them, because the LDS traffic of the reduction shares the scalar loads' counter (lgkmcnt).
     f32x2 xu[IP], xz[IP];
     load_row(0, xz);
-    float lhd_p = 0.0f;                                               // lhd of the previous row: its update is still pending
-    float zp = zpart(xz);
+    float lhd_p[NE], zp[NE];                                          // lhd of the previous row: its update is still pending
+#pragma unroll
+    for (int e = 0; e < NE; ++e) { lhd_p[e] = 0.0f; zp[e] = zpart(xz, e); }
     load_row(0, xu);
     load_row(1, xz);
     // the row loop is one latency-bound dependent chain with three synchronisation points per row: where its head falls in an
@@ -2351,86 +2389,146 @@ __device__ __attribute__((noinline, aligned(256))) float sgd_sweep_wide(const fl
     for (int n = 0; n < ntr; ++n) {
         const cfloat* row = cdata + (size_t)n * ipy;
         const float yn = row[I], dn = row[I + 1];
-        const float z = fmaf(lhd_p, dn, zp);                          // + lhd[n-1] (1 + x[n] . x[n-1])   (row 0: lhd_p == 0)
-        const float e = __builtin_amdgcn_exp2f(z);
+        float hid[NE], ldh[NE];
+        lfloat* mypart = lpart + par * NE * MAX_WAVES * OP;           // [epoch][o][wave]: the partials of one output are contiguous
+        // stage by stage over the epochs (NE = 2): the wave issues in order, so the second epoch's instruction of a stage fills the
+        // latency of the first one's -- for NE = 1 this is the plain sequence
+        float ex[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const float z = fmaf(lhd_p[e], dn, zp[e]);                // + lhd[n-1] (1 + x[n] . x[n-1])   (row 0: lhd_p == 0)
+            ex[e] = __builtin_amdgcn_exp2f(z);
+        }
         // off the chain: apply the update of row n-1 (xu; a no-op for n = 0, where lhd_p = 0), then start row n+1 (xz) from the
         // updated weights; two zero rows follow the image, so the look-ahead never leaves it
-        {
-            const f32x2 l2 = {lhd_p, lhd_p};
 #pragma unroll
-            for (int i = 0; i < IP; ++i) w1[i] = __builtin_elementwise_fma(l2, xu[i], w1[i]);
-            if constexpr (I & 1) w1[IP - 1][1] = 0.0f;                // the pad weight of an odd input count stays zero
-            nb1 += lhd_p;
+        for (int e = 0; e < NE; ++e) {
+            const f32x2 l2 = {lhd_p[e], lhd_p[e]};
+#pragma unroll
+            for (int i = 0; i < IP; ++i) w1[e][i] = __builtin_elementwise_fma(l2, xu[i], w1[e][i]);
+            if constexpr (I & 1) w1[e][IP - 1][1] = 0.0f;             // the pad weight of an odd input count stays zero
+            nb1[e] += lhd_p[e];
         }
-        zp = zpart(xz);
-        const float hid = __builtin_amdgcn_rcpf(1.0f + e);
-        const float ldh = lr * fmaf(-hid, hid, hid);
-        lfloat* mypart = lpart + par * MAX_WAVES * OP;                // [o][wave]: the partials of one output are contiguous
 #pragma unroll
-        for (int o = 0; o < O; ++o) {
-            const float s_ = wave_allsum(hid * w2[o]);
-            if (lane == 0) mypart[o * MAX_WAVES + wave] = s_;
+        for (int e = 0; e < NE; ++e) zp[e] = zpart(xz, e);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) hid[e] = __builtin_amdgcn_rcpf(1.0f + ex[e]);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) ldh[e] = lr * fmaf(-hid[e], hid[e], hid[e]);
+        {
+            float sums[NE * O];
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+#pragma unroll
+                for (int o = 0; o < O; ++o) sums[e * O + o] = hid[e] * w2[e][o];
+            wave_allsum_n<NE * O>(sums);
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < NE * O; ++q) mypart[q * MAX_WAVES + wave] = sums[q];
+            }
         }
         __syncthreads();
         // the partials first, THEN the scalar loads: a wait for the LDS reads is a wait for everything on lgkmcnt
-        float4 pa[O], pb[O];
+        float4 pa[NE][O], pb[NE][O];
 #pragma unroll
-        for (int o = 0; o < O; ++o) {
-            const volatile lfloat* pq = mypart + o * MAX_WAVES;       // volatile: the reads stay above the wait below
-            pa[o] = make_float4(pq[0], pq[1], pq[2], pq[3]);
-            pb[o] = make_float4(pq[4], pq[5], pq[6], pq[7]);
-        }
+        for (int e = 0; e < NE; ++e)
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                const volatile lfloat* pq = mypart + (e * O + o) * MAX_WAVES;   // volatile: the reads stay above the wait below
+                pa[e][o] = make_float4(pq[0], pq[1], pq[2], pq[3]);
+                pb[e][o] = make_float4(pq[4], pq[5], pq[6], pq[7]);
+            }
         __builtin_amdgcn_s_waitcnt(0xC07F);                          // lgkmcnt(0): the partials are here
         __builtin_amdgcn_sched_barrier(0);
         load_row(n, xu);                                              // pending update of the next iteration
         load_row(n + 2, xz);                                          // pre-activation started in the next iteration
         __builtin_amdgcn_sched_barrier(0);
-        float g = 0.0f;
-        float lod[O];
+        float zo[NE][O], eo[NE][O], out[NE][O];
 #pragma unroll
-        for (int o = 0; o < O; ++o) {
-            // all MAX_WAVES partials (entries of absent waves are zero), summed in a fixed order
-            const float zo = cl[o] + (((pa[o].x + pa[o].y) + (pa[o].z + pa[o].w)) + ((pb[o].x + pb[o].y) + (pb[o].z + pb[o].w)));
-            const float out = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zo));
-            float tt;
-            if (TASK == TASK_CLS) tt = ((int)yn == o) ? 1.0f : 0.0f;
-            else tt = yn;
-            const float od = (tt - out) * fmaf(-out, out, out);
-            g = fmaf(od, w2[o], g);                                   // pre-update W2 (Q4)
-            lod[o] = clr * od;
-        }
-        lhd_p = g * ldh;
+        for (int e = 0; e < NE; ++e)
 #pragma unroll
-        for (int o = 0; o < O; ++o) {
-            w2[o] = fmaf(lod[o], hid, w2[o]);
-            cl[o] += lod[o];
+            for (int o = 0; o < O; ++o)       // all MAX_WAVES partials (entries of absent waves are zero), summed in a fixed order
+                zo[e][o] = cl[e][o] + (((pa[e][o].x + pa[e][o].y) + (pa[e][o].z + pa[e][o].w)) + ((pb[e][o].x + pb[e][o].y) + (pb[e][o].z + pb[e][o].w)));
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+#pragma unroll
+            for (int o = 0; o < O; ++o) eo[e][o] = __builtin_amdgcn_exp2f(zo[e][o]);
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+#pragma unroll
+            for (int o = 0; o < O; ++o) out[e][o] = __builtin_amdgcn_rcpf(1.0f + eo[e][o]);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            float g = 0.0f;
+            float lod[O];
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                float tt;
+                if (TASK == TASK_CLS) tt = ((int)yn == o) ? 1.0f : 0.0f;
+                else tt = yn;
+                const float od = (tt - out[e][o]) * fmaf(-out[e][o], out[e][o], out[e][o]);
+                g = fmaf(od, w2[e][o], g);                            // pre-update W2 (Q4)
+                lod[o] = clr * od;
+            }
+            lhd_p[e] = g * ldh[e];
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                w2[e][o] = fmaf(lod[o], hid[e], w2[e][o]);
+                cl[e][o] += lod[o];
+            }
         }
         par ^= 1;
     }
-    if (ntr > 0) {                                                    // the update of the last row is still pending (xu = row ntr-1)
-        const f32x2 l2 = {lhd_p, lhd_p};
 #pragma unroll
-        for (int i = 0; i < IP; ++i) w1[i] = __builtin_elementwise_fma(l2, xu[i], w1[i]);
-        nb1 += lhd_p;
-    }
-    float d1 = 0.0f;
-    auto put = [&](int idx, float v) {
-        w_out[idx] = v;
-        if (w_ref) { const float d = w_ref[idx] - v; d1 = fmaf(d, d, d1); }
-    };
-    if (act) {
+    for (int e = 0; e < NE; ++e) {
+        if (ntr > 0) {                                                // the update of the last row is still pending (xu = row ntr-1)
+            const f32x2 l2 = {lhd_p[e], lhd_p[e]};
 #pragma unroll
-        for (int i = 0; i < I; ++i) put(i * H + t, IC * w1[i >> 1][i & 1]);
+            for (int i = 0; i < IP; ++i) w1[e][i] = __builtin_elementwise_fma(l2, xu[i], w1[e][i]);
+            nb1[e] += lhd_p[e];
+        }
+        float d1 = 0.0f;
+        float* wo = w_out[e];
+        auto put = [&](int idx, float v) {
+            wo[idx] = v;
+            if (w_ref) { const float d = w_ref[idx] - v; d1 = fmaf(d, d, d1); }
+        };
+        if (act) {
 #pragma unroll
-        for (int o = 0; o < O; ++o) put(oW2 + t * O + o, IC * w2[o]);
-        put(oB1 + t, -IC * nb1);
-    }
-    if (t == 0) {
+            for (int i = 0; i < I; ++i) put(i * H + t, IC * w1[e][i >> 1][i & 1]);
 #pragma unroll
-        for (int o = 0; o < O; ++o) put(oB2 + o, -IC * cl[o]);
+            for (int o = 0; o < O; ++o) put(oW2 + t * O + o, IC * w2[e][o]);
+            put(oB1 + t, -IC * nb1[e]);
+        }
+        if (t == 0) {
+#pragma unroll
+            for (int o = 0; o < O; ++o) put(oB2 + o, -IC * cl[e][o]);
+        }
+        d1_out[e] = d1;
     }
     __syncthreads();
-    return d1;
+}
+
+template <int TASK, int I, int O>
+__device__ __attribute__((noinline, aligned(256))) float sgd_sweep_wide(const float* __restrict__ w_in, float* __restrict__ w_out,
+                                                          const float* __restrict__ data, int IPY, int Ntr, int H, float lr,
+                                                          float* __restrict__ part, const float* w_ref = nullptr) {
+    const float* const wi[1] = {w_in};
+    float* const wo[1] = {w_out};
+    float d1[1];
+    sgd_sweep_wide_n<TASK, I, O, 1>(wi, wo, data, IPY, Ntr, H, lr, part, w_ref, d1);
+    return d1[0];
+}
+// the pair: epoch A from w_inA (the proposal in LDS), epoch B from w_inB (a proposal parked in global memory)
+template <int TASK, int I, int O>
+__device__ __attribute__((noinline, aligned(256))) void sgd_sweep_wide_pair(const float* w_inA, const float* w_inB, float* w_outA, float* w_outB,
+                                                                              const float* __restrict__ data, int IPY, int Ntr, int H, float lr,
+                                                                              float* __restrict__ part, const float* w_ref, float* d1_ab) {
+    const float* const wi[2] = {w_inA, w_inB};
+    float* const wo[2] = {w_outA, w_outB};
+    float d1[2];
+    sgd_sweep_wide_n<TASK, I, O, 2>(wi, wo, data, IPY, Ntr, H, lr, part, w_ref, d1);
+    d1_ab[0] = d1[0]; d1_ab[1] = d1[1];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2634,7 +2732,7 @@ __device__ __forceinline__ void segment_wide_body(const SegParams& p, const SegD
     float* wc = fw + wide_img_floats(H, p.FWS, PS);             // RES: the current state (w, eta)
     float* red = wc + (RES ? PS : 0);
     float* part = red + MAX_WAVES * 8;
-    float* scal = part + 2 * MAX_WAVES * OP;                    // 16 floats: staging of an accepted foreign record; then per window slot:
+    float* scal = part + 4 * MAX_WAVES * OP;                    // 16 floats: staging of an accepted foreign record; then per window slot:
     float* s_u = scal + 16;                                     // the step's uniform
     float* s_ne = s_u + WIDE_WINDOW;                            // its eta noise
     float* s_lg = s_ne + WIDE_WINDOW;                           // its Langevin coin (0 / 1)
@@ -2990,7 +3088,7 @@ __global__ void __launch_bounds__(MAX_THREADS) model_wide_kernel(const SegParams
     float* fw = smem;
     float* red = fw + wide_img_floats(p.H, p.FWS, p.PS);
     float* part = red + MAX_WAVES * 8;
-    float* scal = part + 2 * MAX_WAVES * OP;
+    float* scal = part + 4 * MAX_WAVES * OP;
     if (mode == 2) {
         tape_step(p, a0, a1, out, scal);                  // noise straight to the output buffer (16-byte aligned)
         __syncthreads();
@@ -3000,6 +3098,23 @@ __global__ void __launch_bounds__(MAX_THREADS) model_wide_kernel(const SegParams
     const float* w = w_in + (size_t)b * p.P;
     if (mode == 1) {
         sgd_sweep_wide<TASK, I, O>(w, out + (size_t)b * p.P, p.data, p.IPY, p.Ntr, p.H, p.lr, part);
+        return;
+    }
+    if (mode == 3) {
+        // timing of the epoch (constant-rate counter): a0 single epochs, then a0 PAIRS through one row loop; out = ticks of each
+        // (ptnn_time_sgd_epoch for wide nets; results go to p.wide_scratch rows, which no chain uses while this runs)
+        float* oa = p.wide_scratch;
+        float* ob = p.wide_scratch + p.PS;
+        unsigned long long t0 = wall_clock64();
+        for (int rep = 0; rep < a0; ++rep) sgd_sweep_wide<TASK, I, O>(w, oa, p.data, p.IPY, p.Ntr, p.H, p.lr, part);
+        const unsigned long long t1 = wall_clock64();
+        float dd[2];
+        for (int rep = 0; rep < a0; ++rep) sgd_sweep_wide_pair<TASK, I, O>(w, w, oa, ob, p.data, p.IPY, p.Ntr, p.H, p.lr, part, nullptr, dd);
+        const unsigned long long t2 = wall_clock64();
+        if (tid == 0) {
+            out[0] = __uint_as_float((unsigned)((t1 - t0) & 0xffffffffull)); out[1] = __uint_as_float((unsigned)((t1 - t0) >> 32));
+            out[2] = __uint_as_float((unsigned)((t2 - t1) & 0xffffffffull)); out[3] = __uint_as_float((unsigned)((t2 - t1) >> 32));
+        }
         return;
     }
     const EvalSums s = wide_forward<TASK, I, O>(p, w, fw, red);
