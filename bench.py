@@ -384,6 +384,33 @@ def main():
                                           "note": "shared_noise 1 = the reference's behaviour (its forked chains inherit one RNG state, "
                                                   "REG:709-712) and the drop-in's default; 0 = independent Philox streams per chain"}
             lad2.s.close()
+            # the whole drop-in call the reference's own figure is taken over (REG:1019-1022): run_chains() with the trace download
+            # over PCIe, the per-chain result files and show_results -- never `value` (which has its inputs and outputs in HBM)
+            try:
+                import shutil
+                import tempfile
+                from ptnn_amd.pt_timeseries_regression import ParallelTempering
+                tmp = tempfile.mkdtemp(prefix="ptnn_bench_")
+                pt = ParallelTempering(True, wl["lr"], train, test, list(wl["topo"]), R, wl["maxtemp"], R * S, si, 0.5, tmp, seed=SEED,
+                                       shared_noise=bool(a.shared_noise))
+                for sub in ("predictions", "posterior", "posterior/pos_w", "posterior/pos_likelihood", "posterior/accept_list"):
+                    pt.make_directory(os.path.join(tmp, sub))
+                pt.initialize_chains(0.5)
+                t3 = time.perf_counter()
+                pt.run_chains()
+                d3 = time.perf_counter() - t3
+                nbytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(tmp) for f in fs)
+                shutil.rmtree(tmp, ignore_errors=True)
+                tm = pt.timings
+                extras["end_to_end"] = {"run_chains_s": d3, "value": R * (S - 1) / d3, "unit": "samples/s",
+                                        "sampling_s": tm.get("sampling_s"), "trace_download_s": tm.get("fetch_s"),
+                                        "result_files_s": tm.get("chain_files_s"), "show_results_s": tm.get("show_results_s"),
+                                        "result_file_bytes": nbytes,
+                                        "pcie_inclusive_samples_per_s": R * (S - 1) / max((tm.get("sampling_s") or 0) + (tm.get("fetch_s") or 0), 1e-9),
+                                        "note": "the drop-in ParallelTempering(...).run_chains() of this workload, files included; reported, "
+                                                "never `value`"}
+            except Exception as e:                              # noqa: BLE001  (a full /tmp must not cost the bench line)
+                extras["end_to_end"] = {"error": repr(e)}
 
     if rank == 0:
         mh_steps = S - 1                                        # per replica and run
