@@ -309,23 +309,68 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("gloo")          # rendezvous only: unique id, barrier, max of the times
-        device = 0 if a.transport == "host" else local_rank
+        ngpu = torch.cuda.device_count()         # counting devices does not initialise the GPU
+        device = local_rank % max(ngpu, 1)       # a one-GPU box rehearsing N ranks puts them all on GPU 0
         torch.cuda.set_device(device)
     else:
+        ngpu = 1
         device = local_rank
-    # the host-transport rehearsal puts every rank on GPU 0: libptnn then keeps to schedules whose work-groups never wait for each other
-    lad = Ladder(wl, a, train, test, rank, N, device, shared_device=int(sharded and a.transport == "host" and N > 1))
+    # ranks that share a GPU: libptnn then keeps to schedules whose work-groups never wait for each other
+    shared_dev = int(sharded and N > max(ngpu, 1))
+    lad = Ladder(wl, a, train, test, rank, N, device, shared_device=shared_dev)
     s = lad.s
+    transport_used, transport_note = ("none", None)
     if sharded:
+        import torch
         from ptnn_amd import _lib
+        from ptnn_amd import distributed as dm
+        mode = {"auto": 0, "gather": 1, "boundary": 2}[a.exchange]
+
+        def all_ok(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+
+        transport_used = a.transport
         if a.transport == "rccl":
-            uid = [_lib.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            s.comm_init(uid[0], rank, N)
-        else:
-            from ptnn_amd import distributed as dm
+            # RCCL inside libptnn has never run on more than one GPU (no multi-GPU box was ever available to the build): every stage
+            # is bounded (PTNN_COMM_TIMEOUT_S) and agreed on by all ranks, and a bring-up or first-run failure anywhere moves
+            # EVERY rank to the host-staged transport -- the line then says so and is a degraded figure, not an RCCL measurement.
+            why = None
+            box = [None, None]
+            if rank == 0:
+                try:
+                    box[0] = _lib.comm_unique_id()
+                except Exception as e:                          # noqa: BLE001
+                    box[1] = f"rank 0 ncclGetUniqueId: {e!r}"
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is None:
+                why = box[1]
+            else:
+                err = None
+                try:
+                    s.comm_init(box[0], rank, N)
+                    s.comm_set_mode(mode)
+                    lad.whole_run()                             # preflight: the first collectives of this communicator, untimed
+                except Exception as e:                          # noqa: BLE001
+                    err = f"rank {rank}: {e!r} (last stage: {_lib.comm_last_stage()})"
+                if not all_ok(err is None):
+                    errs = [None] * N
+                    dist.all_gather_object(errs, err)
+                    why = "; ".join(x for x in errs if x) or "a peer failed"
+            if why is not None:
+                if rank == 0:
+                    print(f"[bench] RCCL path failed, every rank falls back to the host-staged transport: {why}", file=sys.stderr, flush=True)
+                try:
+                    s.close()
+                except Exception:                               # noqa: BLE001
+                    pass
+                lad = Ladder(wl, a, train, test, rank, N, device, shared_device=shared_dev)
+                s = lad.s
+                transport_used, transport_note = "host", "fallback after an RCCL failure: " + why[:600]
+        if transport_used == "host":
             s.comm_init_host(rank, N, *dm.gloo_transport(dist))
-        s.comm_set_mode({"auto": 0, "gather": 1, "boundary": 2}[a.exchange])
+            s.comm_set_mode(mode)
 
     def fence():
         if dist is not None:
@@ -466,7 +511,7 @@ def main():
                        "schedule": info["schedule"],
                        "slots_per_round": info["slots_per_round"], "groups_per_replica": info["groups_per_replica"],
                        "block_threads": info["block_threads"], "lds_bytes": info["lds_bytes"], "exchange": info.get("exchange", "none"),
-                       "transport": a.transport if sharded else "none"},
+                       "transport": transport_used, **({"transport_note": transport_note} if transport_note else {})},
             "swap_accept_pct": 100.0 * nsw / max(tot, 1), "swap_rounds_per_run": rounds,
             "mh_accept_pct": float(100.0 * np.mean(st["num_accepted"]) / max(S - 1, 1)),
             "roofline": roof,
