@@ -528,6 +528,12 @@ def main():
         dist.barrier()
         s.close()
         dist.destroy_process_group()
+        if transport_note:
+            # an RCCL whose bring-up was abandoned can leave threads behind that keep the interpreter from exiting (seen on the test
+            # box: ncclGetUniqueId in a process that never completes an ncclCommInitRank); the line is out, leave without teardown
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
     else:
         s.close()
 

@@ -988,6 +988,9 @@ static int comm_check_partition(ptnn_handle* h, int rank, int nranks) {
 
 int ptnn_comm_unique_id(void* id_out, int nbytes) {
     if (!id_out || nbytes < (int)sizeof(ncclUniqueId)) return fail(-1, "the unique id needs a buffer of %d bytes", (int)sizeof(ncclUniqueId));
+    // fault injection for the fall-back tests ($PTNN_COMM_FAULT=ncclGetUniqueId): fails before RCCL is loaded
+    if (const char* f = std::getenv("PTNN_COMM_FAULT"))
+        if (std::strstr(f, "ncclGetUniqueId")) return fail(-7, "ncclGetUniqueId failed: injected by $PTNN_COMM_FAULT");
     std::string why;
     const RcclApi* api = rccl_api(why);
     if (!api) return fail(-7, "cannot load RCCL: %s", why.c_str());
@@ -1012,6 +1015,10 @@ int ptnn_comm_init(ptnn_handle* h, const void* unique_id, int nbytes, int rank, 
     std::string why;
     const RcclApi* api = rccl_api(why);
     if (!api) return fail(-7, "cannot load RCCL: %s", why.c_str());
+    // fault injection for the fall-back tests ($PTNN_COMM_FAULT=ncclCommInitRank): fails where a refused bring-up would, RCCL not called
+    if (const char* f = std::getenv("PTNN_COMM_FAULT"))
+        if (std::strstr(f, "ncclCommInitRank"))
+            return fail(-7, "ncclCommInitRank(rank %d of %d, device %d) failed: injected by $PTNN_COMM_FAULT", rank, nranks, h->cfg.device_id);
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     // ncclCommInitRank is a collective: it returns when all nranks have joined.  A peer that never does (it failed before, or was
     // never started) would block this thread for ever, so the call runs on a helper that is abandoned after comm_timeout_s().

@@ -17,6 +17,7 @@ This module holds what the Python host needs around that:
 One process per GPU (bench.py under torch.distributed.run) needs none of it: each rank builds its `_lib.Sampler`, calls
 `comm_init(unique_id, rank, nranks)` and `run()`.
 """
+import os
 import queue
 import struct
 import threading
@@ -120,18 +121,25 @@ class LadderGroup:
     """The handles of one ladder cut into len(devices) equal contiguous blocks, driven by one host thread each.  Offers the
     part of the `_lib.Sampler` interface `ParallelTempering` uses, over the whole ladder."""
 
-    def __init__(self, devices, exchange=_lib.XCHG_AUTO, transport=None, **config):
+    def __init__(self, devices, exchange=_lib.XCHG_AUTO, transport=None, fallback=None, **config):
         self.devices = [int(d) for d in devices]
         n = len(self.devices)
         R = int(config["n_replicas_global"])
         if n < 1 or R % n != 0:
             raise ValueError(f"{R} replicas cannot be cut into {n} equal blocks (one per device)")
         self.n, self.R, self.Rl = n, R, R // n
-        if transport is None:
-            transport = "rccl" if len(set(self.devices)) == n else "host"       # RCCL refuses two ranks on one device
+        distinct = len(set(self.devices)) == n
+        if fallback is None:
+            fallback = transport in (None, "auto")           # an RCCL the caller asked for by name fails loudly
+        if transport in (None, "auto"):
+            transport = "rccl" if distinct else "host"
         if transport not in ("rccl", "host"):
-            raise ValueError("transport must be 'rccl' or 'host'")
+            raise ValueError("transport must be None, 'auto', 'rccl' or 'host'")
+        if transport == "rccl" and not distinct and not os.environ.get("PTNN_COMM_FAULT"):
+            # never attempted: two ranks of ONE process initialising RCCL on one device did not come back on the test box
+            raise ValueError("RCCL needs one distinct device per block; use transport='host' to rehearse on one GPU")
         self.transport = transport
+        self.transport_note = None
         self._pool = ThreadPoolExecutor(max_workers=n)
         self.shards = [None] * n
         self._tt = None                                      # ThreadTransport of a host-staged group
@@ -151,9 +159,25 @@ class LadderGroup:
                 # ncclCommInitRank is a collective: all threads at once, all with the same id.  libptnn bounds it (a rank that
                 # fails before joining makes the others return error -7 after $PTNN_COMM_TIMEOUT_S instead of blocking), and
                 # _each() collects every thread before the first error is raised.
-                uid = _lib.comm_unique_id()
-                self._each(lambda k: self.shards[k].comm_init(uid, k, n))
-            else:
+                # RCCL has never run on more than one GPU here: with `fallback` a failed bring-up (every stage bounded) moves the
+                # whole group to the host-staged transport, with a warning and `transport_note`, instead of ending the run.
+                try:
+                    uid = _lib.comm_unique_id()
+                    self._each(lambda k: self.shards[k].comm_init(uid, k, n))
+                except _lib.PtnnError as e:
+                    if not fallback:
+                        raise
+                    import warnings
+                    self.transport_note = f"host-staged after an RCCL bring-up failure: {e} (last stage: {_lib.comm_last_stage()})"
+                    warnings.warn("LadderGroup: " + self.transport_note, RuntimeWarning, stacklevel=2)
+                    for sh in self.shards:                   # a block whose own bring-up had returned: drop its communicator
+                        try:
+                            sh.comm_finalize()
+                        except _lib.PtnnError:
+                            pass
+                    self.failed = False
+                    self.transport = transport = "host"
+            if transport == "host":
                 self._tt = ThreadTransport(n)
                 self._each(lambda k: self.shards[k].comm_init_host(k, n, *self._tt.callbacks(k)))
             self._each(lambda k: self.shards[k].comm_set_mode(exchange))

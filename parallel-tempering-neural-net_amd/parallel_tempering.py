@@ -82,7 +82,8 @@ class ParallelTemperingBase:
         # devices=[0, 1, ...]: the ladder is cut into len(devices) equal contiguous blocks, one per GPU; the swap rounds exchange
         # over RCCL inside libptnn (where the reference forks one process per chain and pipes every vector through the parent,
         # REG:694-771).  $PTNN_DEVICES="0,1,2,3" does the same for an unmodified driver script.  `exchange`: "auto", "gather"
-        # or "boundary" (include/ptnn.h); `transport`: None = RCCL when the devices are distinct, host-staged otherwise.
+        # or "boundary" (include/ptnn.h); `transport`: None = RCCL when the devices are distinct, host-staged otherwise;
+        # "auto" = try RCCL whatever the list; both fall back to host-staged (with a warning) when the RCCL bring-up fails; "rccl" / "host" = that one or an error.
         if devices is None and os.environ.get("PTNN_DEVICES"):
             devices = [int(v) for v in os.environ["PTNN_DEVICES"].split(",")]
         self.devices = None if devices is None else [int(d) for d in devices]

@@ -195,6 +195,37 @@ def test_run_chains_on_a_sharded_ladder_equals_one_device(key, devices, exchange
             assert open(pa, "rb").read() == open(pa.replace(str(tmp_path / "a"), str(tmp_path / "b")), "rb").read(), f
 
 
+def test_failed_rccl_bring_up_falls_back_to_the_host_transport(tmp_path, monkeypatch):
+    """RCCL inside libptnn has never run on more than one GPU.  `transport=None / "auto"` try it, and a bring-up that fails (here
+    injected by $PTNN_COMM_FAULT before RCCL is loaded: the box has one GPU, RCCL is never asked to put two ranks of one process
+    on one device, and an ncclGetUniqueId that no ncclCommInitRank follows keeps the process from exiting) moves the whole group to the host-staged transport with a warning; the run equals the one-device run.
+    `transport="rccl"` fails loudly instead, and without the injection a repeated device is refused before RCCL is touched."""
+    from ptnn_amd import _lib
+    for sub in "abcd":
+        os.makedirs(tmp_path / sub)
+    a = _run("reg", tmp_path / "a")
+    with pytest.raises(ValueError, match="one distinct device per block"):
+        _run("reg", tmp_path / "d", devices=[0, 0], exchange="boundary", transport="rccl")
+    monkeypatch.setenv("PTNN_COMM_FAULT", "ncclGetUniqueId,ncclCommInitRank")
+    with pytest.warns(RuntimeWarning, match="host-staged after an RCCL bring-up failure"):
+        from ptnn_amd import distributed
+        grp_probe = {}
+        orig = distributed.LadderGroup.__init__
+
+        def forced(self, devices, **kw):                    # the drop-in's "auto" on a repeated device picks host: force the RCCL attempt
+            kw["transport"], kw["fallback"] = "rccl", True
+            orig(self, devices, **kw)
+            grp_probe["g"] = self
+        monkeypatch.setattr(distributed.LadderGroup, "__init__", forced)
+        b = _run("reg", tmp_path / "b", devices=[0, 0], exchange="boundary")
+        monkeypatch.setattr(distributed.LadderGroup, "__init__", orig)
+    assert grp_probe["g"].transport == "host" and "ncclGetUniqueId" in grp_probe["g"].transport_note
+    for x, y in zip(a[2], b[2]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    with pytest.raises(_lib.PtnnError, match="ncclGetUniqueId"):
+        _run("reg", tmp_path / "c", devices=[0, 0], exchange="boundary", transport="rccl")
+
+
 def test_sharded_run_chains_checkpoint_and_resume(tmp_path):
     """Checkpoint / resume of a sharded ladder: one blob per block behind an index, resumed in a new object."""
     global _RUN_KW
