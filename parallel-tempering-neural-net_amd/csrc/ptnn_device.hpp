@@ -1143,6 +1143,13 @@ __host__ __device__ inline size_t mfma_coop_lds_floats(int I, int O, int H, int 
     return (size_t)I * Npad + (size_t)((H + 31) >> 5) * Npad * O;
 }
 
+#ifdef PTNN_STAMPS
+static __device__ unsigned long long fw_dbg[8];              // diagnostic build: cycles of the phases of eval_rows_mfma_coop (block 0, wave 0)
+#define FW_DBG(q_) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                        fw_dbg[q_] += t_ - fw_t; fw_t = t_; } } while (0)
+#else
+#define FW_DBG(q_) do { } while (0)
+#endif
 template <int TASK, int I, int O, bool LEAN = false>
 __device__ __forceinline__ EvalSums eval_rows_mfma_coop(const float* __restrict__ wl, const float* __restrict__ xt,
                                                         float* __restrict__ part, const float* __restrict__ xy, int IPY,
@@ -1153,6 +1160,9 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_coop(const float* __restrict_
     const int col = lane & 31, half = lane >> 5;
     const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
     const int ntiles = (H + 31) >> 5;
+#ifdef PTNN_STAMPS
+    unsigned long long fw_t = __builtin_amdgcn_s_memtime();
+#endif
     // phase 1: one unit = 32 data rows x 32 hidden units (11 row blocks x 2 tiles for Ionosphere).  With two tiles the waves
     // split between them, so a wave keeps ONE tile's operands -- the weights (A), biases and W2 rows of its 32 hidden units --
     // in registers for all of its row blocks, and only the data columns (B) change.  Up to three row blocks run at once:
@@ -1236,7 +1246,9 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_coop(const float* __restrict_
         if (rb + rbstride < nrb) { batch(std::integral_constant<int, 2>{}, rb); rb += 2 * rbstride; }
         if (rb < nrb) batch(std::integral_constant<int, 1>{}, rb);
     }
+    FW_DBG(0);                                                 // matrix products + epilogues of wave 0
     __syncthreads();
+    FW_DBG(1);                                                 // waiting for the other waves
     // phase 2: one lane per data row joins the tiles (ascending) and scores the row
     float a_tr = 0.f, b_tr = 0.f, c_tr = 0.f, a_te = 0.f, b_te = 0.f, c_te = 0.f;
     float b2[O];
@@ -1276,7 +1288,10 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_coop(const float* __restrict_
         if (n < Ntr) { a_tr += a; b_tr += bb; c_tr += c; }
         else { a_te += a; b_te += bb; c_te += c; }
     }
-    return reduce_eval<TASK, false, LEAN>(a_tr, b_tr, c_tr, a_te, b_te, c_te, red, extra);
+    FW_DBG(2);                                                 // scoring the rows
+    const EvalSums es_ = reduce_eval<TASK, false, LEAN>(a_tr, b_tr, c_tr, a_te, b_te, c_te, red, extra);
+    FW_DBG(3);                                                 // work-group reduction
+    return es_;
 }
 
 
@@ -1483,6 +1498,7 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& d
         for (int q_ = 0; q_ < 9; ++q_) atomicAdd(p.stamps + q_, stamp_acc[q_]);
         atomicAdd(p.stamps + 9, (unsigned long long)n_steps);
         atomicAdd(p.stamps + 10, __builtin_amdgcn_s_memtime() - stamp_t0);
+        if (tid == 0) for (int q_ = 0; q_ < 8; ++q_) { atomicAdd(p.stamps + 150 + q_, fw_dbg[q_]); fw_dbg[q_] = 0; }
     }
 #endif
 

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../.."
 T=${1:-0}; I=${2:-4}; O=${3:-1}
 C=parallel-tempering-neural-net_amd/csrc
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -DPTNN_STAMPS -DPTNN_SHAPES(X)=X($T,$I,$O)"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -DPTNN_STAMPS $EXTRA -DPTNN_SHAPES(X)=X($T,$I,$O)"
 /opt/rocm/bin/hipcc $F -c -o /tmp/ptnn_stamps_main.o $C/ptnn.hip
 /opt/rocm/bin/hipcc $F -DPTNN_T=$T -DPTNN_I=$I -DPTNN_O=$O -DPTNN_SHAPE_SYMBOL=ptnn_shape_${T}_${I}_${O} -c -o /tmp/ptnn_stamps_shape.o $C/ptnn_shape.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o profiles/tools/libptnn_stamps.so /tmp/ptnn_stamps_main.o /tmp/ptnn_stamps_shape.o

@@ -6,7 +6,7 @@ os.environ["PTNN_LIBRARY"] = os.environ.get("STAMPS_LIB", os.path.join(R, "profi
 sys.path.insert(0, R)
 import bench
 name = sys.argv[1] if len(sys.argv) > 1 else "iris16"
-a = argparse.Namespace(waves=int(sys.argv[2]) if len(sys.argv) > 2 else 0, schedule=1, groups=0, bf16=False)
+a = argparse.Namespace(waves=int(sys.argv[2]) if len(sys.argv) > 2 else 0, schedule=1, groups=0, bf16=False, shared_noise=1)
 wl = dict(bench.WORKLOADS[name])
 train, test, _ = bench.load_data(wl["data"])
 lad = bench.Ladder(wl, a, train, test, 0, 1, 0)
@@ -20,4 +20,8 @@ d = s.describe()
 print(f"{name} {d['kernel']} {d}: {dt*1e3:.2f} ms/run = {wl['R']*wl['S']/dt/1e6:.2f} M samples/s; replica 0 wave 0: {tot/max(steps,1):.0f} cycles per MH step")
 for n, v in zip(names, st[:7]):
     print(f"    {n:44s} {v/max(steps,1):9.0f} cyc/step  {100*v/tot:5.1f} %")
+fw = st[150:154]
+if sum(fw):
+    for n, v in zip(["matrix products + epilogues (wave 0)", "waiting for the other waves", "scoring the rows", "work-group reduction"], fw):
+        print(f"      forward: {n:38s} {v/max(steps,1):9.0f} cyc/step")
 s.close()
