@@ -61,8 +61,13 @@ typedef struct ptnn_config {
                                    * 1, 2 or 4 work-groups speculating over windows of steps (0 = auto: 4 or 2 where resident) */
     int32_t trace_capacity;       /* rows per replica kept on the device (ring); 0 = all n_samples rows.  With a smaller
                                    * value the caller drains with ptnn_get_traces at least every trace_capacity steps */
-    int32_t forward_bf16;         /* wide nets (n_hidden > 64, multiple of 32): 1 = forward-pass GEMM operands rounded to
-                                   * bf16 with fp32 accumulation (v_mfma_f32_32x32x16_bf16), 0 = exact fp32 MFMA */
+    int32_t forward_bf16;         /* forward pass on the matrix cores (cooperative schedule with 24 <= n_hidden <= 64; wide nets with
+                                   * n_hidden % 32 == 0).  0 (default) = fp32 accuracy: where the split images fit, every fp32 operand
+                                   * is split into three bf16 terms and the six leading partial products run on
+                                   * v_mfma_f32_32x32x16_bf16 (errors of the size of fp32 rounding; not bit-identical to the VALU
+                                   * schedules), else the exact v_mfma_f32_32x32x2_f32.  1 = operands ROUNDED to bf16 (wide nets only;
+                                   * the precision study of BASELINE config 5, changes 0.3 % of the decisions).  2 = always the exact
+                                   * fp32 instruction (k-ordered fma chains, bit-identical to the VALU schedules) */
     int32_t swap_rule;            /* 0 = the reference's cascade (REG:659-690, default); 1 = even/odd Metropolis exchange
                                    * min(1, exp((1/T_k - 1/T_k+1)(L_k+1 - L_k))) on untempered log-likelihoods, the moved state
                                    * brings its likelihood and prior along, no phantom round (not in the reference) */

@@ -87,7 +87,8 @@ struct ptnn_handle {
     float* d_wide_scratch = nullptr;
     float* d_xt = nullptr;          // transposed data image for the MFMA forward pass
     int Npad = 0;
-    bool fw_mfma = false;           // cooperative schedule: forward pass on the matrix cores (24 <= H <= 64, I >= 6)
+    int fw_mfma = 0;                // cooperative / tree schedule: forward pass on the matrix cores (24 <= H <= 64, I >= 6): 1 exact fp32, 2 split bf16 operands (cooperative only)
+    bool xy_global = false;         // split forward pass: no room for the row-major data image in LDS, its rare readers go to global memory
     int groups = 1;                 // work-groups (CUs) per replica in the speculative schedule
     int blocks_per_cu = 0;          // occupancy of the segment kernel as the runtime reports it (0 = not queried)
     unsigned epoch_base = 0;
@@ -156,7 +157,7 @@ struct ptnn_handle {
         p.L_handoff = d_L_handoff; p.L_final = d_L_final;
         p.L_raw = (cfg.swap_rule == 1) ? d_L_raw : nullptr; p.prior_post = d_prior_post;
         p.tr_pos_w = d_pos_w; p.tr_scal = d_scal; p.PW = PW;
-        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.xverdict = d_xverdict; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.noise_shared = cfg.shared_noise ? 1 : 0; p.pk_nred = pk_nred; p.xt = d_xt; p.Npad = Npad; p.fw_mfma = fw_mfma ? 1 : 0; p.forward_bf16 = cfg.forward_bf16; p.tree_ahead = tree_ahead ? 1 : 0; p.compact = compact ? 1 : 0;
+        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.xverdict = d_xverdict; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.noise_shared = cfg.shared_noise ? 1 : 0; p.pk_nred = pk_nred; p.xt = d_xt; p.Npad = Npad; p.fw_mfma = fw_mfma; p.xy_global = xy_global ? 1 : 0; p.forward_bf16 = cfg.forward_bf16 == 1 ? 1 : 0; p.tree_ahead = tree_ahead ? 1 : 0; p.compact = compact ? 1 : 0;
         // wide nets over several work-groups: a window of 8 steps lets the groups balance Langevin (5 units) against random-walk (1)
         // steps; random-walk-only runs have nothing to balance and a longer window only wastes what follows an accepted step
         p.wide_window = cfg.use_langevin ? 8 : groups;
@@ -569,7 +570,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         HIP_TRY(hipMalloc(&h->d_xt, xt.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(h->d_xt, xt.data(), xt.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    h->fw_mfma = false;
+    h->fw_mfma = 0; h->xy_global = false;
     if (H > WAVE) {
         // wide net: one thread per hidden unit, vectors in HBM, only the packed forward image + scratch in LDS
         // matrix-core layout (H a multiple of 32): the state vector joins the proposal in LDS when both fit (ceilings just below
@@ -746,9 +747,23 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         h->seg_lds = seg_lds;
         // a hidden layer that fills most of a 32-unit tile and at least three k-steps: forward pass on the matrix cores
         // (the VALU pass re-reads the weights from LDS with broadcast reads and is bound by the LDS pipe at this size)
-        const size_t extra = mfma_coop_lds_floats(I, h->cfg.n_out, H, h->Npad) * sizeof(float);
-        h->fw_mfma = (H >= 24 && I >= 6 && seg_lds + extra <= LDS_MAX);
+        const size_t extra = (mfma_coop_lds_floats(I, h->cfg.n_out, H, h->Npad) + 4) * sizeof(float);
+        h->fw_mfma = (H >= 24 && I >= 6 && seg_lds + extra <= LDS_MAX) ? 1 : 0;
         if (h->fw_mfma) h->seg_lds = seg_lds + extra;
+        // Split bf16 operands (ptnn_device.hpp, SplitK): the default where the matrix cores are used, unless the caller asked for
+        // the exact fp32 instruction (forward_bf16 = 2: bit-identical to the VALU schedules) or the images do not fit.  They take
+        // more LDS than the transposed fp32 image; a random-walk launch may give up the row-major data image for them (its only
+        // readers left are the chain start and the SGD epochs of a Langevin launch, which therefore keeps it).
+        const char* fs = std::getenv("PTNN_FW_SPLIT");
+        if (h->fw_mfma && h->shape->split_ch > 0 && h->cfg.forward_bf16 != 2 && !(fs && fs[0] == '0')) {
+            const int CH = h->shape->split_ch, KR = h->shape->split_kr, Hpad = ((H + 31) >> 5) << 5;
+            const size_t sfl = (size_t)3 * h->Npad * CH * 4 + (size_t)2 * KR * h->Npad + (size_t)h->Npad + (size_t)3 * Hpad * CH * 4 +
+                               (size_t)(Hpad >> 5) * h->Npad * h->cfg.n_out + 4;
+            const size_t with_xy = seg_lds + sfl * sizeof(float);
+            const size_t without_xy = lds_floats(Nall, IPY, h->PS, H, h->FWS, h->cfg.use_langevin != 0, false) * sizeof(float) + sfl * sizeof(float);
+            if (with_xy <= LDS_MAX) { h->fw_mfma = 2; h->xy_global = false; h->seg_lds = with_xy; }
+            else if (!h->cfg.use_langevin && without_xy <= LDS_MAX) { h->fw_mfma = 2; h->xy_global = true; h->seg_lds = without_xy; }
+        }
     }
     if (sched == PTNN_SCHED_TREE || (sched == PTNN_SCHED_COOPERATIVE && h->cfg.schedule == PTNN_SCHED_AUTO && h->cfg.task == PTNN_TASK_CLS &&
                                      !h->cfg.use_langevin && h->cfg.groups_per_replica == 0 && h->cfg.waves_per_replica == 0 &&
@@ -789,7 +804,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
             if (explicit_tree && want) break;
         }
         if (chosen) {
-            h->tree = true; h->speculative = false; h->groups = chosen; h->seg_lds = chosen_lds; h->fw_mfma = chosen_mfma;
+            h->tree = true; h->speculative = false; h->groups = chosen; h->seg_lds = chosen_lds; h->fw_mfma = chosen_mfma ? 1 : 0; h->xy_global = false;
             if (h->d_xslots) { HIP_TRY(hipFree(h->d_xslots)); h->d_xslots = nullptr; }
             const size_t ng = (size_t)Rl * 2 * (TREE_MAX_NODES + 1) * TREE_REC;
             HIP_TRY(hipMalloc(&h->d_xslots, ng * sizeof(unsigned long long)));
@@ -1583,7 +1598,7 @@ int ptnn_describe(ptnn_handle* h, char* buf, int nbytes) {
                                 kern, h->cfg.task, h->cfg.n_in, h->cfg.n_out,
                                 h->wide ? (h->groups > 1 ? "speculative-wide" : "cooperative-wide") : (h->tree ? "prefetching-tree" : (h->packed ? "packed-speculative" : (h->speculative ? "speculative" : "cooperative"))),
                                 grid, h->nthreads, h->seg_lds, h->groups, slots, h->num_cus, per_cu, fa.numRegs, (size_t)fa.localSizeBytes,
-                                (h->fw_mfma || (h->wide && h->cfg.n_hidden % 32 == 0)) ? 1 : 0,
+                                h->fw_mfma ? h->fw_mfma : ((h->wide && h->cfg.n_hidden % 32 == 0) ? 1 : 0),
                                 h->comm.kind == COMM_NONE ? "none" : (h->cfg.label_swap ? "labels" : (resolved_xchg_mode(h) == PTNN_XCHG_GATHER ? "gather" : "boundary")),
                                 h->wide_res ? 1 : 0, h->compact ? 1 : 0,
                                 (h->persistent && h->comm.kind == COMM_NONE) ? "one per ptnn_run (swap rounds inside)" : "one per swap interval");

@@ -60,7 +60,9 @@ struct SegParams {
     int Ntr, Nte, IPY, FWS;  // rows, data row stride (floats), packed forward row stride (floats)
     int pk_nred;             // packed schedule: log2 of the lane-group width (3: n_hidden <= 8, 4: n_hidden <= 16)
     int noise_shared;        // Q14: every replica reads the step tape of replica 0
-    int fw_mfma;             // cooperative schedule: forward pass on the matrix cores (host decides: 24 <= H <= 64, I >= 6)
+    int fw_mfma;             // cooperative schedule: forward pass on the matrix cores (host decides: 24 <= H <= 64, I >= 6): 1 exact fp32
+                             // instruction, 2 split bf16 operands (SplitK; cooperative kernel only)
+    int xy_global;           // split forward pass without room for the row-major data image in LDS: rows are read from p.data
     int S, switch_step, use_lg;
     int trace_cap;           // rows per replica in the trace rings
     int first_global;
@@ -1043,10 +1045,10 @@ struct Lds {
     float* red; float* scal;
 };
 // lg = false (a launch without Langevin proposals): the two cached SGD epochs are not carved at all
-__device__ __forceinline__ Lds carve(float* base, int Nall, int IPY, int PS, int H, int FWS, bool lg = true) {
+__device__ __forceinline__ Lds carve(float* base, int Nall, int IPY, int PS, int H, int FWS, bool lg = true, bool xy = true) {
     Lds l;
     float* q = base;
-    l.xy = q; q += (Nall + 2) * IPY;
+    l.xy = q; q += xy ? (Nall + 2) * IPY : 0;
     l.w_cur = q; q += PS;                                  // w_cur, w_prop, rec_w, w_gd, w_pgd in this order: the cooperative
     l.w_prop = q; q += PS;                                 // step loop rotates them by offset
     l.rec_w = q; q += PS;
@@ -1056,8 +1058,8 @@ __device__ __forceinline__ Lds carve(float* base, int Nall, int IPY, int PS, int
     l.red = q; q += MAX_WAVES * 8;
     return l;
 }
-__host__ __device__ inline size_t lds_floats(int Nall, int IPY, int PS, int H, int FWS, bool lg = true) {
-    return (size_t)(Nall + 2) * IPY + (lg ? 7 : 5) * (size_t)PS + fw_floats(H, FWS) + MAX_WAVES * 8 + 16;
+__host__ __device__ inline size_t lds_floats(int Nall, int IPY, int PS, int H, int FWS, bool lg = true, bool xy = true) {
+    return (xy ? (size_t)(Nall + 2) * IPY : 0) + (lg ? 7 : 5) * (size_t)PS + fw_floats(H, FWS) + MAX_WAVES * 8 + 16;
 }
 
 // random tape of one step: noise[0..P) and scal[0..2] = {lx, u, n_eta}
@@ -1141,6 +1143,109 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // output sums of every row
 __host__ __device__ inline size_t mfma_coop_lds_floats(int I, int O, int H, int Npad) {
     return (size_t)I * Npad + (size_t)((H + 31) >> 5) * Npad * O;
+}
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ short f32_to_bf16(float f) {            // round to nearest even; inputs are finite
+    const unsigned u = __builtin_bit_cast(unsigned, f);
+    return (short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split-operand forward pass (cooperative schedule, fw_mfma == 2).  Measured on gfx950 (profiles/r03_micro_mfma_valu_overlap.txt):
+// v_mfma_f32_32x32x2_f32 runs at the packed-fp32 VALU rate AND keeps the SIMD's vector issue to itself for its 64 cycles -- the
+// sigmoid / W2 epilogue cannot hide behind it, the two add up.  v_mfma_f32_32x32x16_bf16 covers 8 x the k extent in half the
+// cycles and holds the vector issue for 8 of its 32.  So every fp32 operand is split into three bf16 terms, x = hi + mid + lo
+// (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): 24 significant bits, the residual is below 2^-26 |x|), and a
+// product keeps the six terms down to 2^-24: hi hi, hi mid, mid hi, mid mid, hi lo, lo hi, accumulated in fp32 by the matrix
+// core, small terms first.  The k values a multiple of 16 leaves over (34 = 2 x 16 + 2) go through one exact fp32 instruction
+// per pair.  The result is a sum of the same products in another order with errors of the size of fp32 rounding: the same
+// accuracy against the float64 oracle as the exact pass, NOT bit-identical to the VALU pass (forward_bf16 = 2 keeps that one).
+// Data image: split once per launch into LDS, rows of 16 KB bf16 (k contiguous: one ds_read_b128 per operand and k-step), the
+// 16-byte chunks XOR-swizzled by the row so that 16 consecutive rows hit 16 different bank groups.  Weights: split once per
+// step by the pass that forms the proposal.
+// ------------------------------------------------------------------------------------------------
+template <int I> struct SplitK {
+    static constexpr int KB0 = I / 16, REM0 = I - 16 * KB0;
+    static constexpr bool PADLAST = REM0 >= 7;                 // a zero-padded bf16 k-step (6 instructions) beats >= 4 fp32 ones
+    static constexpr int KB = KB0 + (PADLAST ? 1 : 0);          // bf16 k-steps of 16
+    static constexpr int KBF = 16 * KB;                         // k extent they cover
+    static constexpr int REM = PADLAST ? 0 : REM0;              // k values left to the exact fp32 instruction
+    static constexpr int KR = (REM + 1) / 2;                    // its k-steps of 2
+    static constexpr int CH = 2 * KB;                           // 16-byte chunks per image row
+    static constexpr bool OK = (KB == 1 || KB == 2 || KB == 4);
+};
+// LDS floats of the split images: data {3 levels x Npad rows}, remainder columns (fp32, transposed), labels, weights
+// {3 levels x Hpad rows}, per-tile partial sums
+template <int I>
+__host__ __device__ inline size_t mfma_split_lds_floats(int O, int H, int Npad) {
+    typedef SplitK<I> K;
+    const int Hpad = ((H + 31) >> 5) << 5;
+    return (size_t)3 * Npad * K::CH * 4 + (size_t)2 * K::KR * Npad + (size_t)Npad + (size_t)3 * Hpad * K::CH * 4 + (size_t)(Hpad >> 5) * Npad * O;
+}
+struct SplitLds { uint4* xs; float* xr; float* ylab; uint4* as; float* part; };
+template <int I>
+__device__ __forceinline__ SplitLds carve_split(float* base, int O, int H, int Npad) {
+    typedef SplitK<I> K;
+    const int Hpad = ((H + 31) >> 5) << 5;
+    SplitLds l;
+    float* q = base;
+    l.xs = reinterpret_cast<uint4*>(q); q += (size_t)3 * Npad * K::CH * 4;
+    l.xr = q; q += (size_t)2 * K::KR * Npad;
+    l.ylab = q; q += Npad;
+    l.as = reinterpret_cast<uint4*>(q); q += (size_t)3 * Hpad * K::CH * 4;
+    l.part = q;
+    return l;
+}
+template <int CH> __device__ __forceinline__ int split_chunk(int row, int c) { return c ^ ((row / (16 / CH)) & (CH - 1)); }
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
+    h = (unsigned short)f32_to_bf16(x);
+    const float r1 = x - __builtin_bit_cast(float, h << 16);
+    m = (unsigned short)f32_to_bf16(r1);
+    const float r2 = r1 - __builtin_bit_cast(float, m << 16);
+    l = (unsigned short)f32_to_bf16(r2);
+}
+// image[level][row][k]: elements (row, k) and (row, k + 1), k even, of all three levels
+template <int CH>
+__device__ __forceinline__ void split_store_pair(uint4* img, int rows, int row, int k, float x0, float x1) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3(x0, h0, m0, l0);
+    split3(x1, h1, m1, l1);
+    unsigned* w = reinterpret_cast<unsigned*>(img);
+    const size_t at = ((size_t)row * CH + split_chunk<CH>(row, k >> 3)) * 4 + ((k & 7) >> 1);
+    const size_t lvl = (size_t)rows * CH * 4;
+    w[at] = h0 | (h1 << 16);
+    w[at + lvl] = m0 | (m1 << 16);
+    w[at + 2 * lvl] = l0 | (l1 << 16);
+}
+// once per launch: the data set (global, row-major with IPY floats per row) into the split image, the remainder columns and the labels
+template <int I>
+__device__ __forceinline__ void stage_split_data(const SplitLds& l, const float* __restrict__ data, int IPY, int Nall, int Npad) {
+    typedef SplitK<I> K;
+    for (int e = threadIdx.x; e < Npad * (K::KBF / 2); e += blockDim.x) {
+        const int n = e / (K::KBF / 2), k = 2 * (e - n * (K::KBF / 2));
+        const float x0 = (n < Nall && k < I) ? data[(size_t)n * IPY + k] : 0.0f;
+        const float x1 = (n < Nall && k + 1 < I) ? data[(size_t)n * IPY + k + 1] : 0.0f;
+        split_store_pair<K::CH>(l.xs, Npad, n, k, x0, x1);
+    }
+    for (int e = threadIdx.x; e < 2 * K::KR * Npad; e += blockDim.x) {
+        const int s2 = e / Npad, n = e - s2 * Npad, k = K::KBF + s2;
+        l.xr[e] = (n < Nall && k < I) ? data[(size_t)n * IPY + k] : 0.0f;
+    }
+    for (int n = threadIdx.x; n < Npad; n += blockDim.x) l.ylab[n] = (n < Nall) ? data[(size_t)n * IPY + I] : 0.0f;
+}
+// once per weight vector: W1 (k < 16 KB) into the split image; wval(idx) yields element idx of the flat vector
+template <int I, class F>
+__device__ __forceinline__ void split_weights(uint4* as, int H, F wval) {
+    typedef SplitK<I> K;
+    const int Hpad = ((H + 31) >> 5) << 5;
+    for (int e = threadIdx.x; e < Hpad * (K::KBF / 2); e += blockDim.x) {
+        const int kp = e / Hpad, hid = e - kp * Hpad, k = 2 * kp;      // consecutive threads: consecutive hidden units (w is [k][h])
+        const float x0 = (hid < H && k < I) ? wval(k * H + hid) : 0.0f;
+        const float x1 = (hid < H && k + 1 < I) ? wval((k + 1) * H + hid) : 0.0f;
+        split_store_pair<K::CH>(as, Hpad, hid, k, x0, x1);
+    }
 }
 
 #ifdef PTNN_STAMPS
@@ -1295,6 +1400,193 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_coop(const float* __restrict_
 }
 
 
+// The forward pass itself: same tiling, work split and epilogue as eval_rows_mfma_coop (one unit = 32 data rows x 32 hidden
+// units, a wave keeps one hidden tile's operands in registers for all its row blocks); per unit 6 KB bf16 matrix instructions
+// + KR exact fp32 ones on ONE accumulator (a dependent chain runs at the full pipe rate), software-pipelined against the VALU
+// epilogue of the previous row block (the bf16 instruction leaves the vector issue free for 24 of its 32 cycles).
+template <int TASK, int I, int O, bool LEAN = false>
+__device__ __forceinline__ EvalSums eval_rows_mfma_split(const float* __restrict__ wl, const SplitLds& sl, int H, int Ntr, int Nall,
+                                                         int Npad, float* __restrict__ red, float& extra) {
+    typedef SplitK<I> K;
+    constexpr int KB = K::KB, KR = K::KR, CH = K::CH;
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
+    const int ntiles = (H + 31) >> 5, Hpad = ntiles << 5;
+    float* __restrict__ part = sl.part;
+#ifdef PTNN_STAMPS
+    unsigned long long fw_t = __builtin_amdgcn_s_memtime();
+#endif
+    const int nrb = Npad >> 5;
+    const int tsplit = (ntiles == 2 && nw >= 2) ? 2 : 1;
+    const int t0 = (tsplit == 2) ? (wave & 1) : 0, tcount = (tsplit == 2) ? 1 : ntiles;
+    const int rb0 = (tsplit == 2) ? (wave >> 1) : wave, rbstride = nw / tsplit;
+    for (int tt = 0; tt < tcount; ++tt) {
+        const int t = t0 + tt;
+        const int hbase = t * 32;
+        // A: this lane's hidden unit, k = 16 s + 8 half .. + 7 of every level; the fp32 remainder straight from the flat vector
+        bf16x8 a_h[KB], a_m[KB], a_l[KB];
+        {
+            const int row = hbase + col;
+            const uint4* base = sl.as + (size_t)row * CH;
+#pragma unroll
+            for (int s_ = 0; s_ < KB; ++s_) {
+                const int c = split_chunk<CH>(row, 2 * s_ + half);
+                a_h[s_] = __builtin_bit_cast(bf16x8, base[c]);
+                a_m[s_] = __builtin_bit_cast(bf16x8, base[(size_t)Hpad * CH + c]);
+                a_l[s_] = __builtin_bit_cast(bf16x8, base[(size_t)2 * Hpad * CH + c]);
+            }
+        }
+        float a_r[KR > 0 ? KR : 1];
+#pragma unroll
+        for (int s_ = 0; s_ < KR; ++s_) {
+            const int k = K::KBF + 2 * s_ + half;
+            const float va = wl[min(k, I - 1) * H + min(hbase + col, H - 1)];
+            a_r[s_] = (k < I && hbase + col < H) ? va : 0.0f;
+        }
+        // bias and W2 rows of this lane's 16 hidden units (absent units: both zero: sigmoid(0) = 0.5 meets W2 = 0)
+        const int hq = hbase + 4 * half;
+        const float* pb1 = wl + oB1 + hq;
+        const float* pw2 = wl + oW2 + hq * O;
+        float b1r[16], w2r[16][O];
+#pragma unroll
+        for (int r_ = 0; r_ < 16; ++r_) {
+            const int dh = 8 * (r_ >> 2) + (r_ & 3);
+            const bool in = hq + dh < H;
+            const float bv = pb1[dh];
+            b1r[r_] = in ? bv : 0.0f;
+#pragma unroll
+            for (int o = 0; o < O; ++o) { const float v = pw2[dh * O + o]; w2r[r_][o] = in ? v : 0.0f; }
+        }
+        struct BFrag { bf16x8 h[KB], m[KB], l[KB]; float r[KR > 0 ? KR : 1]; };
+        auto load_b = [&](int rb, BFrag& b) {
+            const int row = rb * 32 + col;                              // this lane's data row (Npad covers the last block)
+            const uint4* base = sl.xs + (size_t)row * CH;
+#pragma unroll
+            for (int s_ = 0; s_ < KB; ++s_) {
+                const int c = split_chunk<CH>(row, 2 * s_ + half);
+                b.h[s_] = __builtin_bit_cast(bf16x8, base[c]);
+                b.m[s_] = __builtin_bit_cast(bf16x8, base[(size_t)Npad * CH + c]);
+                b.l[s_] = __builtin_bit_cast(bf16x8, base[(size_t)2 * Npad * CH + c]);
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < KR; ++s_) b.r[s_] = sl.xr[(size_t)(2 * s_ + half) * Npad + row];
+        };
+        auto chain = [&](const BFrag& b) {
+            f32x16 acc;
+#pragma unroll
+            for (int r_ = 0; r_ < 16; ++r_) acc[r_] = 0.0f;
+#pragma unroll
+            for (int s_ = 0; s_ < KB; ++s_) {                           // the 2^-16 terms
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l[s_], b.h[s_], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h[s_], b.l[s_], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m[s_], b.m[s_], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < KB; ++s_) {                           // the 2^-8 terms
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_m[s_], b.h[s_], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h[s_], b.m[s_], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < KB; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_h[s_], b.h[s_], acc, 0, 0, 0);
+#pragma unroll
+            for (int s_ = 0; s_ < KR; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_r[s_], b.r[s_], acc, 0, 0, 0);
+            return acc;
+        };
+        auto finish = [&](const f32x16& acc, int rb) {
+            const int n = rb * 32 + col;
+            float sum[O];
+#pragma unroll
+            for (int o = 0; o < O; ++o) sum[o] = 0.0f;
+#pragma unroll
+            for (int r_ = 0; r_ < 16; ++r_) {
+                const float hid = sigmoidf_fast(acc[r_] - b1r[r_]);
+#pragma unroll
+                for (int o = 0; o < O; ++o) sum[o] = fmaf(hid, w2r[r_][o], sum[o]);
+            }
+#pragma unroll
+            for (int o = 0; o < O; ++o) {                               // hidden units 4..7, 12..15, ... live in lanes 32..63
+                const unsigned uu = __builtin_bit_cast(unsigned, sum[o]);
+                auto r2 = __builtin_amdgcn_permlane32_swap(uu, uu, false, false);
+                const float tot = __builtin_bit_cast(float, (unsigned)r2[0]) + __builtin_bit_cast(float, (unsigned)r2[1]);
+                if (half == 0) part[((size_t)t * Npad + n) * O + o] = tot;
+            }
+        };
+        if (rb0 < nrb) {
+            BFrag bcur, bnxt;
+            load_b(rb0, bcur);
+            int rb = rb0, nx = rb0 + rbstride;
+            if (nx < nrb) load_b(nx, bnxt);
+            f32x16 acc = chain(bcur);
+            while (nx < nrb) {
+                bcur = bnxt;
+                const int nn = nx + rbstride;
+                if (nn < nrb) load_b(nn, bnxt);
+                const f32x16 acc2 = chain(bcur);
+                finish(acc, rb);
+                // one matrix instruction, then its share of the previous block's epilogue (16 elements x {4 VALU + 2
+                // transcendental + O fma} over 6 KB + KR instructions)
+#pragma unroll
+                for (int q_ = 0; q_ < 6 * KB + KR; ++q_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (16 * (4 + O) + 6 * KB + KR - 1) / (6 * KB + KR), 0);
+                    __builtin_amdgcn_sched_group_barrier(0x400, (32 + 6 * KB + KR - 1) / (6 * KB + KR), 0);
+                }
+                acc = acc2; rb = nx; nx = nn;
+            }
+            finish(acc, rb);
+        }
+    }
+    FW_DBG(0);
+    __syncthreads();
+    FW_DBG(1);
+    // phase 2: one lane per data row joins the tiles (ascending) and scores the row
+    float a_tr = 0.f, b_tr = 0.f, c_tr = 0.f, a_te = 0.f, b_te = 0.f, c_te = 0.f;
+    float b2[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) b2[o] = wl[oB2 + o];
+    for (int n = threadIdx.x; n < Nall; n += blockDim.x) {
+        float tot[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            float v = part[(size_t)n * O + o];
+            for (int t = 1; t < ntiles; ++t) v += part[((size_t)t * Npad + n) * O + o];
+            tot[o] = v - b2[o];
+        }
+        const float y = sl.ylab[n];
+        float a, bb = 0.f, c = 0.f;
+        if (TASK == TASK_REG) {
+            const float d = y - sigmoidf_fast(tot[0]);
+            a = d * d;
+        } else {
+            ArgKey best = argmax_key(tot[0]);
+            float se = 0.0f, oy = 0.0f;
+            int arg = 0;
+            const int yi = (int)y;
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                const float out = sigmoidf_fast(tot[o]);
+                const ArgKey key = argmax_key(tot[o]);
+                if (argkey_greater(key, best)) { best = key; arg = o; }
+                se += expf_fast(out);
+                oy = (o == yi) ? out : oy;
+            }
+            a = oy - logf_fast(se);
+            const float dd = (float)arg - y;
+            bb = dd * dd;
+            c = ((float)arg == y) ? 1.0f : 0.0f;
+        }
+        if (n < Ntr) { a_tr += a; b_tr += bb; c_tr += c; }
+        else { a_te += a; b_te += bb; c_te += c; }
+    }
+    FW_DBG(2);
+    const EvalSums es_ = reduce_eval<TASK, false, LEAN>(a_tr, b_tr, c_tr, a_te, b_te, c_te, red, extra);
+    FW_DBG(3);
+    return es_;
+}
+
+
 // Diagnostic build only (-DPTNN_STAMPS): wave 0 of the first work-group of replica 0 adds up shader-clock cycles per phase
 // of a round and writes the sums to p.stamps at the end.  In the product build no stamp executes.
 #ifdef PTNN_STAMPS
@@ -1317,11 +1609,14 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& d
     const int gid = p.first_global + r;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int Nall = p.Ntr + p.Nte;
-    const Lds l = carve(smem, Nall, p.IPY, p.PS, p.H, p.FWS, p.use_lg != 0);
+    Lds l = carve(smem, Nall, p.IPY, p.PS, p.H, p.FWS, p.use_lg != 0, p.xy_global == 0);
     const int P = p.P, PS = p.PS, H = p.H;
+    const bool split = SplitK<I>::OK && p.fw_mfma == 2;
 
     // stage the data set and this replica's vectors (coalesced)
-    {
+    if (p.xy_global) {
+        l.xy = const_cast<float*>(p.data);                    // read-only; the rare row-major readers (chain start) go to L2
+    } else {
         const float4* src = reinterpret_cast<const float4*>(p.data);
         float4* dst = reinterpret_cast<float4*>(l.xy);
         for (int e = tid; e < ((Nall + 2) * p.IPY) >> 2; e += nthr) dst[e] = src[e];
@@ -1333,9 +1628,16 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& d
         if (p.use_lg) l.w_gd[j] = dyn.gd_w[(size_t)r * PS + j];
     }
     // MFMA forward pass (host decides): transposed data image and per-tile partial sums behind the common LDS block
-    float* xt_l = smem + lds_floats(Nall, p.IPY, p.PS, p.H, p.FWS, p.use_lg != 0);
+    float* xt_l = smem + ((lds_floats(Nall, p.IPY, p.PS, p.H, p.FWS, p.use_lg != 0, p.xy_global == 0) + 3) & ~(size_t)3);
     float* part_l = xt_l + (size_t)I * p.Npad;
-    if (p.fw_mfma)
+    SplitLds sl = {};
+    if constexpr (SplitK<I>::OK) {
+        if (split) {
+            sl = carve_split<I>(xt_l, O, H, p.Npad);
+            stage_split_data<I>(sl, p.data, p.IPY, Nall, p.Npad);
+        }
+    }
+    if (p.fw_mfma == 1)
         for (int e = tid; e < I * p.Npad; e += nthr) xt_l[e] = p.xt[e];
     __syncthreads();
 
@@ -1399,7 +1701,13 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& d
             EvalSums sc;
             float none = 0.0f;
             __syncthreads();                                // the previous step's readers of red[]
-            if (p.fw_mfma) {
+            if (split) {
+                if constexpr (SplitK<I>::OK) {
+                    split_weights<I>(sl.as, H, [&](int idx) { return w_cur[idx]; });
+                    __syncthreads();
+                    sc = eval_rows_mfma_split<TASK, I, O>(w_cur, sl, H, p.Ntr, Nall, p.Npad, l.red, none);
+                }
+            } else if (p.fw_mfma) {
                 sc = eval_rows_mfma_coop<TASK, I, O>(w_cur, xt_l, part_l, l.xy, p.IPY, H, p.Ntr, Nall, p.Npad, l.red, none);
             } else {
                 build_fw<I, O>(w_cur, l.fw, H, p.FWS);
@@ -1436,8 +1744,11 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& d
             diff_prop = langevin_ratio(d1, d2, p.step_w, adapttemp);   // Q6
             lg_count += 1;
             if (!p.fw_mfma) build_fw<I, O>(w_prop, l.fw, H, p.FWS);
+            if constexpr (SplitK<I>::OK) { if (split) split_weights<I>(sl.as, H, [&](int idx) { return w_prop[idx]; }); }   // w_prop: behind the barrier above
         } else if (p.fw_mfma) {
             for (int j = tid; j < P; j += nthr) w_prop[j] = fmaf(p.step_w, noise[j], w_cur[j]);
+            // the split image of W1 is formed from the same expression, so nobody waits for w_prop
+            if constexpr (SplitK<I>::OK) { if (split) split_weights<I>(sl.as, H, [&](int idx) { return fmaf(p.step_w, noise[idx], w_cur[idx]); }); }
         } else {
             propose_build_fw<I, O>(w_cur, noise, p.step_w, w_prop, l.fw, H, p.FWS);
         }
@@ -1456,7 +1767,8 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& d
         }
         STAMP(3);                                         // next step's tape
         EvalSums es;
-        if (p.fw_mfma) es = eval_rows_mfma_coop<TASK, I, O, true>(w_prop, xt_l, part_l, l.xy, p.IPY, H, p.Ntr, Nall, p.Npad, l.red, ssq);
+        if (split) { if constexpr (SplitK<I>::OK) es = eval_rows_mfma_split<TASK, I, O, true>(w_prop, sl, H, p.Ntr, Nall, p.Npad, l.red, ssq); }
+        else if (p.fw_mfma) es = eval_rows_mfma_coop<TASK, I, O, true>(w_prop, xt_l, part_l, l.xy, p.IPY, H, p.Ntr, Nall, p.Npad, l.red, ssq);
         else es = eval_rows<TASK, I, O, false, true>(l.fw, l.xy, p.IPY, p.FWS, H, p.Ntr, Nall, l.red, ssq);
         const float lik_prop = finish_loglik<TASK>(es, p.Ntr, eta_pro) / adapttemp;
         STAMP(4);                                         // forward pass over all rows + likelihood
@@ -2557,12 +2869,6 @@ __device__ __attribute__((noinline, aligned(256))) void sgd_sweep_wide_pair(cons
 // (exact fp32, k-ordered fma chain) or 16 per v_mfma_f32_32x32x16_bf16 (BF16 = true: operands rounded to bf16,
 // fp32 accumulation; the tolerance study of BASELINE config 5).  Needs H % 32 == 0; I is zero-padded to IK.
 // ------------------------------------------------------------------------------------------------
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ short f32_to_bf16(float f) {            // round to nearest even; inputs are finite
-    const unsigned u = __builtin_bit_cast(unsigned, f);
-    return (short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
 
 template <int TASK, int I, int O, bool BF16>
 __device__ __forceinline__ EvalSums eval_rows_mfma(const float* __restrict__ wl, const float* __restrict__ xt,
