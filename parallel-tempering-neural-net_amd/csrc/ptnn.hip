@@ -86,6 +86,7 @@ struct ptnn_handle {
     int pk_nred = 3;                // its lane-group width: 2^3 (H <= 8) or 2^4 hidden units
     float* d_wide_scratch = nullptr;
     float* d_xt = nullptr;          // transposed data image for the MFMA forward pass
+    void* d_xs = nullptr;           // wide nets: the data image split into three bf16 levels (split-operand forward pass)
     int Npad = 0;
     int fw_mfma = 0;                // cooperative / tree schedule: forward pass on the matrix cores (24 <= H <= 64, I >= 6): 1 exact fp32, 2 split bf16 operands (cooperative only)
     bool xy_global = false;         // split forward pass: no room for the row-major data image in LDS, its rare readers go to global memory
@@ -157,7 +158,7 @@ struct ptnn_handle {
         p.L_handoff = d_L_handoff; p.L_final = d_L_final;
         p.L_raw = (cfg.swap_rule == 1) ? d_L_raw : nullptr; p.prior_post = d_prior_post;
         p.tr_pos_w = d_pos_w; p.tr_scal = d_scal; p.PW = PW;
-        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.xverdict = d_xverdict; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.noise_shared = cfg.shared_noise ? 1 : 0; p.pk_nred = pk_nred; p.xt = d_xt; p.Npad = Npad; p.fw_mfma = fw_mfma; p.xy_global = xy_global ? 1 : 0; p.forward_bf16 = cfg.forward_bf16 == 1 ? 1 : 0; p.tree_ahead = tree_ahead ? 1 : 0; p.compact = compact ? 1 : 0;
+        p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.xverdict = d_xverdict; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.noise_shared = cfg.shared_noise ? 1 : 0; p.pk_nred = pk_nred; p.xt = d_xt; p.xs = reinterpret_cast<const uint4*>(d_xs); p.Npad = Npad; p.fw_mfma = fw_mfma; p.xy_global = xy_global ? 1 : 0; p.forward_bf16 = cfg.forward_bf16 == 1 ? 1 : 0; p.tree_ahead = tree_ahead ? 1 : 0; p.compact = compact ? 1 : 0;
         // wide nets over several work-groups: a window of 8 steps lets the groups balance Langevin (5 units) against random-walk (1)
         // steps; random-walk-only runs have nothing to balance and a longer window only wastes what follows an accepted step
         p.wide_window = cfg.use_langevin ? 8 : groups;
@@ -522,7 +523,7 @@ int ptnn_destroy(ptnn_handle* h) {
         if (hipStreamQuery(h->stream) == hipErrorNotReady) return fail(-7, "the stream of a failed communicator did not drain: handle leaked");
     }
     void* ptrs[] = {h->d_data, h->d_state[0], h->d_state[1], h->d_rec_w, h->d_gd_w[0], h->d_gd_w[1], h->d_gd_valid[0], h->d_gd_valid[1], h->d_st_f, h->d_st_i, h->d_temps,
-                    h->d_L_handoff, h->d_L_final, h->d_L_raw, h->d_prior_post, h->d_temps_global, h->d_pos_w, h->d_scal, h->d_src, h->d_label[0], h->d_label[1], h->d_slot_of[0], h->d_slot_of[1], h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_xverdict, h->d_stamps, h->d_wide_scratch, h->d_xt, h->d_barrier};
+                    h->d_L_handoff, h->d_L_final, h->d_L_raw, h->d_prior_post, h->d_temps_global, h->d_pos_w, h->d_scal, h->d_src, h->d_label[0], h->d_label[1], h->d_slot_of[0], h->d_slot_of[1], h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_xverdict, h->d_stamps, h->d_wide_scratch, h->d_xt, h->d_xs, h->d_barrier};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_src) (void)hipHostFree(h->h_src);
@@ -571,6 +572,33 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         HIP_TRY(hipMemcpy(h->d_xt, xt.data(), xt.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     h->fw_mfma = 0; h->xy_global = false;
+    if (h->d_xs) { HIP_TRY(hipFree(h->d_xs)); h->d_xs = nullptr; }
+    if (H > WAVE && H % 32 == 0 && h->shape->split_ch > 0 && h->cfg.forward_bf16 == 0) {
+        // split-operand forward pass of the wide kernels (ptnn_device.hpp, SplitK / eval_rows_mfma_wsplit): x = hi + mid + lo, three
+        // bf16 roundings (nearest even; x - hi and x - hi - mid are exact in fp32), rows of 8 * CH bf16, k contiguous
+        const char* fs = std::getenv("PTNN_FW_SPLIT");
+        if (!(fs && fs[0] == '0')) {
+            const int CH = h->shape->split_ch, KBF = 8 * CH;
+            auto bf16 = [](float f) -> uint32_t { uint32_t u; std::memcpy(&u, &f, 4); return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16; };
+            auto back = [](uint32_t b) -> float { const uint32_t u = b << 16; float f; std::memcpy(&f, &u, 4); return f; };
+            std::vector<uint16_t> xs((size_t)3 * h->Npad * KBF, 0);
+            for (int n = 0; n < Nall; ++n)
+                for (int k = 0; k < I && k < KBF; ++k) {
+                    const float x = packed[(size_t)n * IPY + k];
+                    const uint32_t hi = bf16(x);
+                    const float r1 = x - back(hi);
+                    const uint32_t mid = bf16(r1);
+                    const float r2 = r1 - back(mid);
+                    const uint32_t lo = bf16(r2);
+                    xs[((size_t)0 * h->Npad + n) * KBF + k] = (uint16_t)hi;
+                    xs[((size_t)1 * h->Npad + n) * KBF + k] = (uint16_t)mid;
+                    xs[((size_t)2 * h->Npad + n) * KBF + k] = (uint16_t)lo;
+                }
+            HIP_TRY(hipMalloc(&h->d_xs, xs.size() * sizeof(uint16_t)));
+            HIP_TRY(hipMemcpy(h->d_xs, xs.data(), xs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            h->fw_mfma = 2;
+        }
+    }
     if (H > WAVE) {
         // wide net: one thread per hidden unit, vectors in HBM, only the packed forward image + scratch in LDS
         // matrix-core layout (H a multiple of 32): the state vector joins the proposal in LDS when both fit (ceilings just below

@@ -96,6 +96,7 @@ struct SegParams {
     unsigned long long* stamps;   // diagnostic build only (PTNN_STAMPS): cycle sums per phase, else unused
     float* wide_scratch;     // [Rl][3][PS] proposal, its SGD epoch, noise (wide nets only: these do not fit in LDS)
     const float* xt;         // wide nets: transposed data image Xt[k][Npad] (B operand of the MFMA forward pass), or null
+    const uint4* xs;         // wide nets, split-operand forward pass (fw_mfma == 2): [3 levels][Npad rows][SplitK::CH chunks of 8 bf16], or null
     int Npad;                // rows of Xt, Nall rounded up to 32
     int forward_bf16;        // 1: forward GEMM operands rounded to bf16 (fp32 accumulate); 0: exact fp32 MFMA
     int* seg_progress;       // pinned host word or null (RCCL communicator attached): block 0 stores seg_ordinal when this launch ends
@@ -1199,25 +1200,27 @@ __device__ __forceinline__ SplitLds carve_split(float* base, int O, int H, int N
     return l;
 }
 template <int CH> __device__ __forceinline__ int split_chunk(int row, int c) { return c ^ ((row / (16 / CH)) & (CH - 1)); }
-__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-    h = (unsigned short)f32_to_bf16(x);
-    const float r1 = x - __builtin_bit_cast(float, h << 16);
-    m = (unsigned short)f32_to_bf16(r1);
-    const float r2 = r1 - __builtin_bit_cast(float, m << 16);
-    l = (unsigned short)f32_to_bf16(r2);
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// two floats -> their bf16 roundings (nearest even) packed {lo16 = first, hi16 = second}: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
-// image[level][row][k]: elements (row, k) and (row, k + 1), k even, of all three levels
+// image[level][row][k]: elements (row, k) and (row, k + 1), k even, of all three levels.  x - hi and (x - hi) - mid are exact in fp32.
 template <int CH>
 __device__ __forceinline__ void split_store_pair(uint4* img, int rows, int row, int k, float x0, float x1) {
-    unsigned h0, m0, l0, h1, m1, l1;
-    split3(x0, h0, m0, l0);
-    split3(x1, h1, m1, l1);
+    const unsigned h = pack_bf16(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    const unsigned m = pack_bf16(r0, r1);
+    const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    const unsigned l = pack_bf16(q0, q1);
     unsigned* w = reinterpret_cast<unsigned*>(img);
     const size_t at = ((size_t)row * CH + split_chunk<CH>(row, k >> 3)) * 4 + ((k & 7) >> 1);
     const size_t lvl = (size_t)rows * CH * 4;
-    w[at] = h0 | (h1 << 16);
-    w[at + lvl] = m0 | (m1 << 16);
-    w[at + 2 * lvl] = l0 | (l1 << 16);
+    w[at] = h;
+    w[at + lvl] = m;
+    w[at + 2 * lvl] = l;
 }
 // once per launch: the data set (global, row-major with IPY floats per row) into the split image, the remainder columns and the labels
 template <int I>
@@ -1239,9 +1242,9 @@ __device__ __forceinline__ void stage_split_data(const SplitLds& l, const float*
 template <int I, class F>
 __device__ __forceinline__ void split_weights(uint4* as, int H, F wval) {
     typedef SplitK<I> K;
-    const int Hpad = ((H + 31) >> 5) << 5;
+    const int Hpad = ((H + 31) >> 5) << 5, hs = 31 - __clz(Hpad);       // H <= 64 here: 32 or 64
     for (int e = threadIdx.x; e < Hpad * (K::KBF / 2); e += blockDim.x) {
-        const int kp = e / Hpad, hid = e - kp * Hpad, k = 2 * kp;      // consecutive threads: consecutive hidden units (w is [k][h])
+        const int kp = e >> hs, hid = e & (Hpad - 1), k = 2 * kp;      // consecutive threads: consecutive hidden units (w is [k][h])
         const float x0 = (hid < H && k < I) ? wval(k * H + hid) : 0.0f;
         const float x1 = (hid < H && k + 1 < I) ? wval((k + 1) * H + hid) : 0.0f;
         split_store_pair<K::CH>(as, Hpad, hid, k, x0, x1);
@@ -3002,6 +3005,218 @@ __device__ __forceinline__ EvalSums eval_rows_mfma(const float* __restrict__ wl,
     return s;
 }
 
+// Split-operand forward pass of a wide net (see SplitK above: on gfx950 the fp32 matrix instruction runs at VALU rate and blocks the
+// VALU; six bf16 partial products per k-step of 16 take 198 pipe cycles instead of 520 and leave the vector issue free).  B: the
+// split data image is made once by ptnn_set_data and read from L2 (16 bytes per lane, operand and k-step); a wave holds the
+// operands of TWO row blocks for all hidden tiles.  A: the weights of a tile are read from the flat fp32 proposal in LDS and
+// split in registers, once per pair of row blocks (a split image of W1 would take 96 KB of LDS next to the resident state).
+// Tiles are software-pipelined: the matrix instructions of tile t + 1 are interleaved with the sigmoid / W2 epilogue of tile t.
+template <int TASK, int I, int O>
+__device__ __forceinline__ EvalSums eval_rows_mfma_wsplit(const float* __restrict__ wl, const uint4* __restrict__ xs,
+                                                          const float* __restrict__ xt, const float* __restrict__ data, int IPY, int H,
+                                                          int Ntr, int Nall, int Npad, float* __restrict__ red) {
+    typedef SplitK<I> K;
+    constexpr int KB = K::KB, KR = K::KR, CH = K::CH, NB = 2;
+    const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 31, half = lane >> 5;
+    const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
+    float a_tr = 0.f, b_tr = 0.f, c_tr = 0.f, a_te = 0.f, b_te = 0.f, c_te = 0.f;
+    float b2[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o) b2[o] = wl[oB2 + o];
+    const int ntiles = H >> 5, nrb = Npad >> 5;
+    struct AFrag { bf16x8 h[KB], m[KB], l[KB]; float r[KR > 0 ? KR : 1]; };
+    auto make_a = [&](int t, AFrag& a) {
+        const float* pa = wl + t * 32 + col;
+#pragma unroll
+        for (int s_ = 0; s_ < KB; ++s_) {
+            unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * s_ + 8 * half + 2 * j;
+                const float v0 = pa[min(k, I - 1) * H], v1 = pa[min(k + 1, I - 1) * H];
+                const float x0 = (k < I) ? v0 : 0.0f, x1 = (k + 1 < I) ? v1 : 0.0f;
+                const unsigned h = pack_bf16(x0, x1);
+                const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+                const unsigned m = pack_bf16(r0, r1);
+                const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+                hh[j] = h; mm[j] = m; ll[j] = pack_bf16(q0, q1);
+            }
+            a.h[s_] = __builtin_bit_cast(bf16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
+            a.m[s_] = __builtin_bit_cast(bf16x8, make_uint4(mm[0], mm[1], mm[2], mm[3]));
+            a.l[s_] = __builtin_bit_cast(bf16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < KR; ++s_) {
+            const int k = K::KBF + 2 * s_ + half;
+            const float v = pa[min(k, I - 1) * H];
+            a.r[s_] = (k < I) ? v : 0.0f;
+        }
+    };
+    for (int g = wave; g * NB < nrb; g += nw) {
+        // B operands of this group's row blocks stay in registers for all hidden tiles (a block past the end repeats the last one
+        // and is not scored)
+        bf16x8 b_h[NB][KB], b_m[NB][KB], b_l[NB][KB];
+        float b_r[NB][KR > 0 ? KR : 1];
+#pragma unroll
+        for (int b_ = 0; b_ < NB; ++b_) {
+            const int rb = min(g * NB + b_, nrb - 1), n = rb * 32 + col;
+            const uint4* base = xs + (size_t)n * CH;
+#pragma unroll
+            for (int s_ = 0; s_ < KB; ++s_) {
+                b_h[b_][s_] = __builtin_bit_cast(bf16x8, base[2 * s_ + half]);
+                b_m[b_][s_] = __builtin_bit_cast(bf16x8, base[(size_t)Npad * CH + 2 * s_ + half]);
+                b_l[b_][s_] = __builtin_bit_cast(bf16x8, base[(size_t)2 * Npad * CH + 2 * s_ + half]);
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < KR; ++s_) b_r[b_][s_] = xt[(size_t)(K::KBF + 2 * s_ + half) * Npad + n];
+        }
+        auto chain = [&](const AFrag& a, int b_) {
+            f32x16 acc;
+#pragma unroll
+            for (int r_ = 0; r_ < 16; ++r_) acc[r_] = 0.0f;
+#pragma unroll
+            for (int s_ = 0; s_ < KB; ++s_) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l[s_], b_h[b_][s_], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s_], b_l[b_][s_], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[s_], b_m[b_][s_], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < KB; ++s_) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m[s_], b_h[b_][s_], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s_], b_m[b_][s_], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < KB; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h[s_], b_h[b_][s_], acc, 0, 0, 0);
+#pragma unroll
+            for (int s_ = 0; s_ < KR; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.r[s_], b_r[b_][s_], acc, 0, 0, 0);
+            return acc;
+        };
+        float sum[NB][O];
+#pragma unroll
+        for (int b_ = 0; b_ < NB; ++b_)
+#pragma unroll
+            for (int o = 0; o < O; ++o) sum[b_][o] = 0.0f;
+        // epilogue in place: register r_ is hidden unit hbase + (r_ & 3) + 8 (r_ >> 2) + 4 half; bias and W2 rows of a tile are read
+        // once for both blocks, BEFORE the interleaved region (the scheduler hints place matrix and vector instructions only: a
+        // vector instruction that waits for an LDS read inside the region would drag the whole epilogue behind the matrix block)
+        struct Epi { float b1[16]; float w2[16][O]; };
+        auto load_epi = [&](int t, Epi& e) {
+            const int hbase = t * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int h0 = hbase + 8 * q + 4 * half;
+                const float4 b1v = *reinterpret_cast<const float4*>(wl + oB1 + h0);
+                e.b1[4 * q] = b1v.x; e.b1[4 * q + 1] = b1v.y; e.b1[4 * q + 2] = b1v.z; e.b1[4 * q + 3] = b1v.w;
+#pragma unroll
+                for (int i_ = 0; i_ < 4; ++i_)
+#pragma unroll
+                    for (int o = 0; o < O; ++o) e.w2[4 * q + i_][o] = wl[oW2 + (h0 + i_) * O + o];
+            }
+        };
+        auto finish = [&](const f32x16 (&acc)[NB], const Epi& e) {
+#pragma unroll
+            for (int r_ = 0; r_ < 16; ++r_)
+#pragma unroll
+                for (int b_ = 0; b_ < NB; ++b_) {
+                    const float hid = sigmoidf_fast(acc[b_][r_] - e.b1[r_]);
+#pragma unroll
+                    for (int o = 0; o < O; ++o) sum[b_][o] = fmaf(hid, e.w2[r_][o], sum[b_][o]);
+                }
+        };
+        // one pipeline stage: the matrix instructions of tile t + 1 into `nxt`, interleaved with the epilogue of tile t in `cur` (ONE
+        // basic block: the scheduler hints only reach what sits in the same block)
+        auto stage = [&](const f32x16 (&cur)[NB], f32x16 (&nxt)[NB], int t) {
+            AFrag a;
+            Epi e;
+            make_a(t + 1, a);
+            load_epi(t, e);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b_ = 0; b_ < NB; ++b_) nxt[b_] = chain(a, b_);
+            finish(cur, e);
+#pragma unroll
+            for (int q_ = 0; q_ < NB * (6 * KB + KR); ++q_) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (16 * (4 + O) + 6 * KB + KR - 1) / (6 * KB + KR), 0);
+                __builtin_amdgcn_sched_group_barrier(0x400, (32 + 6 * KB + KR - 1) / (6 * KB + KR), 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto last = [&](const f32x16 (&cur)[NB], int t) { Epi e; load_epi(t, e); finish(cur, e); };
+        f32x16 accA[NB], accB[NB];
+        {
+            AFrag a;
+            make_a(0, a);
+#pragma unroll
+            for (int b_ = 0; b_ < NB; ++b_) accA[b_] = chain(a, b_);
+        }
+        int t = 0;
+        for (; t + 2 < ntiles; t += 2) { stage(accA, accB, t); stage(accB, accA, t + 1); }   // two stages a trip: no accumulator is ever copied
+        if (t + 1 < ntiles) { stage(accA, accB, t); last(accB, t + 1); }
+        else last(accA, t);
+#pragma unroll
+        for (int b_ = 0; b_ < NB; ++b_) {
+            const int rb = g * NB + b_, n = rb * 32 + col;
+            // join the two lane halves (hidden units 4..7, 12..15, ... live in lanes 32..63)
+            float tot[O];
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                const unsigned u = __builtin_bit_cast(unsigned, sum[b_][o]);
+                auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                tot[o] = __builtin_bit_cast(float, (unsigned)r2[0]) + __builtin_bit_cast(float, (unsigned)r2[1]) - b2[o];
+            }
+            if (half == 0 && rb < nrb && n < Nall) {
+                const float y = data[(size_t)n * IPY + I];
+                float a_, bb = 0.f, c = 0.f;
+                if (TASK == TASK_REG) {
+                    const float d = y - sigmoidf_fast(tot[0]);
+                    a_ = d * d;
+                } else {
+                    ArgKey best = argmax_key(tot[0]);
+                    float se = 0.0f, oy = 0.0f;
+                    int arg = 0;
+                    const int yi = (int)y;
+#pragma unroll
+                    for (int o = 0; o < O; ++o) {
+                        const float out = sigmoidf_fast(tot[o]);
+                        const ArgKey key = argmax_key(tot[o]);
+                        if (argkey_greater(key, best)) { best = key; arg = o; }
+                        se += expf_fast(out);
+                        oy = (o == yi) ? out : oy;
+                    }
+                    a_ = oy - logf_fast(se);
+                    const float dd = (float)arg - y;
+                    bb = dd * dd;
+                    c = ((float)arg == y) ? 1.0f : 0.0f;
+                }
+                if (n < Ntr) { a_tr += a_; b_tr += bb; c_tr += c; }
+                else { a_te += a_; b_te += bb; c_te += c; }
+            }
+        }
+    }
+    a_tr = wave_allsum(a_tr);
+    a_te = wave_allsum(a_te);
+    if (TASK == TASK_CLS) {
+        b_tr = wave_allsum(b_tr); c_tr = wave_allsum(c_tr);
+        b_te = wave_allsum(b_te); c_te = wave_allsum(c_te);
+    }
+    EvalSums s;
+    __syncthreads();
+    if (lane == 0) {
+        float* r = red + wave * 8;
+        r[0] = a_tr; r[1] = b_tr; r[2] = c_tr; r[3] = a_te; r[4] = b_te; r[5] = c_te;
+    }
+    __syncthreads();
+    s.a_tr = s.b_tr = s.c_tr = s.a_te = s.b_te = s.c_te = 0.f;
+    for (int k = 0; k < nw; ++k) {
+        const float* r = red + k * 8;
+        s.a_tr += r[0]; s.b_tr += r[1]; s.c_tr += r[2]; s.a_te += r[3]; s.b_te += r[4]; s.c_te += r[5];
+    }
+    return s;
+}
+
 // forward pass of a wide net under weight vector w (global): MFMA when the hidden layer tiles (H % 32 == 0), else the
 // lane-per-row VALU path on the packed image.  `img` is the LDS image area (max of both layouts).
 __device__ __forceinline__ bool wide_mfma(const SegParams& p) { return (p.H & 31) == 0 && p.xt != nullptr; }
@@ -3017,6 +3232,9 @@ __device__ __forceinline__ EvalSums wide_forward(const SegParams& p, const float
             __syncthreads();
         }
         if (p.forward_bf16) return eval_rows_mfma<TASK, I, O, true>(img, p.xt, p.data, p.IPY, p.H, p.Ntr, Nall, p.Npad, red);
+        if constexpr (SplitK<I>::OK) {
+            if (p.fw_mfma == 2) return eval_rows_mfma_wsplit<TASK, I, O>(img, p.xs, p.xt, p.data, p.IPY, p.H, p.Ntr, Nall, p.Npad, red);
+        }
         return eval_rows_mfma<TASK, I, O, false>(img, p.xt, p.data, p.IPY, p.H, p.Ntr, Nall, p.Npad, red);
     }
     build_fw<I, O>(w, img, p.H, p.FWS);
