@@ -805,8 +805,23 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         if (explicit_tree && want != 0 && want != 3 && want != 7 && want != 15 && want != 31)
             return fail(-1, "tree schedule: groups_per_replica must be 0 (auto), 3, 7, 15 or 31");
         h->nthreads = (nw ? nw : coop_nw) * 64;
-        const size_t extra = mfma_coop_lds_floats(I, h->cfg.n_out, H, h->Npad) * sizeof(float);
+        size_t extra = (mfma_coop_lds_floats(I, h->cfg.n_out, H, h->Npad) + 4) * sizeof(float);
         const bool coop_mfma = H >= 24 && I >= 6 && lds_floats(Nall, IPY, h->PS, H, h->FWS, false) * sizeof(float) + extra <= LDS_MAX;
+        // the split-operand forward pass of the cooperative kernel (same arithmetic: the tree commits the cooperative chain bit for
+        // bit either way), when its images fit next to the shallowest tree
+        bool tree_split = false;
+        {
+            const char* fs = std::getenv("PTNN_FW_SPLIT");
+            if (coop_mfma && h->shape->split_ch > 0 && h->cfg.forward_bf16 != 2 && !(fs && fs[0] == '0')) {
+                const int CH = h->shape->split_ch, KR = h->shape->split_kr, Hpad = ((H + 31) >> 5) << 5;
+                const size_t sfl = (size_t)3 * h->Npad * CH * 4 + (size_t)2 * KR * h->Npad + (size_t)h->Npad + (size_t)3 * Hpad * CH * 4 +
+                                   (size_t)(Hpad >> 5) * h->Npad * h->cfg.n_out + 4;
+                if (tree_lds_floats(Nall, IPY, h->PS, H, h->FWS, 2, false, true) * sizeof(float) + sfl * sizeof(float) <= 152 * 1024) {
+                    tree_split = true;
+                    extra = sfl * sizeof(float);
+                }
+            }
+        }
         int chosen = 0;
         size_t chosen_lds = 0;
         bool chosen_mfma = false;
@@ -832,7 +847,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
             if (explicit_tree && want) break;
         }
         if (chosen) {
-            h->tree = true; h->speculative = false; h->groups = chosen; h->seg_lds = chosen_lds; h->fw_mfma = chosen_mfma ? 1 : 0; h->xy_global = false;
+            h->tree = true; h->speculative = false; h->groups = chosen; h->seg_lds = chosen_lds; h->fw_mfma = chosen_mfma ? (tree_split ? 2 : 1) : 0; h->xy_global = false;
             if (h->d_xslots) { HIP_TRY(hipFree(h->d_xslots)); h->d_xslots = nullptr; }
             const size_t ng = (size_t)Rl * 2 * (TREE_MAX_NODES + 1) * TREE_REC;
             HIP_TRY(hipMalloc(&h->d_xslots, ng * sizeof(unsigned long long)));

@@ -3987,8 +3987,10 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
     float* fw = tapes0 + tape_floats;
     float* red = fw + (mfma ? 0 : fw_floats(H, p.FWS));
     float* recs = red + MAX_WAVES * 8;                     // [nodes][TREE_REC]
-    float* xt_l = smem + tree_lds_floats(Nall, p.IPY, PS, H, p.FWS, D, ahead, mfma);
+    float* xt_l = smem + ((tree_lds_floats(Nall, p.IPY, PS, H, p.FWS, D, ahead, mfma) + 3) & ~(size_t)3);
     float* part_l = xt_l + (size_t)I * p.Npad;
+    const bool split = SplitK<I>::OK && p.fw_mfma == 2;     // split-operand forward pass: the cooperative kernel's (same arithmetic, same chain)
+    SplitLds sl = {};
     // what the scoring reads as xy[n * stride + I]
     const float* const ysrc = mfma ? xy - I : xy;
     const int ystride = mfma ? 1 : p.IPY;
@@ -4004,7 +4006,13 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
         w_cur[j] = gw[j];
         rec_w[j] = p.rec_w[(size_t)r * PS + j];
     }
-    if (p.fw_mfma)
+    if constexpr (SplitK<I>::OK) {
+        if (split) {
+            sl = carve_split<I>(xt_l, O, H, p.Npad);
+            stage_split_data<I>(sl, p.data, p.IPY, Nall, p.Npad);
+        }
+    }
+    if (p.fw_mfma == 1)
         for (int e = tid; e < I * p.Npad; e += nthr) xt_l[e] = p.xt[e];
     __syncthreads();
 
@@ -4069,7 +4077,13 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
         if (i == p.switch_step) {                            // re-evaluate the current w untempered (Q9, REG:322 / CLS)
             EvalSums sc;
             float none = 0.0f;
-            if (p.fw_mfma) {
+            if (split) {
+                if constexpr (SplitK<I>::OK) {
+                    split_weights<I>(sl.as, H, [&](int idx) { return w_cur[idx]; });
+                    __syncthreads();
+                    sc = eval_rows_mfma_split<TASK, I, O>(w_cur, sl, H, p.Ntr, Nall, p.Npad, red, none);
+                }
+            } else if (p.fw_mfma) {
                 sc = eval_rows_mfma_coop<TASK, I, O>(w_cur, xt_l, part_l, ysrc, ystride, H, p.Ntr, Nall, p.Npad, red, none);
             } else {
                 build_fw<I, O>(w_cur, fw, H, p.FWS);
@@ -4092,6 +4106,7 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
         if (active) {
             if (p.fw_mfma) {
                 for (int j = tid; j < P; j += nthr) w_prop[j] = path_value(j);
+                if constexpr (SplitK<I>::OK) { if (split) split_weights<I>(sl.as, H, [&](int idx) { return path_value(idx); }); }
             } else {
                 const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
                 constexpr int K = I + 1 + O;
@@ -4121,7 +4136,8 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
             float ssq = 0.0f;
             for (int j = tid; j < P; j += nthr) ssq = fmaf(w_prop[j], w_prop[j], ssq);
             EvalSums es;
-            if (p.fw_mfma) es = eval_rows_mfma_coop<TASK, I, O, true>(w_prop, xt_l, part_l, ysrc, ystride, H, p.Ntr, Nall, p.Npad, red, ssq);
+            if (split) { if constexpr (SplitK<I>::OK) es = eval_rows_mfma_split<TASK, I, O, true>(w_prop, sl, H, p.Ntr, Nall, p.Npad, red, ssq); }
+            else if (p.fw_mfma) es = eval_rows_mfma_coop<TASK, I, O, true>(w_prop, xt_l, part_l, ysrc, ystride, H, p.Ntr, Nall, p.Npad, red, ssq);
             else es = eval_rows<TASK, I, O, false, true>(fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, red, ssq);
             rv[0] = finish_loglik<TASK>(es, p.Ntr, eta) / adapttemp;
             rv[1] = prior_value<TASK>(p, ssq, eta);
