@@ -490,14 +490,28 @@ def main():
                                      "sequential SGD epoch timed in this process; measured = dominant kernel time per swap interval"}
         roof["note"] = ("instruction-issue / dependent-chain bound by construction (sequential SGD rows, arithmetic intensity far "
                         "above the machine balance); the HBM fraction is reported because BASELINE.json asks for it")
-        if wl["topo"][1] > 64:
-            # config 5: the forward pass is a per-replica GEMM (Ntr+Nte) x I x H on the matrix cores -- its own roofline beside it
-            gemm = 2.0 * (train.shape[0] + test.shape[0]) * wl["topo"][0] * wl["topo"][1]
+        if info.get("forward_mfma"):
+            # configs 4 and 5: the forward pass is a per-replica GEMM (Ntr+Nte) x I x H on the matrix cores -- its own roofline beside it.
+            # forward_mfma 2 = fp32 operands split into three bf16 terms, six partial products on v_mfma_f32_32x32x16_bf16 (fp32
+            # accuracy; the fp32 matrix instruction runs at VALU rate and blocks the VALU on gfx950): `achieved` stays the
+            # ALGORITHMIC fp32 flops against the fp32 dense peak, `pipe` is what the bf16 pipe executes for them against ITS peak
+            I_, H_ = wl["topo"][0], wl["topo"][1]
+            gemm = 2.0 * (train.shape[0] + test.shape[0]) * I_ * H_
+            split = info["forward_mfma"] == 2
             peak = MFMA_BF16_PEAK_TFLOPS if a.bf16 else VALU_PEAK_TFLOPS
             ach = R * steps_per_launch * gemm / avg_launch_s / 1e12 if launches else 0.0
             roof["mfma"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                            "instruction": "v_mfma_f32_32x32x16_bf16 on three-way split fp32 operands (6 partial products per k-step of 16)"
+                                           if split else ("v_mfma_f32_32x32x16_bf16 (operands rounded)" if a.bf16 else "v_mfma_f32_32x32x2_f32"),
                             "note": "flops of the forward GEMM only, over the whole fused launch (which also runs the SGD epochs, the "
                                     "random tape and the vector streams)"}
+            if split:
+                kbf = 16 * ((I_ + 15) // 16 if I_ % 16 >= 7 else I_ // 16)      # SplitK: k extent on the bf16 instruction
+                rows_pad = (train.shape[0] + test.shape[0] + 31) // 32 * 32
+                pipe = 6.0 * 2.0 * rows_pad * kbf * ((H_ + 31) // 32 * 32)
+                roof["mfma"]["pipe"] = {"achieved": R * steps_per_launch * pipe / avg_launch_s / 1e12 if launches else 0.0,
+                                        "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s (bf16, padded tiles, 6 products)"}
+                roof["mfma"]["pipe"]["frac"] = roof["mfma"]["pipe"]["achieved"] / MFMA_BF16_PEAK_TFLOPS
         out = {
             "metric": "MCMC samples/sec (all replicas) + swap-accept rate; " + ("Sunspot 64-replica FNN" if a.workload == "sunspot64" else wl["desc"]),
             "value": value, "unit": "samples/s", "n_gpus": N, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,

@@ -1462,6 +1462,9 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_split(const float* __restrict
 #pragma unroll
             for (int o = 0; o < O; ++o) { const float v = pw2[dh * O + o]; w2r[r_][o] = in ? v : 0.0f; }
         }
+        float b1s[16];                                                  // log2e b1: exp2(-log2e z + log2e b1) = exp(-(z - b1))
+#pragma unroll
+        for (int r_ = 0; r_ < 16; ++r_) b1s[r_] = LOG2E * b1r[r_];
         struct BFrag { bf16x8 h[KB], m[KB], l[KB]; float r[KR > 0 ? KR : 1]; };
         auto load_b = [&](int rb, BFrag& b) {
             const int row = rb * 32 + col;                              // this lane's data row (Npad covers the last block)
@@ -1497,20 +1500,24 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_split(const float* __restrict
             for (int s_ = 0; s_ < KR; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_r[s_], b.r[s_], acc, 0, 0, 0);
             return acc;
         };
+        // epilogue on register PAIRS (v_pk_fma_f32 / v_pk_add_f32: two elements per issue slot; this pass is VALU-bound):
+        // exp2(-log2e (z - b1)) as ONE packed fma with the bias pre-scaled, 1 + e packed, two partial W2 sums (even / odd registers)
         auto finish = [&](const f32x16& acc, int rb) {
             const int n = rb * 32 + col;
-            float sum[O];
+            f32x2 sum2[O];
 #pragma unroll
-            for (int o = 0; o < O; ++o) sum[o] = 0.0f;
+            for (int o = 0; o < O; ++o) sum2[o] = f32x2{0.0f, 0.0f};
 #pragma unroll
-            for (int r_ = 0; r_ < 16; ++r_) {
-                const float hid = sigmoidf_fast(acc[r_] - b1r[r_]);
+            for (int r_ = 0; r_ < 16; r_ += 2) {
+                const f32x2 zz = __builtin_elementwise_fma(f32x2{acc[r_], acc[r_ + 1]}, f32x2{-LOG2E, -LOG2E}, f32x2{b1s[r_], b1s[r_ + 1]});
+                const f32x2 ee = f32x2{__builtin_amdgcn_exp2f(zz.x), __builtin_amdgcn_exp2f(zz.y)} + f32x2{1.0f, 1.0f};
+                const f32x2 hid = f32x2{__builtin_amdgcn_rcpf(ee.x), __builtin_amdgcn_rcpf(ee.y)};
 #pragma unroll
-                for (int o = 0; o < O; ++o) sum[o] = fmaf(hid, w2r[r_][o], sum[o]);
+                for (int o = 0; o < O; ++o) sum2[o] = __builtin_elementwise_fma(hid, f32x2{w2r[r_][o], w2r[r_ + 1][o]}, sum2[o]);
             }
 #pragma unroll
             for (int o = 0; o < O; ++o) {                               // hidden units 4..7, 12..15, ... live in lanes 32..63
-                const unsigned uu = __builtin_bit_cast(unsigned, sum[o]);
+                const unsigned uu = __builtin_bit_cast(unsigned, sum2[o].x + sum2[o].y);
                 auto r2 = __builtin_amdgcn_permlane32_swap(uu, uu, false, false);
                 const float tot = __builtin_bit_cast(float, (unsigned)r2[0]) + __builtin_bit_cast(float, (unsigned)r2[1]);
                 if (half == 0) part[((size_t)t * Npad + n) * O + o] = tot;
@@ -1533,7 +1540,7 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_split(const float* __restrict
 #pragma unroll
                 for (int q_ = 0; q_ < 6 * KB + KR; ++q_) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, (16 * (4 + O) + 6 * KB + KR - 1) / (6 * KB + KR), 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (8 * (2 + O) + 8 + 6 * KB + KR - 1) / (6 * KB + KR), 0);
                     __builtin_amdgcn_sched_group_barrier(0x400, (32 + 6 * KB + KR - 1) / (6 * KB + KR), 0);
                 }
                 acc = acc2; rb = nx; nx = nn;
@@ -3093,36 +3100,39 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_wsplit(const float* __restric
             for (int s_ = 0; s_ < KR; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.r[s_], b_r[b_][s_], acc, 0, 0, 0);
             return acc;
         };
-        float sum[NB][O];
+        f32x2 sum2[NB][O];                                              // partial W2 sums over the even / odd registers
 #pragma unroll
         for (int b_ = 0; b_ < NB; ++b_)
 #pragma unroll
-            for (int o = 0; o < O; ++o) sum[b_][o] = 0.0f;
+            for (int o = 0; o < O; ++o) sum2[b_][o] = f32x2{0.0f, 0.0f};
         // epilogue in place: register r_ is hidden unit hbase + (r_ & 3) + 8 (r_ >> 2) + 4 half; bias and W2 rows of a tile are read
         // once for both blocks, BEFORE the interleaved region (the scheduler hints place matrix and vector instructions only: a
         // vector instruction that waits for an LDS read inside the region would drag the whole epilogue behind the matrix block)
-        struct Epi { float b1[16]; float w2[16][O]; };
+        struct Epi { float b1[16]; float w2[16][O]; };                  // b1 pre-scaled by log2e
         auto load_epi = [&](int t, Epi& e) {
             const int hbase = t * 32;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int h0 = hbase + 8 * q + 4 * half;
                 const float4 b1v = *reinterpret_cast<const float4*>(wl + oB1 + h0);
-                e.b1[4 * q] = b1v.x; e.b1[4 * q + 1] = b1v.y; e.b1[4 * q + 2] = b1v.z; e.b1[4 * q + 3] = b1v.w;
+                e.b1[4 * q] = LOG2E * b1v.x; e.b1[4 * q + 1] = LOG2E * b1v.y; e.b1[4 * q + 2] = LOG2E * b1v.z; e.b1[4 * q + 3] = LOG2E * b1v.w;
 #pragma unroll
                 for (int i_ = 0; i_ < 4; ++i_)
 #pragma unroll
                     for (int o = 0; o < O; ++o) e.w2[4 * q + i_][o] = wl[oW2 + (h0 + i_) * O + o];
             }
         };
+        // on register pairs (packed fp32: two elements per issue slot; this pass is VALU-bound), see eval_rows_mfma_split
         auto finish = [&](const f32x16 (&acc)[NB], const Epi& e) {
 #pragma unroll
-            for (int r_ = 0; r_ < 16; ++r_)
+            for (int r_ = 0; r_ < 16; r_ += 2)
 #pragma unroll
                 for (int b_ = 0; b_ < NB; ++b_) {
-                    const float hid = sigmoidf_fast(acc[b_][r_] - e.b1[r_]);
+                    const f32x2 zz = __builtin_elementwise_fma(f32x2{acc[b_][r_], acc[b_][r_ + 1]}, f32x2{-LOG2E, -LOG2E}, f32x2{e.b1[r_], e.b1[r_ + 1]});
+                    const f32x2 ee = f32x2{__builtin_amdgcn_exp2f(zz.x), __builtin_amdgcn_exp2f(zz.y)} + f32x2{1.0f, 1.0f};
+                    const f32x2 hid = f32x2{__builtin_amdgcn_rcpf(ee.x), __builtin_amdgcn_rcpf(ee.y)};
 #pragma unroll
-                    for (int o = 0; o < O; ++o) sum[b_][o] = fmaf(hid, e.w2[r_][o], sum[b_][o]);
+                    for (int o = 0; o < O; ++o) sum2[b_][o] = __builtin_elementwise_fma(hid, f32x2{e.w2[r_][o], e.w2[r_ + 1][o]}, sum2[b_][o]);
                 }
         };
         // one pipeline stage: the matrix instructions of tile t + 1 into `nxt`, interleaved with the epilogue of tile t in `cur` (ONE
@@ -3139,7 +3149,7 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_wsplit(const float* __restric
 #pragma unroll
             for (int q_ = 0; q_ < NB * (6 * KB + KR); ++q_) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, (16 * (4 + O) + 6 * KB + KR - 1) / (6 * KB + KR), 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (8 * (2 + O) + 6 * KB + KR - 1) / (6 * KB + KR), 0);
                 __builtin_amdgcn_sched_group_barrier(0x400, (32 + 6 * KB + KR - 1) / (6 * KB + KR), 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -3163,7 +3173,7 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_wsplit(const float* __restric
             float tot[O];
 #pragma unroll
             for (int o = 0; o < O; ++o) {
-                const unsigned u = __builtin_bit_cast(unsigned, sum[b_][o]);
+                const unsigned u = __builtin_bit_cast(unsigned, sum2[b_][o].x + sum2[b_][o].y);
                 auto r2 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
                 tot[o] = __builtin_bit_cast(float, (unsigned)r2[0]) + __builtin_bit_cast(float, (unsigned)r2[1]) - b2[o];
             }

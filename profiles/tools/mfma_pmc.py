@@ -36,6 +36,12 @@ if dur:
     res["avg_launch_ms_in_this_pass"] = sum(dur) / len(dur) / 1e6
 flops = mean.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512.0
 res["mfma_flops_per_launch"] = flops
+bflops = mean.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) * 512.0     # the split-operand forward pass runs on the bf16 instruction
+if bflops:
+    res["mfma_bf16_flops_per_launch"] = bflops
+    if dur:
+        res["mfma_bf16_tflops"] = bflops / (sum(dur) / len(dur) * 1e-9) / 1e12
+        res["mfma_bf16_frac_of_dense_peak_2500"] = res["mfma_bf16_tflops"] / 2500.0
 if dur and flops:
     res["mfma_tflops"] = flops / (sum(dur) / len(dur) * 1e-9) / 1e12
     res["mfma_frac_of_fp32_matrix_peak_157.3"] = res["mfma_tflops"] / 157.3
