@@ -55,7 +55,7 @@ class ParallelTemperingBase:
     def __init__(self, use_langevin_gradients, learn_rate, traindata, testdata, topology, num_chains, maxtemp,
                  NumSample, swap_interval, langevin_prob, path, *, seed=None, device=None, devices=None, exchange="auto",
                  transport=None, waves_per_replica=0, schedule=0, groups_per_replica=0, trace_capacity=0, swap_rule=0,
-                 label_swap=False, shared_noise=True, write_files=True, io_threads=None):
+                 label_swap=False, shared_noise=True, write_files=True, io_threads=None, forward_bf16=0):
         # FNN chain variables (REG:491-494)
         self.traindata = traindata
         self.testdata = testdata
@@ -95,6 +95,9 @@ class ParallelTemperingBase:
         self.schedule = int(schedule)            # 0 auto, 1 cooperative, 2 speculative, 3 packed, 4 prefetching tree (include/ptnn.h)
         self.groups_per_replica = int(groups_per_replica)
         self.swap_rule = int(swap_rule)          # 0 = the reference's cascade; 1 = even/odd Metropolis exchange (not in the reference)
+        # forward pass on the matrix cores (nets of 24..64 or a multiple of 32 > 64 hidden units): 0 = fp32 accuracy on split bf16
+        # operands (default), 2 = the exact fp32 instruction (bit-identical to the other schedules), 1 = operands rounded to bf16 (study)
+        self.forward_bf16 = int(forward_bf16)
         # True (default): all chains read ONE noise tape -- what the reference's forked chains do, which all inherit the parent's
         # numpy / random state (REG:709-712); the only mode that meets every statistical parity bound against the
         # reference's own runs (tests: F9).  False: every (chain, step) has its own Philox counter, the statistically sounder
@@ -164,7 +167,7 @@ class ParallelTemperingBase:
             use_langevin=1 if self.use_langevin_gradients is True else 0, waves_per_replica=self.waves_per_replica,
             schedule=self.schedule, groups_per_replica=self.groups_per_replica, trace_capacity=self.trace_capacity,
             swap_rule=self.swap_rule, shared_noise=int(self.shared_noise), label_swap=int(self.label_swap),
-            l_prob=float(self.langevin_prob), learn_rate=float(self.learn_rate), step_w=0.025, step_eta=0.2,
+            forward_bf16=self.forward_bf16, l_prob=float(self.langevin_prob), learn_rate=float(self.learn_rate), step_w=0.025, step_eta=0.2,
             sigma_squared=25.0, nu_1=0.0, nu_2=0.0, seed=self.seed)
         if self.devices is not None and len(self.devices) > 1:
             from . import distributed

@@ -1223,6 +1223,48 @@ def test_baseline_replica_counts_against_oracle(name):
     s.close()
 
 
+SPLIT_CASES = {   # task, topo, data, R, Langevin, lr, maxtemp, S, si, expected forward_mfma
+    "ions_langevin_cooperative": (1, (34, 50, 2), "ions_small", 6, True, 0.01, 10, 40, 10, 2),   # 150 + 60 rows: split images NEXT TO the row-major image (the SGD epochs read it)
+    "ions_rw_32_hidden": (1, (34, 32, 2), "ions", 5, False, 0.01, 10, 45, 15, 2),           # one hidden tile, no tile split between the waves
+    "ions_rw_exact": (1, (34, 50, 2), "ions", 5, False, 0.01, 10, 45, 15, 1),               # forward_bf16 = 2
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(SPLIT_CASES))
+def test_split_forward_pass_against_oracle(name):
+    """The split-operand matrix-core forward pass of the cooperative kernel (and the exact one beside it) against the float64
+    oracle on the same tape: every trace row, swap log and counters, the kernel's log alpha inside the measured fp32 bound on every
+    step -- under Langevin proposals (the SGD epochs keep the row-major data image in LDS next to the split images), with a
+    single hidden tile, and with the exact fp32 instruction requested."""
+    task, topo, dname, R, lg, lr, maxtemp, S, si, want = SPLIT_CASES[name]
+    d = ds()
+    if dname == "ions_small":
+        train, test = d["ions_train"][:150], d["ions_test"][:60]
+    else:
+        train, test = d[dname + "_train"], d[dname + "_test"]
+    seed = 900 + R
+    pt = orc.PTOracle(task, topo, train, test, R, maxtemp, R * S, si, use_lg=lg, l_prob=0.5, lr=lr, seed=seed)
+    w0 = np.stack([rep.w for rep in pt.replicas]).astype(np.float32)
+    for rep, w in zip(pt.replicas, w0):
+        rep.__init__(task, topo, pt.train, pt.test, w.astype(np.float64), rep.T, S, lg, 0.5, lr, pt.tape, rep.gid)
+    o = parity.OracleRun(pt).run()
+    s = parity.make_sampler(task, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=lg, lr=lr, seed=seed,
+                            schedule=1, forward_bf16=2 if want == 1 else 0)
+    assert s.describe()["forward_mfma"] == want, s.describe()
+    s.set_state(w0, np.array(pt.temperatures, dtype=np.float32))
+    s.run(-1)
+    s.sync()
+    tr = s.traces()
+    nsw, tot, rounds = s.swap_stats()
+    assert rounds == pt.rounds_done and tot == pt.total_swap_proposals == rounds * (R - 1)
+    firsts = parity.check_run_against_oracle(s, tr, o, f"{name} ")
+    log = s.swap_log()
+    if all(f is None for f in firsts) and all((log[k] == np.array(pt.src_log[k])).all() for k in range(rounds)):
+        assert nsw == pt.num_swap
+    s.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["reg_cascade", "cls_cascade", "reg_evenodd"])
 def test_label_swapping_option(case):
