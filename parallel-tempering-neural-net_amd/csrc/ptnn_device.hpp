@@ -760,13 +760,22 @@ template <int TASK, bool WL, bool LEAN>
 __device__ __forceinline__ EvalSums reduce_eval(float a_tr, float b_tr, float c_tr, float a_te, float b_te, float c_te,
                                                 float* __restrict__ red, float& extra) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-    a_tr = wave_allsum(a_tr);
-    a_te = wave_allsum(a_te);
+    // all wave sums stage by stage (wave_allsum_n: the same operations per value as wave_allsum, the DPP latencies shared)
     if (TASK == TASK_CLS) {
-        b_tr = wave_allsum(b_tr); c_tr = wave_allsum(c_tr);
-        b_te = wave_allsum(b_te); c_te = wave_allsum(c_te);
+        float v[LEAN ? 7 : 6];
+        v[0] = a_tr; v[1] = a_te; v[2] = b_tr; v[3] = c_tr; v[4] = b_te; v[5] = c_te;
+        if (LEAN) v[LEAN ? 6 : 0] = extra;
+        wave_allsum_n(v);
+        a_tr = v[0]; a_te = v[1]; b_tr = v[2]; c_tr = v[3]; b_te = v[4]; c_te = v[5];
+        if (LEAN) extra = v[LEAN ? 6 : 0];
+    } else {
+        float v[LEAN ? 3 : 2];
+        v[0] = a_tr; v[1] = a_te;
+        if (LEAN) v[LEAN ? 2 : 0] = extra;
+        wave_allsum_n(v);
+        a_tr = v[0]; a_te = v[1];
+        if (LEAN) extra = v[LEAN ? 2 : 0];
     }
-    if (LEAN) extra = wave_allsum(extra);
     EvalSums s;
     if (WL || nw == 1) {
         s.a_tr = a_tr; s.b_tr = b_tr; s.c_tr = c_tr; s.a_te = a_te; s.b_te = b_te; s.c_te = c_te;
@@ -1523,7 +1532,11 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_split(const float* __restrict
                 if (half == 0) part[((size_t)t * Npad + n) * O + o] = tot;
             }
         };
+#if PTNN_ABLATE == 5
+        if (false) {
+#else
         if (rb0 < nrb) {
+#endif
             BFrag bcur, bnxt;
             load_b(rb0, bcur);
             int rb = rb0, nx = rb0 + rbstride;
@@ -1556,7 +1569,11 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_split(const float* __restrict
     float b2[O];
 #pragma unroll
     for (int o = 0; o < O; ++o) b2[o] = wl[oB2 + o];
+#if PTNN_ABLATE == 3
+    for (int n = threadIdx.x; n < 0; n += blockDim.x) {
+#else
     for (int n = threadIdx.x; n < Nall; n += blockDim.x) {
+#endif
         float tot[O];
 #pragma unroll
         for (int o = 0; o < O; ++o) {
@@ -1591,7 +1608,11 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_split(const float* __restrict
         else { a_te += a; b_te += bb; c_te += c; }
     }
     FW_DBG(2);
+#if PTNN_ABLATE == 4
+    EvalSums es_; es_.a_tr = a_tr; es_.b_tr = b_tr; es_.c_tr = c_tr; es_.a_te = a_te; es_.b_te = b_te; es_.c_te = c_te;
+#else
     const EvalSums es_ = reduce_eval<TASK, false, LEAN>(a_tr, b_tr, c_tr, a_te, b_te, c_te, red, extra);
+#endif
     FW_DBG(3);
     return es_;
 }
@@ -1758,7 +1779,9 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& d
         } else if (p.fw_mfma) {
             for (int j = tid; j < P; j += nthr) w_prop[j] = fmaf(p.step_w, noise[j], w_cur[j]);
             // the split image of W1 is formed from the same expression, so nobody waits for w_prop
+#if PTNN_ABLATE != 6
             if constexpr (SplitK<I>::OK) { if (split) split_weights<I>(sl.as, H, [&](int idx) { return fmaf(p.step_w, noise[idx], w_cur[idx]); }); }
+#endif
         } else {
             propose_build_fw<I, O>(w_cur, noise, p.step_w, w_prop, l.fw, H, p.FWS);
         }
@@ -1772,8 +1795,13 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& d
         if (i + 1 < step_end) {
             float* const nn = l.noise + (par ^ 1) * (PS + 8);
             float* const ns = l.scal + (par ^ 1) * (PS + 8);
+#if PTNN_ABLATE == 1
+            if (i == step_begin)                            // timing experiment: the tape of one step only (results are garbage)
+#endif
+            {
             if (!tape_one_wave) tape_step(p, gid, i + 1, nn, ns);
             else if (wave == nwaves - 1) tape_step<true>(p, gid, i + 1, nn, ns);
+            }
         }
         STAMP(3);                                         // next step's tape
         EvalSums es;
@@ -1808,6 +1836,9 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& d
         ring_pos = (ring_pos + 1 == p.trace_cap) ? 0 : ring_pos + 1;
         float* prow = p.tr_pos_w + tpos * (size_t)p.PW;
         const float* const w_rec = wbuf + o_rec;
+#if PTNN_ABLATE == 2
+        if (i == step_begin)
+#endif
         for (int j = tid; j < p.PW; j += nthr) prow[j] = (j < P) ? w_rec[j] : 0.0f;
         if (tid == 0) {
             store_trace_row(p.tr_scal + tpos * TR_COUNT, (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp /* REG:391 / CLS:404 */,
