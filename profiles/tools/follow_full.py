@@ -22,7 +22,10 @@ FULL = {
     "mackey64": (0, (4, 10, 1), "mackey", 64, True, 0.1, 2, 10000, 100),
     "ionosphere256": (1, (34, 50, 2), "ions", 256, False, 0.01, 10, 3000, 100),
 }
+ONLY = os.environ.get("FOLLOW_ONLY")                       # e.g. FOLLOW_ONLY=ionosphere256
 for name, (task, topo, dname, R, lg, lr, mt, S, si) in FULL.items():
+    if ONLY and name not in ONLY.split(","):
+        continue
     t0 = time.time()
     rep = tf.followed_run(task, topo, dname, R, lg, lr, mt, S, si, 1, f"{name} full ", shared_noise=1)
     rep["workload"], rep["S"], rep["seconds"] = name, S, round(time.time() - t0, 1)
