@@ -2653,7 +2653,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
 // res: the current state vector is kept in LDS next to the proposal (matrix-core layout only: there the flat image IS the proposal)
 __host__ __device__ inline size_t wide_lds_floats(int H, int FWS, int O, int PS, bool res = false) {
     const size_t img = (fw_floats(H, FWS) > (size_t)PS) ? fw_floats(H, FWS) : (size_t)PS;   // packed or flat image
-    return img + (res ? (size_t)PS : 0) + MAX_WAVES * 8 + 4 * MAX_WAVES * (size_t)((O + 3) & ~3) + 16 + 6 * 8;   // partial sums of up to two epochs; + per-slot scalars of a window (WIDE_WINDOW = 8)
+    return img + (res ? (size_t)PS : 0) + MAX_WAVES * 8 + 4 * MAX_WAVES * (size_t)((O + 3) & ~3) + 16 + 6 * 16;   // partial sums of up to two epochs; + per-slot scalars of a window (WIDE_WINDOW = 16)
 }
 __host__ __device__ inline size_t wide_img_floats(int H, int FWS, int PS) {
     return (fw_floats(H, FWS) > (size_t)PS) ? fw_floats(H, FWS) : (size_t)PS;
@@ -3299,7 +3299,7 @@ __device__ __forceinline__ EvalSums wide_forward(const SegParams& p, const float
 // step reads it from LDS and hands back its share of |w - w_prop_gd|^2 from registers.  With compact traces (p.compact) a
 // rejected step moves no vector at all: per step a random-walk proposal touches global memory for nothing but the shared data
 // image, a Langevin one reads the cached epoch (70 KB) and writes its own (70 KB).  It was 280 - 560 KB per step and group.
-constexpr int WIDE_WINDOW = 8;
+constexpr int WIDE_WINDOW = 16;
 template <int TASK, int I, int O, bool RES>
 __device__ __forceinline__ void segment_wide_body(const SegParams& p, const SegDyn& dyn, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -12,7 +12,7 @@ train, test, _ = bench.load_data(wl["data"])
 names = ["prologue", "tape", "gd recompute", "proposal+sweep", "eval+MH", "publish", "wait wg", "gather", "commit"]
 for use_lg in (True, False):
     w = dict(wl, lg=use_lg)
-    lad = bench.Ladder(w, argparse.Namespace(waves=4, schedule=2, groups=4, bf16=False), train, test, 0, 1, 0)
+    lad = bench.Ladder(w, argparse.Namespace(waves=4, schedule=2, groups=4, bf16=False, shared_noise=1), train, test, 0, 1, 0)
     s = lad.s
     lad.whole_run(); s.debug_stamps()
     t0 = time.perf_counter(); lad.whole_run(); dt = time.perf_counter() - t0
