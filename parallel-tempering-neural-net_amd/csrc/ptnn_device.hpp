@@ -1909,6 +1909,18 @@ __device__ __forceinline__ bool granule_wait(const granule_t* g, unsigned epoch,
 }
 
 
+// Work-groups are dispatched round-robin to the 8 XCDs (each with its own L2).  The work-groups of ONE replica exchange records
+// every round, so each XCD is given a contiguous range of logical blocks: a replica's groups then share an L2 (when the grid is a
+// multiple of 8 and the replicas per XCD come out whole; otherwise the plain order).
+__device__ __forceinline__ int xcd_block(int G) {
+    const int b = blockIdx.x, nb = gridDim.x;
+#if defined(PTNN_NO_XCD_MAP)
+    return b;
+#else
+    return (G > 1 && (nb & 7) == 0 && ((nb >> 3) % G) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;   // G == 1: block = replica, as the one-group bodies take it
+#endif
+}
+
 // p.G work-groups (one per CU) cooperate on one replica: work-group g, wave v owns speculative slot g*NW + v.
 // Every work-group keeps its own LDS copy of the chain state and applies the same commits, so the copies never
 // diverge; only the per-slot results (and the accepted proposal) cross CUs.
@@ -1920,7 +1932,8 @@ __device__ __forceinline__ void segment_spec_body(const SegParams& p, const SegD
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
     const int G = p.G;
-    const int r = blockIdx.x / G, grp = blockIdx.x - r * G;
+    const int lb = xcd_block(G);
+    const int r = lb / G, grp = lb - r * G;
     const int gid = p.first_global + r;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int wave = tid >> 6, lane = tid & 63, NW = nthr >> 6;
@@ -3305,7 +3318,8 @@ __device__ __forceinline__ void segment_wide_body(const SegParams& p, const SegD
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int OP = (O + 3) & ~3;
     const int G = p.G;
-    const int r = blockIdx.x / G, grp = blockIdx.x - r * G;
+    const int lb = xcd_block(G);
+    const int r = lb / G, grp = lb - r * G;
     const int gid = p.first_global + r;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int P = p.P, PS = p.PS, H = p.H;
@@ -4010,7 +4024,8 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int G = p.G;                                     // 2^D - 1
     const int D = 31 - __clz(G + 1);
-    const int r = blockIdx.x / G, g = blockIdx.x - r * G;
+    const int lb = xcd_block(G);
+    const int r = lb / G, g = lb - r * G;
     const int node = g + 1, depth = 31 - __clz(node);      // heap index, level (root: 0)
     const int gid = p.first_global + r;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -4470,7 +4485,7 @@ __device__ __forceinline__ void persistent_loop(const SegParams& p0, const int s
         if (!handoff || !swap_inside) break;
         pp = persist_args();
         if (!grid_barrier(pp->barrier, pp->nblocks, ++phase, p.error_flag)) { if (threadIdx.x == 0) atomicAdd(p.error_flag, 1); return; }
-        if ((int)blockIdx.x % p.G == 0) {
+        if (xcd_block(p.G) % p.G == 0) {                              // the bodies' own (replica, group) of this work-group
 #if defined(__HIP_DEVICE_COMPILE__)
             SwapParams sp = pp->sp;
 #else
@@ -4482,7 +4497,7 @@ __device__ __forceinline__ void persistent_loop(const SegParams& p0, const int s
             sp.label_cur = pp->label[lflip]; sp.slot_cur = pp->slot_of[lflip];
             sp.label_next = pp->label[lflip ^ 1]; sp.slot_next = pp->slot_of[lflip ^ 1];
             sp.canonical = (p.switch_step >= 0 && cur - 1 >= p.switch_step) ? 1 : 0;
-            swap_block(sp, round, 3, (int)blockIdx.x / p.G, smem);
+            swap_block(sp, round, 3, xcd_block(p.G) / p.G, smem);
         }
         if (pp->sp.label_mode) lflip ^= 1; else flip ^= 1;
         round += 1;
