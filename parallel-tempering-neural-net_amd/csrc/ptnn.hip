@@ -185,7 +185,7 @@ seg_fn segment_function(const ptnn_handle* h) {
     const Shape* sh = h->shape;
     if (h->wide) return h->wide_res ? sh->seg_wide_res : sh->seg_wide;
     if (h->tree) return sh->tree;
-    if (h->packed) return sh->pack;
+    if (h->packed) return h->groups > 1 ? sh->packm : sh->pack;
     return h->speculative ? sh->spec : sh->seg;
 }
 
@@ -231,7 +231,7 @@ int launch_segment(ptnn_handle* h, int begin, int end, bool swap_inside = false,
     PersistParams pp{};
     pp.end = end; pp.swap_inside = swap_inside ? 1 : 0; pp.task = h->cfg.task; pp.si = h->cfg.swap_interval;
     pp.round0 = h->rounds_done; pp.flip0 = h->flip; pp.lflip0 = h->lflip;
-    const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
+    const int grid = h->cfg.n_replicas_local * ((h->speculative || h->tree || h->wide) ? h->groups : 1);   // packed: groups > 1 only for the multi-CU variant
     pp.nblocks = grid; pp.barrier = h->d_barrier;
     for (int b = 0; b < 2; ++b) {
         pp.state[b] = h->d_state[b]; pp.gd[b] = h->d_gd_w[b]; pp.gd_valid[b] = h->d_gd_valid[b];
@@ -369,10 +369,10 @@ int resolve_persistent(ptnn_handle* h) {
     h->persistent = false;
     const char* e = std::getenv("PTNN_PERSISTENT");
     if ((e && e[0] == '0') || h->cfg.shared_device) return 0;     // grid barriers want every work-group resident: not on a shared GPU
-    const int G = (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
+    const int G = ((h->speculative || h->tree || h->wide) ? h->groups : 1);
     if (G > 1 && !(e && e[0] == '1')) return 0;
     // kernels compiled without the interval loop (ptnn_device.hpp: persistent_loop<false>)
-    if ((h->speculative && !h->packed) || h->tree) return 0;
+    if ((h->speculative && !h->packed) || h->tree || (h->packed && h->groups > 1)) return 0;
     if (h->packed && !(h->shape->loops & 2)) return 0;
     if (!h->wide && !h->packed && !h->speculative && !(h->shape->loops & 1)) return 0;
     const size_t swap_lds = (size_t)(3 * h->cfg.n_replicas_global + 1) * sizeof(float);
@@ -384,7 +384,7 @@ int resolve_persistent(ptnn_handle* h) {
     if (int rc = raise_lds_limit(fn, h->seg_lds)) return rc;
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, h->nthreads, h->seg_lds));
-    const long long grid = (long long)h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
+    const long long grid = (long long)h->cfg.n_replicas_local * ((h->speculative || h->tree || h->wide) ? h->groups : 1);
     h->persistent = grid <= (long long)per_cu * h->num_cus;
     return 0;
 }
@@ -694,20 +694,45 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         const bool fits = H <= 16 && pk <= LDS_MAX;
         if (sched == PTNN_SCHED_PACKED && !fits)
             return fail(-3, "the packed schedule needs n_hidden <= 16 and %zu B of LDS <= 160 KiB", pk);
-        // 16-lane groups give 8 slots per round: with CUs to spare, 4 CUs x 4 waves per replica (16 slots) are still quicker
-        // (Mackey-Glass 4-10-1, 64 replicas: 13.7 M vs 12.9 M samples/s), so the wider groups are taken when replicas are many
-        const bool pays = (H <= 8) || h->cfg.n_replicas_local * 4 > h->num_cus;
+        // 16-lane groups give 8 slots per round on one CU.  With CUs to spare the packed round runs on 2 or 4 CUs per replica (16 / 32
+        // slots per round, segment_packm_kernel): Mackey-Glass 4-10-1, 64 replicas needs 18.7 / 13.6 / 11.6 rounds per swap interval
+        // with 8 / 16 / 32 slots (profiles/r03_window_sim.jsonl) and a packed round is shorter than the multi-CU speculative one (the
+        // forward passes run beside the epochs).  groups_per_replica = 1, 2, 4 decides otherwise; $PTNN_PACK_MULTI=0 keeps one CU.
+        int pack_groups = 1;
+        const size_t pkm = pack_multi_lds_floats(Nall, IPY, h->PS, H, h->FWS, pack_slots(4)) * sizeof(float);
+        const char* pm_env = std::getenv("PTNN_PACK_MULTI");
+        if (h->pk_nred == 4 && fits && pkm <= LDS_MAX && h->cfg.use_langevin && !h->cfg.shared_device && !(pm_env && pm_env[0] == '0') &&
+            (sched == PTNN_SCHED_PACKED || h->cfg.schedule == PTNN_SCHED_AUTO) && h->cfg.waves_per_replica == 0) {
+            const int Rl_ = h->cfg.n_replicas_local, want = h->cfg.groups_per_replica;
+            if (want == 2 || want == 4) pack_groups = want;
+            else if (want == 0) { if (Rl_ * 4 <= h->num_cus) pack_groups = 4; else if (Rl_ * 2 <= h->num_cus) pack_groups = 2; }
+        }
+        const bool pays = (H <= 8) || pack_groups > 1 || h->cfg.n_replicas_local * 4 > h->num_cus;
         if (sched == PTNN_SCHED_PACKED ||
             (h->cfg.schedule == PTNN_SCHED_AUTO && sched == PTNN_SCHED_SPECULATIVE && fits && pays && h->cfg.use_langevin &&
-             h->cfg.waves_per_replica == 0 && h->cfg.groups_per_replica == 0)) {
-            h->packed = true; h->speculative = true; h->groups = 1;
+             h->cfg.waves_per_replica == 0 && (h->cfg.groups_per_replica == 0 || pack_groups > 1))) {
+            h->packed = true; h->speculative = true; h->groups = pack_groups;
             // eight waves (forward passes two to a SIMD) while every replica has a CU to itself, four beyond that; an explicit
             // waves_per_replica of 4 or 8 decides otherwise
             const int pkw = (h->cfg.waves_per_replica == 4 || h->cfg.waves_per_replica == 8) ? h->cfg.waves_per_replica
                             : (h->cfg.n_replicas_local <= h->num_cus ? PK_WAVES : 4);
-            h->nthreads = pkw * WAVE;
-            h->seg_lds = pk;
+            h->nthreads = (pack_groups > 1) ? PK_WAVES * WAVE : pkw * WAVE;
+            h->seg_lds = (pack_groups > 1) ? pkm : pk;
             sched = PTNN_SCHED_PACKED;
+            if (pack_groups > 1) {                              // exchange buffers of the multi-CU variant (segment_spec_body's layout)
+                const int Rl_ = h->cfg.n_replicas_local;
+                if (h->d_xslots) { HIP_TRY(hipFree(h->d_xslots)); h->d_xslots = nullptr; }
+                if (h->d_xw) { HIP_TRY(hipFree(h->d_xw)); h->d_xw = nullptr; }
+                if (h->d_xverdict) { HIP_TRY(hipFree(h->d_xverdict)); h->d_xverdict = nullptr; }
+                const size_t ns = (size_t)Rl_ * 2 * MAX_SLOTS * SL_COUNT, nx = (size_t)Rl_ * 2 * pack_groups * 2 * h->PS, nvd = (size_t)Rl_ * 2 * MAX_SLOTS;
+                HIP_TRY(hipMalloc(&h->d_xslots, ns * sizeof(unsigned long long)));
+                HIP_TRY(hipMalloc(&h->d_xw, nx * sizeof(unsigned long long)));
+                HIP_TRY(hipMalloc(&h->d_xverdict, nvd * sizeof(unsigned long long)));
+                HIP_TRY(hipMemset(h->d_xslots, 0, ns * sizeof(unsigned long long)));
+                HIP_TRY(hipMemset(h->d_xw, 0, nx * sizeof(unsigned long long)));
+                HIP_TRY(hipMemset(h->d_xverdict, 0, nvd * sizeof(unsigned long long)));
+                h->epoch_base = 1;                              // tag 0 = never written
+            }
         }
     }
     int nw = h->cfg.waves_per_replica;
@@ -863,8 +888,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
     if (h->d_data) { HIP_TRY(hipFree(h->d_data)); h->d_data = nullptr; }
     HIP_TRY(hipMalloc(&h->d_data, packed.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(h->d_data, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (int rc = raise_lds_limit(reinterpret_cast<const void*>(h->tree ? h->shape->tree : (h->packed ? h->shape->pack : (h->speculative ? h->shape->spec : h->shape->seg))),
-                                 h->seg_lds)) return rc;
+    if (int rc = raise_lds_limit(reinterpret_cast<const void*>(segment_function(h)), h->seg_lds)) return rc;
     if (int rc = raise_lds_limit(reinterpret_cast<const void*>(h->shape->model), h->model_lds)) return rc;
     if (int rc = resolve_persistent(h)) return rc;
     h->have_data = true;
@@ -1625,16 +1649,16 @@ int ptnn_tape(ptnn_handle* h, int replica, int step, float* noise, float* scal) 
 int ptnn_describe(ptnn_handle* h, char* buf, int nbytes) {
     if (!h || !buf || nbytes < 1) return fail(-1, "bad argument");
     if (!h->have_data) return fail(-1, "ptnn_set_data has not been called (the schedule depends on the data set)");
-    const char* kern = h->wide ? (h->wide_res ? "segment_wide_res_kernel" : "segment_wide_kernel") : (h->tree ? "segment_tree_kernel" : (h->packed ? "segment_pack_kernel" : (h->speculative ? "segment_spec_kernel" : "segment_kernel")));
+    const char* kern = h->wide ? (h->wide_res ? "segment_wide_res_kernel" : "segment_wide_kernel") : (h->tree ? "segment_tree_kernel" : (h->packed ? (h->groups > 1 ? "segment_packm_kernel" : "segment_pack_kernel") : (h->speculative ? "segment_spec_kernel" : "segment_kernel")));
     const void* fn = reinterpret_cast<const void*>(segment_function(h));
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, h->nthreads, h->seg_lds));
     hipFuncAttributes fa{};
     HIP_TRY(hipFuncGetAttributes(&fa, fn));
-    const int grid = h->cfg.n_replicas_local * (((h->speculative && !h->packed) || h->tree || h->wide) ? h->groups : 1);
+    const int grid = h->cfg.n_replicas_local * ((h->speculative || h->tree || h->wide) ? h->groups : 1);
     // tree: the steps committed per round (its depth)
-    const int slots = h->tree ? tree_depth(h->groups) : (h->wide ? (h->groups > 1 && h->cfg.use_langevin ? 8 : h->groups) : !h->speculative ? 1 : (h->packed ? pack_slots(h->pk_nred) : h->groups * (h->nthreads / WAVE)));
+    const int slots = h->tree ? tree_depth(h->groups) : (h->wide ? (h->groups > 1 && h->cfg.use_langevin ? 8 : h->groups) : !h->speculative ? 1 : (h->packed ? pack_slots(h->pk_nred) * h->groups : h->groups * (h->nthreads / WAVE)));
     const int n = std::snprintf(buf, (size_t)nbytes,
                                 "{\"kernel\": \"ptnn::%s<%d,%d,%d>\", \"schedule\": \"%s\", \"grid_blocks\": %d, \"block_threads\": %d, "
                                 "\"lds_bytes\": %zu, \"groups_per_replica\": %d, \"slots_per_round\": %d, \"num_cus\": %d, "

@@ -2333,12 +2333,25 @@ __host__ __device__ inline size_t pack_lds_floats(int Nall, int IPY, int PS, int
     return (size_t)(Nall + 2) * IPY + 4 * (size_t)PS + MAX_WAVES * 8 + (size_t)nslots * SL_COUNT +
            (size_t)nslots * pack_slot_floats(PS) + pack_ring_floats(PS, nslots) + (size_t)PK_WAVES * fw_floats(H, FWS);
 }
+// Several CUs per replica (MULTI, 16-lane groups only): every work-group runs a packed round over ITS PK_SLOTS slots of a window of
+// G x PK_SLOTS steps; the ring holds twice the widest window (G <= PK_MULTI_MAXG), plus a staging area for the accepted step of
+// another work-group {proposal, its epoch, slot scalars} and the groups' verdicts.
+constexpr int PK_MULTI_MAXG = 4;
+__host__ __device__ inline size_t pack_multi_lds_floats(int Nall, int IPY, int PS, int H, int FWS, int nslots) {
+    return pack_lds_floats(Nall, IPY, PS, H, FWS, nslots) + pack_ring_floats(PS, (PK_MULTI_MAXG - 1) * nslots) + 2 * (size_t)PS + SL_COUNT + 8;
+}
 
-template <int TASK, int I, int O, int PK_NRED>
+template <int TASK, int I, int O, int PK_NRED, bool MULTI = false>
 __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegDyn& dyn, const int step_begin, const int n_steps) {
     constexpr int PK_NG = WAVE >> PK_NRED, PK_SLOTS = pack_slots(PK_NRED);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int r = blockIdx.x;
+    // MULTI: p.G work-groups (CUs) per replica, work-group grp owns slots [grp PK_SLOTS, (grp + 1) PK_SLOTS) of a window of KT steps;
+    // all of them keep the chain state and apply the same commits (segment_spec_body's protocol: verdicts and the accepted step
+    // cross CUs as {tag, value} granules)
+    const int G = MULTI ? p.G : 1;
+    const int lb = MULTI ? xcd_block(G) : (int)blockIdx.x;
+    const int r = MULTI ? lb / G : lb, grp = MULTI ? lb - r * G : 0;
+    const int KT = G * PK_SLOTS, s0 = grp * PK_SLOTS;
     const int gid = p.first_global + r;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -2358,10 +2371,20 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
     // RING = 2 PK_SLOTS steps (step j lives in entry j mod RING): at the start of a round the ring holds steps [i, i + RING)
     // minus what the previous round committed, and the forward-pass waves refill it while the sweep waves are still sweeping.
     // The tape is never on the critical path of a round.
-    constexpr int RING = 2 * PK_SLOTS;
+    constexpr int RING = (MULTI ? 2 * PK_MULTI_MAXG : 2) * PK_SLOTS;
     float* ring_n = q; q += (size_t)RING * PS;
     float* ring_s = q; q += (size_t)RING * 4;
     float* my_fw = q + (size_t)wave * fw_floats(H, p.FWS);
+    q += (size_t)PK_WAVES * fw_floats(H, p.FWS);
+    float* win_v = q; q += MULTI ? 2 * (size_t)PS : 0;      // MULTI: the accepted step of another work-group {proposal, its SGD epoch}
+    float* win_s = q; q += MULTI ? SL_COUNT : 0;            //        its slot scalars
+    float* gverd = q;                                       //        the groups' verdicts of this round (first accepted local slot, or -1)
+    granule_t* const xv = MULTI ? p.xverdict + (size_t)r * 2 * MAX_SLOTS : nullptr;
+    granule_t* const xsl = MULTI ? p.xslots + (size_t)r * 2 * MAX_SLOTS * SL_COUNT : nullptr;
+    granule_t* const xwv = MULTI ? p.xw + (size_t)r * 2 * G * 2 * PS : nullptr;
+    unsigned epoch = dyn.epoch_base;
+    int xpar = 0;
+    bool failed = false;
     auto s_prop = [&](int s_) { return sl0 + (size_t)s_ * SLF; };
     auto s_pgd = [&](int s_) { return sl0 + (size_t)s_ * SLF + PS; };
 
@@ -2451,7 +2474,8 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
     fill_ring(step_begin, step_begin + RING, wave, nwaves);
     int ring_hi = step_begin + RING;                        // first step whose tape is not in the ring yet
     __syncthreads();
-    while (i < end) {
+    while (i < end && !failed) {
+        if (MULTI) { epoch += 1; }
         if (i == p.switch_step) {
             if (wave == 0) {
                 build_fw<I, O, true>(w_cur, my_fw, H, p.FWS);
@@ -2465,8 +2489,9 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
             lik = uni_f(red[0]);
             __syncthreads();
         }
-        int k = min(PK_SLOTS, end - i);
-        if (p.switch_step > i) k = min(k, p.switch_step - i);
+        int kt = min(KT, end - i);                          // steps of this round's window (all work-groups of the replica)
+        if (p.switch_step > i) kt = min(kt, p.switch_step - i);
+        const int k = MULTI ? max(0, min(PK_SLOTS, kt - s0)) : kt;   // ... of which this work-group computes slots s0 .. s0 + k - 1
 #ifdef PTNN_STAMPS
         stamp_rounds += 1;
 #endif
@@ -2476,7 +2501,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
             gd_valid = 1;
             __syncthreads();
         }
-        const int rpos0 = i % RING;                         // ring entry of slot 0 (= step i)
+        const int rpos0 = (i + s0) % RING;                  // ring entry of this work-group's slot 0 (= step i + s0)
         auto s_noise = [&](int s_) { int e_ = rpos0 + s_; if (e_ >= RING) e_ -= RING; return ring_n + (size_t)e_ * PS; };
         auto s_scal = [&](int s_) { int e_ = rpos0 + s_; if (e_ >= RING) e_ -= RING; return ring_s + e_ * 4; };
         STAMP(1);
@@ -2501,7 +2526,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
 #endif
         if (ev_i >= 0) {
             for (int s_ = ev_i; s_ < k; s_ += ev_n) {
-                const int j = i + s_;
+                const int j = i + s0 + s_;
                 const float adapttemp = (p.switch_step >= 0 && j >= p.switch_step) ? 1.0f : T;
                 const float* sc_ = s_scal(s_);
                 const bool lg = sweeping && (sc_[0] < p.l_prob);
@@ -2574,39 +2599,95 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
         STAMP(5);                                           // MH
         // commit the prefix up to and including the first accepted step
         const bool f_acc = (lane < k) && (slots[lane * SL_COUNT + SL_ACCEPT] != 0.0f);
-        const bool f_lg = (lane < k) && (slots[lane * SL_COUNT + SL_LG] != 0.0f);
-        const unsigned long long bal_acc = __ballot(f_acc), bal_lg = __ballot(f_lg);
-        const int m = bal_acc ? (__ffsll((long long)bal_acc) - 1) : k;
-        const int ncommit = (m < k) ? m + 1 : k;
-        for (int item = tid; item < ncommit * p.PW; item += nthr) {  // trace rows: all (slot, element) pairs at once
-            const int s_ = (int)(((float)item + 0.5f) * inv_PW), e = item - s_ * p.PW;
-            int tp = tpos0 + s_;
-            if (tp >= p.trace_cap) tp -= p.trace_cap;
-            p.tr_pos_w[(trow + (size_t)tp) * (size_t)p.PW + e] = (e < P) ? ((s_ == m) ? s_prop(s_) : rec_w)[e] : 0.0f;
+        const unsigned long long bal_acc = __ballot(f_acc);
+        const int ml = bal_acc ? (__ffsll((long long)bal_acc) - 1) : -1;          // first accepted LOCAL slot, or none
+        int m = (ml >= 0) ? s0 + ml : kt;                                           // first accepted step of the window (slot index)
+        const float* sm = slots + (ml >= 0 ? ml : 0) * SL_COUNT;                    // its scalars ...
+        const float* wacc = s_prop(ml >= 0 ? ml : 0);                               // ... and vectors {proposal, its epoch}
+        if constexpr (MULTI) {
+            // every work-group posts its verdict; one with an accepted slot posts that slot's scalars and vectors with it (it may not
+            // be the window's first: the readers take the winner's only)
+            granule_t* const xv_r = xv + (size_t)xpar * MAX_SLOTS;
+            if (tid == 0) granule_store(xv_r + grp, epoch, (float)ml);
+            if (ml >= 0) {
+                if (tid < SL_COUNT) granule_store(xsl + ((size_t)xpar * MAX_SLOTS + grp) * SL_COUNT + tid, epoch, sm[tid]);
+                granule_t* const xo = xwv + ((size_t)xpar * G + grp) * 2 * PS;
+                for (int e = tid; e < 2 * PS; e += nthr) granule_store(xo + e, epoch, wacc[e]);
+            }
+            if (tid < G) {
+                float v = 0.0f;
+                if (!granule_wait(xv_r + tid, epoch, v)) v = -2.0f;
+                gverd[tid] = v;
+            }
+            __syncthreads();
+            int win = -1;
+            m = kt;
+            for (int g_ = 0; g_ < G; ++g_) {
+                const float v = gverd[g_];
+                if (v == -2.0f) failed = true;
+                const int cand = (v >= 0.0f) ? g_ * PK_SLOTS + (int)v : kt;
+                if (cand < m) { m = cand; win = g_; }
+            }
+            if (failed) break;
+            if (win >= 0 && win != grp) {                       // the accepted step was computed elsewhere: fetch it
+                bool ok = true;
+                if (tid < SL_COUNT) {
+                    float v;
+                    ok = granule_wait(xsl + ((size_t)xpar * MAX_SLOTS + win) * SL_COUNT + tid, epoch, v);
+                    win_s[tid] = v;
+                }
+                const granule_t* const xi = xwv + ((size_t)xpar * G + win) * 2 * PS;
+                for (int e = tid; e < 2 * PS; e += nthr) {
+                    float v;
+                    ok = granule_wait(xi + e, epoch, v) && ok;
+                    win_v[e] = v;
+                }
+                failed = __syncthreads_or(ok ? 0 : 1) != 0;
+                if (failed) break;
+                sm = win_s; wacc = win_v;
+            }
+            xpar ^= 1;
         }
-        if (tid < ncommit) {
+        const int ncommit = (m < kt) ? m + 1 : kt;
+        const int nloc = max(0, min(k, ncommit - s0));          // of them this work-group's own slots: it writes their trace rows
+        for (int item = tid; item < nloc * p.PW; item += nthr) { // trace rows: all (slot, element) pairs at once
+            const int s_ = (int)(((float)item + 0.5f) * inv_PW), e = item - s_ * p.PW;
+            int tp = tpos0 + s0 + s_;
+            if (tp >= p.trace_cap) tp -= p.trace_cap;
+            p.tr_pos_w[(trow + (size_t)tp) * (size_t)p.PW + e] = (e < P) ? ((s0 + s_ == m) ? s_prop(s_) : rec_w)[e] : 0.0f;
+        }
+        if (tid < nloc) {
             const int s_ = tid;
-            const bool acc_me = (s_ == m);
+            const bool acc_me = (s0 + s_ == m);
             const float* sl = slots + s_ * SL_COUNT;
-            int tp = tpos0 + s_;
+            int tp = tpos0 + s0 + s_;
             if (tp >= p.trace_cap) tp -= p.trace_cap;
             const size_t tpos = trow + (size_t)tp;
             store_trace_row(p.tr_scal + tpos * TR_COUNT, (TASK == TASK_REG) ? sl[SL_LIKPROP] : sl[SL_LIKPROP] * sl[SL_ADAPT],
                             acc_me ? sl[SL_RM_TR] : rec_rmse_tr, acc_me ? sl[SL_RM_TE] : rec_rmse_te,
                             acc_me ? sl[SL_AC_TR] : rec_acc_tr, acc_me ? sl[SL_AC_TE] : rec_acc_te, nacc, sl[SL_LOGALPHA]);
         }
-        lg_count += __popcll(bal_lg & ((1ull << ncommit) - 1ull));
-        if (TASK == TASK_REG) tau_eta_last = uni_f(slots[(ncommit - 1) * SL_COUNT + SL_ETAPRO]);
-        if (m < k) {
+        if constexpr (MULTI) {
+            // Langevin coins and the last proposed eta of the committed steps, from the tape (every work-group holds the whole
+            // window's): the same expressions the forward waves evaluate for their own slots
+            const int e_ = (i + lane) % RING;
+            const bool f_lg = sweeping && (lane < ncommit) && (ring_s[e_ * 4] < p.l_prob);
+            lg_count += __popcll(__ballot(f_lg));
+            if (TASK == TASK_REG) tau_eta_last = uni_f(fmaf(p.step_eta, ring_s[((i + ncommit - 1) % RING) * 4 + 2], eta));
+        } else {
+            const bool f_lg = (lane < k) && (slots[lane * SL_COUNT + SL_LG] != 0.0f);
+            const unsigned long long bal_lg = __ballot(f_lg);
+            lg_count += __popcll(bal_lg & ((1ull << ncommit) - 1ull));
+            if (TASK == TASK_REG) tau_eta_last = uni_f(slots[(ncommit - 1) * SL_COUNT + SL_ETAPRO]);
+        }
+        if (m < kt) {
             // no barrier between the trace rows above and this update: they read rec_w, the new recorded row goes to rec_alt
-            const float* sm = slots + m * SL_COUNT;
             nacc += 1;
             lik = uni_f(sm[SL_LIKPROP]); prior_cur = uni_f(sm[SL_PRIORPROP]); eta = uni_f(sm[SL_ETAPRO]);
             rec_rmse_tr = uni_f(sm[SL_RM_TR]); rec_rmse_te = uni_f(sm[SL_RM_TE]);
             rec_acc_tr = uni_f(sm[SL_AC_TR]); rec_acc_te = uni_f(sm[SL_AC_TE]);
             lg_acc += (sm[SL_LG] != 0.0f) ? 1 : 0;
             gd_valid = sweeping ? 1 : 0;
-            const float* wacc = s_prop(m);
             for (int e = tid; e < P; e += nthr) {
                 const float v = wacc[e];
                 w_cur[e] = v; rec_alt[e] = v;
@@ -2633,6 +2714,11 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
     }
 #endif
 
+    if (failed) {
+        if (tid == 0) atomicAdd(p.error_flag, 1);           // a bounded spin ran out: the host reports it
+        return;
+    }
+    if (grp != 0) return;                                   // every work-group holds the same state: the first one writes it back
     for (int j = tid; j < PS; j += nthr) {
         gw[j] = (j == P) ? eta : w_cur[j];
         p.rec_w[(size_t)r * PS + j] = rec_w[j];
@@ -4531,6 +4617,12 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
         if (q.pk_nred == 4) segment_pack_body<TASK, I, O, 4>(q, d, b, n);
         else segment_pack_body<TASK, I, O, 3>(q, d, b, n);
     });
+}
+// the packed schedule over several CUs per replica (16-lane groups: 9 <= n_hidden <= 16): its own kernel, so that the one-CU kernel
+// (the benchmark's) keeps its registers and its code
+template <int TASK, int I, int O>
+__global__ void __launch_bounds__(PK_WAVES * WAVE) segment_packm_kernel(const SegParams p, const PersistParams pp, const int step_begin) {
+    persistent_loop<false>(p, step_begin, [](const SegParams& q, const SegDyn& d, int b, int n) { segment_pack_body<TASK, I, O, 4, true>(q, d, b, n); });
 }
 template <int TASK, int I, int O>
 __global__ void __launch_bounds__(MAX_THREADS) segment_tree_kernel(const SegParams p, const PersistParams pp, const int step_begin) {

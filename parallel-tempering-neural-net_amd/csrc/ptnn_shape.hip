@@ -15,4 +15,5 @@ extern "C" const Shape PTNN_SHAPE_SYMBOL = {PTNN_T, PTNN_I, PTNN_O,
                                             &model_wide_kernel<PTNN_T, PTNN_I, PTNN_O>, &segment_pack_kernel<PTNN_T, PTNN_I, PTNN_O>,
                                             &segment_tree_kernel<PTNN_T, PTNN_I, PTNN_O>, &segment_wide_res_kernel<PTNN_T, PTNN_I, PTNN_O>,
                                             (coop_has_loop<PTNN_T, PTNN_I, PTNN_O>() ? 1 : 0) | (pack_has_loop<PTNN_T, PTNN_I, PTNN_O>() ? 2 : 0),
-                                            SplitK<PTNN_I>::OK ? SplitK<PTNN_I>::CH : 0, SplitK<PTNN_I>::KR};
+                                            SplitK<PTNN_I>::OK ? SplitK<PTNN_I>::CH : 0, SplitK<PTNN_I>::KR,
+                                            &segment_packm_kernel<PTNN_T, PTNN_I, PTNN_O>};

@@ -28,5 +28,6 @@ struct Shape {
     seg_fn seg_wide_res;    // 64 < H <= 512, H % 32 == 0, state + proposal resident in LDS
     int loops;              // which kernels carry the interval loop of a persistent launch: bit 0 seg, bit 1 pack (wide: always; spec, tree: never)
     int split_ch, split_kr; // split-operand forward pass (SplitK<I>): 16-byte chunks per image row (0: not available for this n_in), fp32 k-steps
+    seg_fn packm;           // 9 <= H <= 16: packed schedule over several CUs per replica
 };
 }  // namespace ptnn

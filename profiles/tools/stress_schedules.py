@@ -53,6 +53,8 @@ def run(seed=0, ncase=30, verbose=True, shapes="timeseries+iris", oracle=False):
           variants = [dict(schedule=0, groups=1), dict(schedule=0, groups=2), dict(schedule=0, groups=4), dict(schedule=0), dict(schedule=1)]
       if H <= 16:
           variants.append(dict(schedule=3))
+          if H > 8 and lg:                            # 16-lane groups: the packed round on one, two, four CUs per replica
+              variants += [dict(schedule=3, groups=1), dict(schedule=3, groups=2), dict(schedule=3, groups=4)]
       if H < 24 or I < 6:
           variants.append(dict(schedule=1, waves=1))
       if H <= 64:

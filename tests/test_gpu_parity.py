@@ -363,6 +363,25 @@ def test_speculative_schedule_is_wave_count_invariant(case):
             assert (got[0][k] == ref[0][k]).all(), ("packed", k)
         for k in got[3]:
             assert (got[3][k] == ref[3][k]).all(), ("packed", k)
+    if 8 < topo[1] <= 16 and lg:
+        # ... and so does the packed round spread over 2 or 4 CUs per replica (segment_packm_kernel: 16 / 32 slots per round; the
+        # verdicts and the accepted step cross CUs), which the library picks by itself for such nets when CUs are to spare
+        for groups in (2, 4, 0):
+            s = parity.make_sampler(task, topo, d[name + "_train"], d[name + "_test"], R_local=R, R_global=R, first=0, S=S, si=si,
+                                    use_lg=lg, lr=lr, seed=77, schedule=3 if groups else 0, groups=groups)
+            info = s.describe()
+            assert info["kernel"].startswith("ptnn::segment_packm_kernel") and info["groups_per_replica"] == (groups or 4), info
+            assert info["slots_per_round"] == 8 * info["groups_per_replica"], info
+            s.set_state(w0, T)
+            s.run(-1)
+            s.sync()
+            got = (s.traces(), s.swap_stats(), s.swap_log().copy(), s.state())
+            s.close()
+            assert got[1] == ref[1] and (got[2] == ref[2]).all()
+            for k in got[0]:
+                assert (got[0][k] == ref[0][k]).all(), ("packed multi-CU", groups, k)
+            for k in got[3]:
+                assert (got[3][k] == ref[3][k]).all(), ("packed multi-CU", groups, k)
     assert ref is not None
 
 
