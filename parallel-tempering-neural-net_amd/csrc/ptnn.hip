@@ -699,13 +699,13 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         // with 8 / 16 / 32 slots (profiles/r03_window_sim.jsonl) and a packed round is shorter than the multi-CU speculative one (the
         // forward passes run beside the epochs).  groups_per_replica = 1, 2, 4 decides otherwise; $PTNN_PACK_MULTI=0 keeps one CU.
         int pack_groups = 1;
-        const size_t pkm = pack_multi_lds_floats(Nall, IPY, h->PS, H, h->FWS, pack_slots(4)) * sizeof(float);
+        const size_t pkm = pack_multi_lds_floats(Nall, IPY, h->PS, H, h->FWS, pack_slots(h->pk_nred)) * sizeof(float);
         const char* pm_env = std::getenv("PTNN_PACK_MULTI");
-        if (h->pk_nred == 4 && fits && pkm <= LDS_MAX && h->cfg.use_langevin && !h->cfg.shared_device && !(pm_env && pm_env[0] == '0') &&
+        if (fits && pkm <= LDS_MAX && h->cfg.use_langevin && !h->cfg.shared_device && !(pm_env && pm_env[0] == '0') &&
             (sched == PTNN_SCHED_PACKED || h->cfg.schedule == PTNN_SCHED_AUTO) && h->cfg.waves_per_replica == 0) {
             const int Rl_ = h->cfg.n_replicas_local, want = h->cfg.groups_per_replica;
-            if (want == 2 || want == 4) pack_groups = want;
-            else if (want == 0) { if (Rl_ * 4 <= h->num_cus) pack_groups = 4; else if (Rl_ * 2 <= h->num_cus) pack_groups = 2; }
+            if (want == 2 || want == 4) pack_groups = want;                       // (8-lane groups: on request only -- 16 slots on one CU already)
+            else if (want == 0 && h->pk_nred == 4) { if (Rl_ * 4 <= h->num_cus) pack_groups = 4; else if (Rl_ * 2 <= h->num_cus) pack_groups = 2; }
         }
         const bool pays = (H <= 8) || pack_groups > 1 || h->cfg.n_replicas_local * 4 > h->num_cus;
         if (sched == PTNN_SCHED_PACKED ||

@@ -4622,7 +4622,10 @@ __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_pack_kernel(const Seg
 // (the benchmark's) keeps its registers and its code
 template <int TASK, int I, int O>
 __global__ void __launch_bounds__(PK_WAVES * WAVE) segment_packm_kernel(const SegParams p, const PersistParams pp, const int step_begin) {
-    persistent_loop<false>(p, step_begin, [](const SegParams& q, const SegDyn& d, int b, int n) { segment_pack_body<TASK, I, O, 4, true>(q, d, b, n); });
+    persistent_loop<false>(p, step_begin, [](const SegParams& q, const SegDyn& d, int b, int n) {
+        if (q.pk_nred == 4) segment_pack_body<TASK, I, O, 4, true>(q, d, b, n);
+        else segment_pack_body<TASK, I, O, 3, true>(q, d, b, n);
+    });
 }
 template <int TASK, int I, int O>
 __global__ void __launch_bounds__(MAX_THREADS) segment_tree_kernel(const SegParams p, const PersistParams pp, const int step_begin) {

@@ -363,6 +363,19 @@ def test_speculative_schedule_is_wave_count_invariant(case):
             assert (got[0][k] == ref[0][k]).all(), ("packed", k)
         for k in got[3]:
             assert (got[3][k] == ref[3][k]).all(), ("packed", k)
+    if topo[1] <= 8 and lg:
+        # (8-lane groups: 16 slots fit one CU, several CUs are taken on request only -- measured slower on the benchmark's shape)
+        s = parity.make_sampler(task, topo, d[name + "_train"], d[name + "_test"], R_local=R, R_global=R, first=0, S=S, si=si,
+                                use_lg=lg, lr=lr, seed=77, schedule=3, groups=2)
+        assert s.describe()["kernel"].startswith("ptnn::segment_packm_kernel") and s.describe()["slots_per_round"] == 32
+        s.set_state(w0, T)
+        s.run(-1)
+        s.sync()
+        got = (s.traces(), s.swap_stats(), s.swap_log().copy(), s.state())
+        s.close()
+        assert got[1] == ref[1] and (got[2] == ref[2]).all()
+        for k in got[0]:
+            assert (got[0][k] == ref[0][k]).all(), ("packed on 2 CUs", k)
     if 8 < topo[1] <= 16 and lg:
         # ... and so does the packed round spread over 2 or 4 CUs per replica (segment_packm_kernel: 16 / 32 slots per round; the
         # verdicts and the accepted step cross CUs), which the library picks by itself for such nets when CUs are to spare
