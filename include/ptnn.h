@@ -58,7 +58,10 @@ typedef struct ptnn_config {
     int32_t groups_per_replica;   /* speculative schedule: work-groups (CUs) cooperating on one replica; 0 = auto
                                    * (as many of 1, 2, 4 as keeps replicas x groups <= number of CUs).  Tree schedule: 3, 7, 15
                                    * or 31 (0 = auto: the deepest tree up to 15 nodes that is resident).  Wide nets (n_hidden > 64):
-                                   * 1, 2 or 4 work-groups speculating over windows of steps (0 = auto: 4 or 2 where resident) */
+                                   * 1, 2 or 4 work-groups speculating over windows of steps (0 = auto: 4 or 2 where resident).
+                                   * Packed schedule: 1, 2 or 4 CUs, each running a packed round over its slots of one window
+                                   * (0 = auto: 4 or 2 where resident for 9 <= n_hidden <= 16, whose lane groups leave 8 slots per
+                                   * CU; 1 for n_hidden <= 8, which has its 16 slots on one CU) */
     int32_t trace_capacity;       /* rows per replica kept on the device (ring); 0 = all n_samples rows.  With a smaller
                                    * value the caller drains with ptnn_get_traces at least every trace_capacity steps */
     int32_t forward_bf16;         /* forward pass on the matrix cores (cooperative schedule with 24 <= n_hidden <= 64; wide nets with
