@@ -734,7 +734,7 @@ def test_shared_noise_option_matches_oracle(schedule):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["reg_packed", "reg_spec", "cls_coop", "wide_compact"])
+@pytest.mark.parametrize("case", ["reg_packed", "reg_spec", "cls_coop", "wide_compact", "reg_packed_4cus"])
 def test_checkpoint_resume_continues_bit_for_bit(case):
     """chains saved mid-run (between swap intervals and in the middle of one) and restored into a fresh handle
     produce the same trace rows, swap log and counters as the uninterrupted run.  wide_compact: a 32-96-1 net on the LDS-resident
@@ -745,6 +745,8 @@ def test_checkpoint_resume_continues_bit_for_bit(case):
     if case == "wide_compact":
         task, topo, lg, lr, mt, sched = orc.TASK_REG, (32, 96, 1), True, 0.1, 2, 0
         train, test = d["synth32_train"], d["synth32_test"]
+    elif case == "reg_packed_4cus":                             # Mackey-Glass 4-10-1: the packed round over 4 CUs per replica (auto)
+        task, topo, train, test, lg, lr, mt, sched = orc.TASK_REG, (4, 10, 1), d["mackey_train"], d["mackey_test"], True, 0.1, 2, 0
     elif case.startswith("reg"):
         task, topo, train, test, lg, lr, mt = orc.TASK_REG, (4, 5, 1), d["sunspot_train"], d["sunspot_test"], True, 0.1, 2
         sched = 0 if case == "reg_packed" else 2
@@ -761,6 +763,11 @@ def test_checkpoint_resume_continues_bit_for_bit(case):
         info = probe.describe()
         probe.close()
         assert info["lds_resident_state"] == 1 and info["compact_traces"] == 1, info
+    if case == "reg_packed_4cus":
+        probe = make()
+        info = probe.describe()
+        probe.close()
+        assert info["kernel"].startswith("ptnn::segment_packm_kernel") and info["groups_per_replica"] == 4, info
     full = make()
     full.set_state(np.stack([philox.initial_weights(seed, r, Pw) for r in range(R)]), ladder.temperatures(R, mt))
     full.run(-1)
