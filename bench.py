@@ -143,6 +143,19 @@ def _cpu_chain(args):
     return time.perf_counter() - t0, rep.posted_L()
 
 
+def _cpu_chain_c(args):
+    """The same chain in the C restatement (oracle/ptnn_oracle_c.c): MH steps 0 .. n_steps - 1 of one replica."""
+    gid, n_steps, train, test, T, topo = args
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ptnn_oracle as orc
+    import ptnn_oracle_c as orc_c
+    tape = orc.PhiloxTape(SEED)
+    rep = orc_c.CReplica(orc.TASK_REG, topo, train, test, tape.w_init(gid, n_param(topo)), T, n_steps + 1, True, 0.5, 0.1, SEED, gid)
+    t0 = time.perf_counter()
+    rep.run(0, n_steps)
+    return time.perf_counter() - t0, rep.posted_L()
+
+
 def usable_cores():
     """Host cores this process may actually use: the affinity mask and the cgroup CPU quota, not the machine's core count."""
     n = os.cpu_count() or 1
@@ -192,7 +205,22 @@ def cpu_baseline(wl, train, test, n_steps=101):
     src, nsw = orc.swap_cascade([L for _, L in res], orc.PhiloxTape(SEED).swap_uniforms(0, R - 1))
     wall = time.perf_counter() - t0
     value = R * n_steps / wall
-    return {"value": value, "unit": "samples/s", "cores": cores, "kind": "port",
+    # the plain-C restatement of the same oracle on the same cores, a whole run's worth of MH steps per replica (no swaps): what a compiled
+    # CPU port of the reference does (about 100 x the interpreted reference) -- reported beside the numpy port, which is the one
+    # BASELINE.md 3.2 relates to the reference
+    c_port = None
+    try:
+        n_c = 100 * (n_steps - 1) + 1
+        jobs_c = [(g, n_c, train, test, T[g], wl["topo"]) for g in range(R)]
+        t1 = time.perf_counter()
+        with ctx.Pool(cores) as pool:
+            res_c = pool.map(_cpu_chain_c, jobs_c, chunksize=1)
+        wall_c = time.perf_counter() - t1
+        c_port = {"value": R * n_c / wall_c, "unit": "samples/s", "cores": cores, "kind": "port (plain C, oracle/ptnn_oracle_c.c)",
+                  "sample": f"{R} replicas x MH steps 0..{n_c - 1}, {cores} processes, {sum(t for t, _ in res_c):.1f} s of CPU work"}
+    except Exception as e:                                      # noqa: BLE001  (no compiler on the box: the numpy leg stands alone)
+        c_port = {"error": repr(e)}
+    return {"value": value, "unit": "samples/s", "cores": cores, "kind": "port", "c_port": c_port,
             "port_over_reference": PORT_OVER_REFERENCE,
             "reference_equivalent": value / PORT_OVER_REFERENCE,
             "port_over_reference_source": "BASELINE.md 3.2 / DESIGN.md 8: the reference and the faithful oracle timed on identical work in "
@@ -537,6 +565,8 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
+            if isinstance(cpu.get("c_port"), dict) and cpu["c_port"].get("value"):
+                out["speedup_vs_c_port"] = value / cpu["c_port"]["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
