@@ -73,9 +73,23 @@ def load_datasets():
     d["ions_test"] = np.genfromtxt(os.path.join(cbase, "Ions", "Ions", "ftest.csv"), delimiter=",")[:, :-1]
     d["cancer_train"] = np.genfromtxt(os.path.join(cbase, "Cancer", "ftrain.txt"), delimiter=" ")[:, :-1]
     d["cancer_test"] = np.genfromtxt(os.path.join(cbase, "Cancer", "ftest.txt"), delimiter=" ")[:, :-1]
+    # BASELINE configs 1 and 3 name FIVE-input nets ("FNN 5-5-1", "FNN 5-10-1"); the shipped embedding has 4 lag inputs (SURVEY 8:
+    # "Input Neuron: 4").  The literal variant: the same scaled series re-embedded with window 6 (5 lags + target), stride 2,
+    # split like the shipped files (first int(0.6 n) rows train, last int(0.4 n) - 1 rows test)
+    for name in ("sunspot", "mackey"):
+        d[name + "5_train"], d[name + "5_test"] = reembed(d[name + "_scaled"], window=6, stride=2)
     # small sibling of BASELINE config 5: teacher FNN on uniform inputs, 32 features, targets in [0,1]
     d["synth32_train"], d["synth32_test"] = synthetic_regression(96, 64, 32, 96, seed=5)
     return d
+
+
+def reembed(series, window, stride):
+    """Rows series[stride k : stride k + window]; the shipped train/test files are this with window 5 (checked in
+    tests/test_host_cpu.py against the shipped Sunspot / Mackey / Lazer files)."""
+    series = np.asarray(series, dtype=np.float64).reshape(-1)
+    n = (series.shape[0] - window) // stride + 1
+    rows = np.stack([series[stride * k:stride * k + window] for k in range(n)])
+    return rows[:int(0.6 * n)], rows[n - (int(0.4 * n) - 1):]
 
 
 def synthetic_regression(n_rows, n_train, n_in, n_hidden, seed):
@@ -203,6 +217,8 @@ CASES = [  # (key, module, task, topology, dataset)
     ("cls_ions_34_50_2", "CLS", orc.TASK_CLS, [34, 50, 2], "ions"),
     ("reg_synth_32_96_1", "REG", orc.TASK_REG, [32, 96, 1], "synth32"),      # H > 64: the multi-wave (wide) kernels
     ("cls_ions_34_100_2", "CLS", orc.TASK_CLS, [34, 100, 2], "ions"),
+    ("reg_sunspot5_5_5_1", "REG", orc.TASK_REG, [5, 5, 1], "sunspot5"),       # BASELINE config 1's literal topology
+    ("reg_mackey5_5_10_1", "REG", orc.TASK_REG, [5, 10, 1], "mackey5"),       # BASELINE config 3's literal topology
 ]
 
 
@@ -215,8 +231,10 @@ def make_replica(modname, topo, train, test, T, S, use_lg, lr, l_prob, si, path,
                          FakeEvent(), FakeEvent())
 
 
-def gen_functions(ds, out):
+def gen_functions(ds, out, only=None):
     for key, modname, task, topo, dname in CASES:
+        if only and "functions_" + key not in only:
+            continue
         mod = REG if modname == "REG" else CLS
         train, test = ds[dname + "_train"], ds[dname + "_test"]
         P = orc.num_param(topo)
@@ -281,11 +299,15 @@ TRAJ = [  # key, module, task, topo, dataset, use_lg, lr, T, S, seed
     ("reg_rw_noswitch", "REG", orc.TASK_REG, [4, 5, 1], "sunspot", False, 0.1, 2.0, 57, 107),  # 0.6*57 not integral
     ("reg_lg_wide", "REG", orc.TASK_REG, [32, 96, 1], "synth32", True, 0.1, 1.2599210498948732, 30, 108),
     ("cls_lg_wide", "CLS", orc.TASK_CLS, [34, 100, 2], "ions", True, 0.01, 1.0, 30, 109),
+    ("reg_lg_sunspot5", "REG", orc.TASK_REG, [5, 5, 1], "sunspot5", True, 0.1, 1.2599210498948732, 100, 110),
+    ("reg_lg_mackey5", "REG", orc.TASK_REG, [5, 10, 1], "mackey5", True, 0.1, 1.5874010519681994, 60, 111),
 ]
 
 
-def gen_trajectories(ds, out):
+def gen_trajectories(ds, out, only=None):
     for key, modname, task, topo, dname, use_lg, lr, T, S, seed in TRAJ:
+        if only and "trajectory_" + key not in only:
+            continue
         train, test = ds[dname + "_train"], ds[dname + "_test"]
         P = orc.num_param(topo)
         tape = RefTape(seed)
@@ -367,11 +389,15 @@ SWAPTRAJ = [  # key, module, task, topo, dataset, use_lg, lr, R, maxtemp, NumSam
     ("reg_nophantom", "REG", orc.TASK_REG, [4, 5, 1], "sunspot", False, 0.1, 4, 2, 412, 10, 202),  # S=103
     ("cls", "CLS", orc.TASK_CLS, [4, 12, 3], "iris", False, 0.01, 4, 10, 400, 10, 203),      # S=100 phantom
     ("cls_nophantom", "CLS", orc.TASK_CLS, [4, 12, 3], "iris", True, 0.01, 5, 10, 515, 10, 204),   # S=103
+    # BASELINE config 1 as worded: Sunspot, FNN 5-5-1, 4 replicas, Langevin proposals, through the reference's own run_chains()
+    ("reg_sunspot5", "REG", orc.TASK_REG, [5, 5, 1], "sunspot5", True, 0.1, 4, 2, 400, 10, 205),
 ]
 
 
-def gen_swap_trajectories(ds, out):
+def gen_swap_trajectories(ds, out, only=None):
     for key, modname, task, topo, dname, use_lg, lr, R, maxtemp, NumSample, si, seed in SWAPTRAJ:
+        if only and "swap_trajectory_" + key not in only:
+            continue
         mod = REG if modname == "REG" else CLS
         train, test = ds[dname + "_train"], ds[dname + "_test"]
         tmp = tempfile.mkdtemp()
@@ -419,7 +445,7 @@ def gen_swap_trajectories(ds, out):
             for nm in ("rmse_train", "rmse_test", "acc_train", "acc_test"):
                 rec[f"{nm}_{g}"] = np.load(os.path.join(tmp, "predictions", f"{nm}_chain_{tn}.txt.npy"))
         np.savez_compressed(os.path.join(out, f"swap_trajectory_{key}.npz"), **rec)
-        if key == "reg":
+        if key == "reg" and not only:
             gen_layout(tmp, out)
         shutil.rmtree(tmp)
         print("F6", key, "swap_perc", float(res[8]), "num_swap", pt.num_swap, "/", pt.total_swap_proposals)
@@ -538,11 +564,12 @@ def main():
         gen_stats(ds, a.out, a.only)
         return
     np.savez_compressed(os.path.join(a.out, "datasets.npz"), **ds)
-    gen_ladder(a.out)
-    gen_cascade(a.out)
-    gen_functions(ds, a.out)
-    gen_trajectories(ds, a.out)
-    gen_swap_trajectories(ds, a.out)
+    if not a.only:                       # --only functions_<key> trajectory_<key> swap_trajectory_<key>: just those files (+ datasets.npz)
+        gen_ladder(a.out)
+        gen_cascade(a.out)
+    gen_functions(ds, a.out, a.only)
+    gen_trajectories(ds, a.out, a.only)
+    gen_swap_trajectories(ds, a.out, a.only)
 
 
 if __name__ == "__main__":

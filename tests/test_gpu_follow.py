@@ -56,6 +56,9 @@ WHOLE = {
     # (CLS:950-957: 9 inputs, 12 hidden units, 2 classes, random-walk), 10 chains as in its main()
     "lazer10": (0, (4, 5, 1), "lazer", 10, True, 0.1, 2, 2000, 20),
     "cancer10": (1, (9, 12, 2), "cancer", 10, False, 0.01, 10, 2000, 40),
+    # BASELINE configs 1 and 3 with their literal five-input topologies (series re-embedded with window 6, tests/golden/make_fixtures.py)
+    "sunspot5_r4": (0, (5, 5, 1), "sunspot5", 4, True, 0.1, 2, 5000, 50),
+    "mackey5_r64": (0, (5, 10, 1), "mackey5", 64, True, 0.1, 2, 1000, 100),
 }
 
 

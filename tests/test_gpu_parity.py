@@ -22,7 +22,9 @@ def ds():
 
 
 FUNC_CASES = {"reg_sunspot_4_5_1": "sunspot", "reg_mackey_4_10_1": "mackey", "cls_iris_4_12_3": "iris",
-              "cls_ions_34_50_2": "ions", "reg_synth_32_96_1": "synth32", "cls_ions_34_100_2": "ions"}
+              "cls_ions_34_50_2": "ions", "reg_synth_32_96_1": "synth32", "cls_ions_34_100_2": "ions",
+              # BASELINE configs 1 / 3 as worded (FNN 5-5-1, 5-10-1): the series re-embedded with five lags (make_fixtures.py: reembed)
+              "reg_sunspot5_5_5_1": "sunspot5", "reg_mackey5_5_10_1": "mackey5"}
 
 
 def test_library_is_the_hip_build():
@@ -109,7 +111,8 @@ def test_model_functions_against_reference_vectors(key, waves):
         s.close()
 
 
-TRAJ = ["reg_rw", "reg_lg", "reg_lg_mackey", "cls_rw", "cls_lg", "cls_rw_ions", "reg_rw_noswitch", "reg_lg_wide", "cls_lg_wide"]
+TRAJ = ["reg_rw", "reg_lg", "reg_lg_mackey", "cls_rw", "cls_lg", "cls_rw_ions", "reg_rw_noswitch", "reg_lg_wide", "cls_lg_wide",
+        "reg_lg_sunspot5", "reg_lg_mackey5"]
 
 
 @pytest.mark.parametrize("key", TRAJ)
@@ -162,7 +165,7 @@ def test_single_replica_trajectory(key, schedule, waves):
     s.close()
 
 
-SWAPTRAJ = ["reg", "reg_nophantom", "cls", "cls_nophantom"]
+SWAPTRAJ = ["reg", "reg_nophantom", "cls", "cls_nophantom", "reg_sunspot5"]
 
 
 @pytest.mark.parametrize("key", SWAPTRAJ)

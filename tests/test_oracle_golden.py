@@ -17,8 +17,9 @@ def _load(golden_dir, name):
 
 
 FUNC_CASES = ["reg_sunspot_4_5_1", "reg_mackey_4_10_1", "cls_iris_4_12_3", "cls_ions_34_50_2", "reg_synth_32_96_1",
-              "cls_ions_34_100_2"]
-DATA_OF = {"reg_sunspot_4_5_1": "sunspot", "reg_mackey_4_10_1": "mackey", "cls_iris_4_12_3": "iris",
+              "cls_ions_34_100_2", "reg_sunspot5_5_5_1", "reg_mackey5_5_10_1"]      # the last two: BASELINE configs 1 / 3 literally
+DATA_OF = {"reg_sunspot5_5_5_1": "sunspot5", "reg_mackey5_5_10_1": "mackey5",
+           "reg_sunspot_4_5_1": "sunspot", "reg_mackey_4_10_1": "mackey", "cls_iris_4_12_3": "iris",
            "cls_ions_34_50_2": "ions", "reg_synth_32_96_1": "synth32", "cls_ions_34_100_2": "ions"}
 
 
@@ -129,7 +130,7 @@ def test_single_replica_trajectory(golden_dir, datasets, key):
         assert rep.adapttemp == 1
 
 
-SWAPTRAJ = ["reg", "reg_nophantom", "cls", "cls_nophantom"]
+SWAPTRAJ = ["reg", "reg_nophantom", "cls", "cls_nophantom", "reg_sunspot5"]
 
 
 @pytest.mark.parametrize("key", SWAPTRAJ)
