@@ -16,9 +16,14 @@ the chains with ptnn_set_state, inside the timed region), bracketed by a barrier
 maximum over ranks is the time.  Inputs (data set, initial weights) are resident in HBM before the timed region, the trace
 rows the result files need are written to HBM inside it (sized for 288 GB: no host transfer in the timed region).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling, the same replicas per GPU on a ladder of N times as
-many temperatures; the swap rounds run inside libptnn over RCCL (ptnn_comm_init; torch.distributed is only the launcher's
-rendezvous: it carries the RCCL unique id, the barrier and the max-over-ranks of the time).
+N > 1: one rank (process) per GPU.  Under torch.distributed.run the ranks are the launcher's; run bare (`python3 bench.py --gpus N`,
+WORLD_SIZE unset) rank 0's parent starts the N ranks itself -- N fresh child processes of this script with RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set, before anything touches the GPU -- relays rank 0's JSON line and exits with the worst child's status.
+Weak scaling by default (the same replicas per GPU on a ladder of N times as many temperatures); `--scaling strong` keeps the
+workload's replica count and cuts it into N blocks (BASELINE config 4: `--workload ionosphere256 --scaling strong --gpus 8` =
+256 replicas over 8 GPUs).  The swap rounds run inside libptnn over RCCL (ptnn_comm_init; torch.distributed is only the
+rendezvous: it carries the RCCL unique id, the barrier and the max-over-ranks of the time); the line's `comm` object says what
+the communicator itself saw (ranks, devices, bytes, rounds).
 
 Prints ONE JSON line on rank 0.
 """
@@ -276,6 +281,61 @@ def pmc_traffic(workload, kernel):
     return None, None
 
 
+# ------------------------------------------------------------------------------------------------ N > 1 without a launcher
+def launch_plan(argv, n, master_port=None, environ=None, python=None, script=None):
+    """What `python3 bench.py --gpus N` run bare starts: one command line + environment per rank (a pure function: the CPU test
+    reads it).  Every child is a fresh process of this same script with the same arguments; RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT are what torch.distributed.run would have set."""
+    env0 = dict(os.environ if environ is None else environ)
+    if master_port is None:
+        import socket
+        with socket.socket() as sk:                          # a free port, asked of the kernel
+            sk.bind(("127.0.0.1", 0))
+            master_port = sk.getsockname()[1]
+    plans = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(master_port), PTNN_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        plans.append(([python or sys.executable, script or os.path.abspath(__file__)] + list(argv), env))
+    return plans
+
+
+def self_launch(argv, n, plans=None):
+    """Start the N ranks, pass rank 0's stdout through (its ONE JSON line), the other ranks' stdout to stderr; wait for all; the
+    exit status is the worst child's.  A rank that dies takes the others with it after a grace period (they would wait for it in
+    a collective until their own bounds expire)."""
+    import subprocess
+    import threading
+    plans = launch_plan(argv, n) if plans is None else plans
+    procs = [subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True) for cmd, env in plans]
+
+    def pump(r, p):
+        for line in p.stdout:
+            (sys.stdout if r == 0 else sys.stderr).write(line if r == 0 else f"[rank {r}] {line}")
+            (sys.stdout if r == 0 else sys.stderr).flush()
+    threads = [threading.Thread(target=pump, args=(r, p), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    worst, t_fail = 0, None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        for p in procs:
+            rc = p.poll()
+            if rc not in (None, 0) and t_fail is None:
+                t_fail = time.time()
+        if t_fail is not None and time.time() - t_fail > float(os.environ.get("PTNN_COMM_TIMEOUT_S", "120")) + 60.0:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                                 # these pids only
+    for t in threads:
+        t.join(timeout=5.0)
+    for p in procs:
+        rc = p.returncode
+        worst = max(worst, abs(rc) if rc is not None else 1)
+    return min(worst, 255)
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -300,6 +360,9 @@ def main():
     ap.add_argument("--force-comm", action="store_true", help="N = 1: attach a one-rank communicator anyway, so that the whole N > 1 code "
                     "path (torch.distributed rendezvous next to RCCL inside libptnn, swap rounds through the communicator) runs on a "
                     "one-GPU box")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = the workload's replicas PER GPU (N times the ladder); strong = the workload's replicas in "
+                         "total, cut into N blocks (R / N per GPU)")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
                     help="N > 1: rccl = RCCL over xGMI inside libptnn; host = host-staged through gloo (rehearsal of the N > 1 code "
                          "path with every rank on GPU 0 of a one-GPU box; what it prints is not a measurement)")
@@ -309,13 +372,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != N:
+        if "WORLD_SIZE" not in os.environ and N > 1:
+            # bare `python3 bench.py --gpus N`: this process becomes the launcher -- nothing has touched the GPU yet
+            sys.exit(self_launch(sys.argv[1:], N))
         if world == 1 and N > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+            raise SystemExit(f"--gpus {N} but WORLD_SIZE=1: unset WORLD_SIZE (bench.py then starts its own ranks) or launch with "
+                             f"torch.distributed.run --nproc-per-node {N}")
         N = world
     wl = dict(WORKLOADS[a.workload])
     if a.replicas:
         wl["desc"] = wl["desc"].replace(f"{wl['R']} replicas", f"{a.replicas} replicas")
         wl["R"] = a.replicas
+    if a.scaling == "strong" and N > 1:
+        if wl["R"] % N:
+            raise SystemExit(f"--scaling strong: {wl['R']} replicas cannot be cut into {N} equal blocks")
+        wl["desc"] += f" [strong scaling: {wl['R']} replicas in total, {wl['R'] // N} per GPU]"
+        wl["R"] = wl["R"] // N
     if a.rw:
         wl["lg"] = False
         wl["desc"] = wl["desc"].replace("Langevin p=0.5 lr=0.1", "random-walk").replace("Langevin p=0.5", "random-walk")
@@ -333,9 +405,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        import ptnn_amd  # noqa: F401
+        from ptnn_amd import distributed as dm0
+        dm0.single_node_rccl_env()               # this process is the bench's own: loopback bootstrap, no verbs probe, dmabuf IPC
         import torch
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("gloo")          # rendezvous only: unique id, barrier, max of the times
         ngpu = torch.cuda.device_count()         # counting devices does not initialise the GPU
         device = local_rank % max(ngpu, 1)       # a one-GPU box rehearsing N ranks puts them all on GPU 0
@@ -360,7 +434,14 @@ def main():
             return bool(t.item())
 
         transport_used = a.transport
-        if a.transport == "rccl":
+        if a.transport == "rccl" and shared_dev and not dm.injected_fault():
+            # more ranks than GPUs (a one-GPU box rehearsing N ranks): RCCL refuses two ranks on one device, and asking it anyway is
+            # the one bring-up that did not come back on the test box -- not attempted
+            transport_used, transport_note = "host", (f"fallback: {N} ranks share {max(ngpu, 1)} GPU(s), RCCL needs one device per "
+                                                      "rank -- not attempted; this line is a rehearsal of the N > 1 path, not a measurement")
+            if rank == 0:
+                print(f"[bench] {transport_note}", file=sys.stderr, flush=True)
+        if transport_used == "rccl":
             # RCCL inside libptnn has never run on more than one GPU (no multi-GPU box was ever available to the build): every stage
             # is bounded (PTNN_COMM_TIMEOUT_S) and agreed on by all ranks, and a bring-up or first-run failure anywhere moves
             # EVERY rank to the host-staged transport -- the line then says so and is a degraded figure, not an RCCL measurement.
@@ -422,6 +503,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     launches, kms = s.kernel_time()
+    comm = None
+    if dist is not None:
+        # what the communicator itself saw, from every rank (ptnn_comm_info / ptnn_comm_stats), not what argv asked for
+        mine = dict(s.comm_info(), **s.comm_stats())
+        allc = [None] * N
+        dist.all_gather_object(allc, mine)
+        comm = {"transport": sorted({c["transport"] for c in allc})[0] if len({c["transport"] for c in allc}) == 1 else [c["transport"] for c in allc],
+                "nranks_seen": sorted({c["nranks"] for c in allc})[0] if len({c["nranks"] for c in allc}) == 1 else [c["nranks"] for c in allc],
+                "device_ids": [c["device"] for c in allc], "distinct_devices": len({c["device"] for c in allc}),
+                "exchange": allc[0]["mode"], "bytes_sent": [c["bytes_sent"] for c in allc], "bytes_received": [c["bytes_received"] for c in allc],
+                "rounds": allc[0]["rounds"], "launcher": "self" if os.environ.get("PTNN_BENCH_SELF_LAUNCHED") else "torch.distributed.run"}
     nsw, tot, rounds = s.swap_stats()            # counters restart with every run: these are the last run's
     st = s.state()
     info = s.describe()
@@ -543,7 +635,7 @@ def main():
         out = {
             "metric": "MCMC samples/sec (all replicas) + swap-accept rate; " + ("Sunspot 64-replica FNN" if a.workload == "sunspot64" else wl["desc"]),
             "value": value, "unit": "samples/s", "n_gpus": N, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.bf16 else "f32", "data": data_desc,
+            "higher_is_better": True, "scaling": a.scaling if N > 1 else "weak", "vs_baseline": None, "dtype": "bf16" if a.bf16 else "f32", "data": data_desc,
             "config": {"workload": wl["desc"] + f"; swap every {si} MH steps; 1 bench step = 1 WHOLE RUN from the chain start: "
                                                 f"S = {S} samples per replica ({S - 1} MH steps, {S // si} swap rounds, chain start-up included)",
                        "replicas": R * N, "replicas_per_gpu": R, "samples_per_replica": S, "swap_interval": si,
@@ -562,6 +654,8 @@ def main():
                             "(ParallelTempering.timings reports those; DESIGN.md 8)",
         }
         out.update(extras)
+        if comm is not None:
+            out["comm"] = comm
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]

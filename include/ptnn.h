@@ -164,10 +164,19 @@ int ptnn_steps_done(ptnn_handle *h);
  * ncclGetUniqueId and ncclCommInitRank run on a helper thread that is abandoned after $PTNN_COMM_TIMEOUT_S seconds (default 120),
  * and every wait behind a collective (ptnn_sync, the getters, the boundary exchange's per-round wait) gives up when the stream
  * is busy but the device has completed no swap round for that long; all of them return -7 with the stage that stalled.
- * Unless $PTNN_COMM_KEEP_ENV=1, the first call sets NCCL_SOCKET_IFNAME=lo and NCCL_IB_DISABLE=1 when they are unset: the
- * ladder is sharded inside one node, so the bootstrap needs neither a routable interface nor a verbs probe. */
+ * The library never changes the environment.  The ladder is sharded inside one node, so the bootstrap needs neither a routable
+ * interface nor a verbs probe: callers that own their process export NCCL_SOCKET_IFNAME=lo and NCCL_IB_DISABLE=1 before their
+ * first thread starts (the Python host does: distributed.single_node_rccl_env). */
 int ptnn_comm_unique_id(void *id_out, int nbytes);
 int ptnn_comm_init(ptnn_handle *h, const void *unique_id, int nbytes, int rank, int nranks);
+/* One bounded RCCL round trip among `devices` (distinct) from the calling process: unique id, ncclCommInitRank on a thread per
+ * device, a 4-byte all-gather, destroy; *seconds = how long it took.  Run it in a fresh CHILD process before the long-lived
+ * process touches RCCL: a bring-up that fails or stalls half-way can keep the process it happened in from exiting.  0 = RCCL
+ * works among these devices; -7 = it does not (ptnn_last_error names the stage). */
+int ptnn_comm_probe(const int32_t *devices, int n, double *seconds);
+/* what is attached to the handle: transport (0 none, 1 RCCL, 2 host-staged), this rank, the number of ranks -- for RCCL as the
+ * communicator itself reports it (ncclCommCount), not as the caller passed it in -- and the handle's device */
+int ptnn_comm_info(ptnn_handle *h, int32_t *transport, int32_t *rank, int32_t *nranks, int32_t *device);
 /* the last stage a communicator bring-up / exchange entered in this process, as text ("ncclCommInitRank(rank 0 of 1, device 0)
  * (entered 0.4 s ago)"); $PTNN_COMM_TRACE=1 prints every stage to stderr as it is entered.  Returns the length written. */
 int ptnn_comm_last_stage(char *buf, int nbytes);
@@ -236,7 +245,9 @@ int ptnn_get_traces(ptnn_handle *h, int step0, int nsteps, float *pos_w, float *
                     float *rmse_test, float *acc_train, float *acc_test, int32_t *accept_count);
 /* The scalar trace rows as the device keeps them, rows [R, nsteps, 8] float32: {likeh, rmse_train, rmse_test, acc_train,
  * acc_test, accept_count (int32 bits), log alpha of the step as the kernel computed it (REG:372: diff_likelihood + diff_prior +
- * diff_prop; diagnostic, the parity tests measure the fp32 error of the MH decision with it), 0}.  Does not mark rows as
+ * diff_prop; diagnostic, the parity tests measure the fp32 error of the MH decision with it), 0}.  Regression (task 0): the
+ * acc_train slot -- identically 0 in the reference (REG:403) and in ptnn_get_traces -- holds eta = log tau^2 of the recorded
+ * state here (the chain's eta after an accepted step; tests set the oracle's state from it).  Does not mark rows as
  * fetched.  Same range rules as ptnn_get_traces. */
 int ptnn_get_trace_rows(ptnn_handle *h, int step0, int nsteps, float *rows);
 /* num_swap / total_swap_proposals (REG:501-502, 680-688) */
@@ -300,10 +311,21 @@ int ptnn_debug_stamps(ptnn_handle *h, uint64_t *out16);
 /* np.savetxt(path, data[rows, cols], fmt=fmt) with ' ' between columns and '\n' after rows (REG:454-481, 864-868).
  * fmt is one printf floating conversion such as "%.18e", "%1.8f", "%1.2f". */
 int ptnn_savetxt(const char *path, const double *data, int64_t rows, int64_t cols, const char *fmt);
+/* the same for float32 data as the device's traces are fetched (ptnn_get_traces): row r starts at data + r * row_stride; every
+ * value is printed as the double it converts to, exactly as np.savetxt prints a float32 array; append != 0 continues an existing
+ * file (a run written in windows).  Both savetxt entry points produce np.savetxt's bytes: values are formatted by exact integer
+ * arithmetic (correctly rounded, ties to even, as glibc's printf), printf itself only for formats or magnitudes outside that
+ * path, and a row identical to the one before it (a rejected MH step: pos_w[i+1] = pos_w[i], REG:417) reuses that row's text. */
+int ptnn_savetxt_f32(const char *path, const float *data, int64_t rows, int64_t cols, int64_t row_stride, const char *fmt, int append);
 
 /* in place: every value as np.loadtxt would read it back after np.savetxt(fmt=fmt) (show_results re-reads the per-chain
  * files, REG:795-831) */
 int ptnn_text_round(double *values, int64_t n, const char *fmt);
+int ptnn_text_round_f32(const float *in, double *out, int64_t n, const char *fmt);
+/* out[p][c * m + t] = pos_w[c][first_row + t][p] with m = n_rows - first_row, as float64: the posterior matrix show_results
+ * returns (REG:795-797, 848: every chain's pos_w file read back, burn-in cut, chains side by side, transposed).
+ * pos_w [n_chains, n_rows, n_param] float32 as ptnn_get_traces delivers it; out [n_param, n_chains * m]; `threads` host threads. */
+int ptnn_posterior_matrix(const float *pos_w, int64_t n_chains, int64_t n_rows, int64_t n_param, int64_t first_row, double *out, int threads);
 
 #ifdef __cplusplus
 }

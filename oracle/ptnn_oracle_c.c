@@ -164,11 +164,12 @@ double orc_prior(int task, int I, int H, int O, double sigma_sq, double nu1, dou
 typedef struct {
     int32_t task, I, H, O, P, Ntr, Nte, ncols, S, use_lg, gid, noise_gid;
     int32_t num_accepted, langevin_count, init_count, lik_stale;
-    int32_t last_stale, last_natural, last_forced, pad_;
+    int32_t last_stale, last_natural, last_forced, last_lg;        /* last_lg: the step drew a Langevin proposal */
     uint64_t seed;
     double T, adapttemp, l_prob, lr, step_w, step_eta, sigma_sq, nu1, nu2, pt_samples;
     double eta, tau_pro, likelihood, prior_current;
     double last_logalpha, last_u, last_scale;
+    double last_lik_cur, last_prior_cur;        /* the cached likelihood / prior the step's log alpha was formed with (after the R10 switch) */
     const double *train, *test;                 /* [N][ncols] row-major */
     double* w;                                  /* [P] current state */
     double *pos_w, *likeh, *accept_list, *rmse_train, *rmse_test, *acc_train, *acc_test;   /* traces: [S][P], [S][2], [S] ... */
@@ -201,6 +202,22 @@ void orc_replica_init(orc_replica* r) {
 /* Loop body for index i (REG:313-423 / CLS:313-434).  force < 0: the chain decides for itself; force = 0 / 1: the decision is
  * imposed (the caller follows another implementation's chain and has checked that the two decisions differ only inside the
  * fp32 error of log alpha); last_natural keeps what this chain would have decided.  Returns the decision taken. */
+/* The chain's state replaced by another implementation's (w, eta) -- the fp32 values a device recorded for this chain -- with the
+ * cached likelihood and prior RE-EVALUATED here in float64 from that state (what REG:395-399 keeps after an accepted step, at
+ * the temperature and noise variance of that step).  A followed run (tests/parity.py: follow_device_run) calls this after every
+ * accepted step, so that the next step's log alpha is compared between two sides that start from the SAME state: what is then
+ * measured is the fp32 error of ONE step, not the drift of two chains over thousands of accepted steps.  w_new: [P];
+ * eta_new: NaN = keep the chain's own. */
+void orc_replica_set_state(orc_replica* r, const double* w_new, double eta_new) {
+    double* sc = r->scratch + 4 * r->P;
+    memcpy(r->w, w_new, (size_t)r->P * sizeof(double));
+    if (eta_new == eta_new && r->task == TASK_REG) r->eta = eta_new;
+    const double tau = (r->task == TASK_REG) ? exp(r->eta) : 1.0;
+    r->likelihood = orc_likelihood(r->task, r->I, r->H, r->O, r->train, r->Ntr, r->ncols, r->w, tau, r->adapttemp, NULL, NULL, NULL, sc);
+    r->prior_current = orc_prior(r->task, r->I, r->H, r->O, r->sigma_sq, r->nu1, r->nu2, r->w, tau);
+    r->lik_stale = 0;
+}
+
 int orc_replica_step(orc_replica* r, int i, int force) {
     const int P = r->P, S = r->S;
     double *noise = r->scratch, *w_prop = noise + P, *w_gd = w_prop + P, *w_pgd = w_gd + P, *sc = w_pgd + P;
@@ -229,7 +246,9 @@ int orc_replica_step(orc_replica* r, int i, int force) {
         first = -0.5 * a / sig; second = -0.5 * b / sig;
         diff_prop = (first - second) / r->adapttemp;               /* Q6 */
         r->langevin_count += 1;
+        r->last_lg = 1;
     } else {
+        r->last_lg = 0;
         for (int j = 0; j < P; ++j) w_prop[j] = r->w[j] + r->step_w * noise[j];
     }
     double eta_pro = r->eta;
@@ -247,6 +266,7 @@ int orc_replica_step(orc_replica* r, int i, int force) {
     r->accept_list[i + 1] = (double)r->num_accepted;               /* Q7: the count BEFORE this step (REG:380) */
     r->likeh[2 * (i + 1)] = (r->task == TASK_REG) ? lik_prop : lik_prop * r->adapttemp;     /* REG:391 / CLS:404 */
     r->last_logalpha = la; r->last_u = u; r->last_stale = r->lik_stale;
+    r->last_lik_cur = r->likelihood; r->last_prior_cur = r->prior_current;
     r->last_scale = fabs(lik_prop) + fabs(r->likelihood) + fabs(prior_prop) + fabs(r->prior_current) +
                     (diff_prop != 0.0 ? (fabs(first) + fabs(second)) / r->adapttemp : 0.0);
     const int natural = (u < mh) ? 1 : 0;
@@ -277,15 +297,59 @@ int orc_replica_step(orc_replica* r, int i, int force) {
 /* steps [i0, i1) of one chain (the chains are independent between two swap rounds); force: NULL or one byte per step
  * (-1 / 0 / 1); per-step records (any may be NULL): log alpha, log u, scale, decided-on-a-stale-likelihood, natural decision */
 void orc_replica_run(orc_replica* r, int i0, int i1, const int8_t* force, double* logalpha, double* logu, double* scale,
-                     int8_t* stale, int8_t* natural) {
+                     int8_t* stale, int8_t* natural, const float* sync_w, int64_t sync_stride, const float* sync_eta, int64_t sync_eta_stride,
+                     double* la_sync, double* scale_sync, double* lik_sync) {
+    /* sync_w (or NULL): the other implementation's recorded pos_w rows (float32), the row MH step i wrote (trace row i + 1) at
+     * sync_w + (i - i0) * sync_stride; sync_eta (or NULL): its eta after step i at sync_eta[(i - i0) * sync_eta_stride].  After
+     * every ACCEPTED step the chain's state is set from them (orc_replica_set_state).  The chain's own trace rows keep its own
+     * float64 proposal, so comparing them with the other side's rows measures ONE step from a common state.
+     *
+     * la_sync / scale_sync / lik_sync (or NULL; NaN on rejected steps): the accepted step RE-EVALUATED AT THE OTHER SIDE'S OWN
+     * PROPOSAL -- the recorded row is the proposal it accepted, so log alpha = (lik(w') - lik) + (prior(w') - prior) + diff_prop
+     * (REG:365-372) is formed here in float64 from exactly the inputs the other side had: the common state w, its proposal w' and
+     * eta', this chain's cached likelihood / prior of w, and for a Langevin step first = -|w - sgd(w')|^2 / 2 step^2 with this
+     * chain's float64 epoch of w', second = -|noise|^2 / 2.  What differs from the other side's recorded value is then the
+     * arithmetic of ONE evaluation (forward passes, sums, one SGD epoch), not the position of the proposal: with tau^2 ~ 1e-4 a
+     * proposal moved by half a float32 ulp already changes log alpha by 1e-4 .. 1e-2.  lik_sync = the likeh_list entry of that
+     * step at the other side's proposal (REG:391 tempered / CLS:404 times adapttemp). */
+    const int P = r->P;
+    double* wtmp = sync_w ? (double*)malloc((size_t)2 * P * sizeof(double)) : NULL;
+    double* w_before = wtmp ? wtmp + P : NULL;
     for (int i = i0; i < i1; ++i) {
-        (void)orc_replica_step(r, i, force ? (int)force[i - i0] : -1);
+        if (la_sync) la_sync[i - i0] = NAN;
+        if (scale_sync) scale_sync[i - i0] = NAN;
+        if (lik_sync) lik_sync[i - i0] = NAN;
+        if (sync_w) memcpy(w_before, r->w, (size_t)P * sizeof(double));
+        const int took = orc_replica_step(r, i, force ? (int)force[i - i0] : -1);
         if (logalpha) logalpha[i - i0] = r->last_logalpha;
         if (logu) logu[i - i0] = log(r->last_u);
         if (scale) scale[i - i0] = r->last_scale;
         if (stale) stale[i - i0] = (int8_t)r->last_stale;
         if (natural) natural[i - i0] = (int8_t)r->last_natural;
+        if (took && sync_w) {
+            const float* row = sync_w + (size_t)(i - i0) * (size_t)sync_stride;
+            for (int j = 0; j < P; ++j) wtmp[j] = (double)row[j];
+            const double lik0 = r->last_lik_cur, pri0 = r->last_prior_cur;
+            orc_replica_set_state(r, wtmp, sync_eta ? (double)sync_eta[(size_t)(i - i0) * (size_t)sync_eta_stride] : NAN);
+            if (r->task == TASK_REG) r->tau_pro = exp(r->eta);      /* the last proposed tau IS this accepted one (Q9 reads it at the switch) */
+            if (la_sync || scale_sync) {
+                double diff = 0.0, first = 0.0, second = 0.0;
+                if (r->last_lg) {
+                    double *noise = r->scratch, *w_pgd = noise + 3 * P, *sc = noise + 4 * P;
+                    orc_langevin_gradient(r->task, r->I, r->H, r->O, r->train, r->Ntr, r->ncols, wtmp, r->lr, w_pgd, sc);
+                    double a = 0.0, b = 0.0;
+                    for (int j = 0; j < P; ++j) { const double dc = w_before[j] - w_pgd[j]; a += dc * dc; b += noise[j] * noise[j]; }
+                    first = -0.5 * a / (r->step_w * r->step_w); second = -0.5 * b;
+                    diff = (first - second) / r->adapttemp;
+                }
+                if (la_sync) la_sync[i - i0] = (r->likelihood - lik0) + (r->prior_current - pri0) + diff;
+                if (scale_sync) scale_sync[i - i0] = fabs(r->likelihood) + fabs(lik0) + fabs(r->prior_current) + fabs(pri0) +
+                                                     (fabs(first) + fabs(second)) / r->adapttemp;
+            }
+            if (lik_sync) lik_sync[i - i0] = (r->task == TASK_REG) ? r->likelihood : r->likelihood * r->adapttemp;
+        }
     }
+    free(wtmp);
 }
 
 int orc_replica_struct_bytes(void) { return (int)sizeof(orc_replica); }

@@ -33,10 +33,11 @@ _dp = C.POINTER(C.c_double)
 class _Rep(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("task", "I", "H", "O", "P", "Ntr", "Nte", "ncols", "S", "use_lg", "gid", "noise_gid",
                                           "num_accepted", "langevin_count", "init_count", "lik_stale",
-                                          "last_stale", "last_natural", "last_forced", "pad_")] +
+                                          "last_stale", "last_natural", "last_forced", "last_lg")] +
                 [("seed", C.c_uint64)] +
                 [(n, C.c_double) for n in ("T", "adapttemp", "l_prob", "lr", "step_w", "step_eta", "sigma_sq", "nu1", "nu2", "pt_samples",
-                                           "eta", "tau_pro", "likelihood", "prior_current", "last_logalpha", "last_u", "last_scale")] +
+                                           "eta", "tau_pro", "likelihood", "prior_current", "last_logalpha", "last_u", "last_scale",
+                                           "last_lik_cur", "last_prior_cur")] +
                 [(n, _dp) for n in ("train", "test", "w", "pos_w", "likeh", "accept_list", "rmse_train", "rmse_test", "acc_train",
                                     "acc_test", "scratch")])
 
@@ -52,7 +53,9 @@ def lib():
         l_.orc_replica_step.restype = C.c_int
         l_.orc_replica_step.argtypes = [C.POINTER(_Rep), C.c_int, C.c_int]
         l_.orc_replica_init.argtypes = [C.POINTER(_Rep)]
-        l_.orc_replica_run.argtypes = [C.POINTER(_Rep), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        l_.orc_replica_run.argtypes = [C.POINTER(_Rep), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        l_.orc_replica_set_state.argtypes = [C.POINTER(_Rep), _dp, C.c_double]
         l_.orc_likelihood.restype = C.c_double
         l_.orc_likelihood.argtypes = [C.c_int] * 4 + [_dp, C.c_int, C.c_int, _dp, C.c_double, C.c_double, _dp, _dp, _dp, _dp]
         l_.orc_prior.restype = C.c_double
@@ -172,14 +175,38 @@ class CReplica:
     def step(self, i, force=None):
         return bool(lib().orc_replica_step(C.byref(self.c), int(i), -1 if force is None else int(bool(force))))
 
-    def run(self, i0, i1, force=None):
-        """Steps [i0, i1); force: None or int8 [i1 - i0] of -1 / 0 / 1.  -> dict of per-step records."""
+    def run(self, i0, i1, force=None, sync_w=None, sync_eta=None):
+        """Steps [i0, i1); force: None or int8 [i1 - i0] of -1 / 0 / 1.  sync_w: float32 [i1 - i0, >= P] (row k = the pos_w row
+        another implementation recorded for MH step i0 + k), sync_eta: float32 [i1 - i0] (its eta after that step) or None:
+        after every accepted step the chain continues from that state, likelihood and prior re-evaluated in float64
+        (orc_replica_set_state).  -> dict of per-step records."""
         n = i1 - i0
         rec = dict(logalpha=np.empty(n), logu=np.empty(n), scale=np.empty(n), stale=np.empty(n, dtype=np.int8), natural=np.empty(n, dtype=np.int8))
         f = None if force is None else np.ascontiguousarray(force, dtype=np.int8)
+        sw, ss, se, es = None, 0, None, 0
+        if sync_w is not None:
+            assert sync_w.dtype == np.float32 and sync_w.ndim == 2 and sync_w.shape[0] == n and sync_w.shape[1] >= self.P
+            assert sync_w.strides[1] == 4 and sync_w.strides[0] % 4 == 0
+            sw, ss = sync_w.ctypes.data, sync_w.strides[0] // 4
+            if sync_eta is not None:
+                assert sync_eta.dtype == np.float32 and sync_eta.shape == (n,) and sync_eta.strides[0] % 4 == 0
+                se, es = sync_eta.ctypes.data, sync_eta.strides[0] // 4
+        extra = [None, None, None]
+        if sync_w is not None:
+            # the accepted steps re-evaluated at the other side's own proposal (NaN on rejected steps): see orc_replica_run
+            rec.update(la_sync=np.empty(n), scale_sync=np.empty(n), lik_sync=np.empty(n))
+            extra = [rec[k].ctypes.data for k in ("la_sync", "scale_sync", "lik_sync")]
         lib().orc_replica_run(C.byref(self.c), int(i0), int(i1), None if f is None else f.ctypes.data, rec["logalpha"].ctypes.data,
-                              rec["logu"].ctypes.data, rec["scale"].ctypes.data, rec["stale"].ctypes.data, rec["natural"].ctypes.data)
+                              rec["logu"].ctypes.data, rec["scale"].ctypes.data, rec["stale"].ctypes.data, rec["natural"].ctypes.data,
+                              sw, ss, se, es, *extra)
         return rec
+
+    def set_state(self, w, eta=None):
+        """Continue from another implementation's state: (w, eta) replaced, the cached likelihood / prior re-evaluated from it in
+        float64 at the chain's present temperature (orc_replica_set_state).  eta None (or classification): keep the chain's own."""
+        w = _f64(w)
+        assert w.shape == (self.P,)
+        lib().orc_replica_set_state(C.byref(self.c), _p(w), float("nan") if eta is None else float(eta))
 
     def posted_L(self):
         """Q11: REG posts likelihood * T (REG:430), CLS the tempered likelihood (CLS:439)."""

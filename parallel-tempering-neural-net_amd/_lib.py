@@ -57,6 +57,8 @@ SYMBOLS = {
     "ptnn_steps_done": (C.c_int, [C.c_void_p]),
     "ptnn_comm_unique_id": (C.c_int, [C.c_void_p, C.c_int]),
     "ptnn_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "ptnn_comm_probe": (C.c_int, [_ip, C.c_int, C.POINTER(C.c_double)]),
+    "ptnn_comm_info": (C.c_int, [C.c_void_p, _ip, _ip, _ip, _ip]),
     "ptnn_comm_last_stage": (C.c_int, [C.c_char_p, C.c_int]),
     "ptnn_comm_init_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ptnn_comm_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
@@ -92,6 +94,9 @@ SYMBOLS = {
     "ptnn_debug_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "ptnn_text_round": (C.c_int, [C.POINTER(C.c_double), C.c_int64, C.c_char_p]),
     "ptnn_savetxt": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_char_p]),
+    "ptnn_savetxt_f32": (C.c_int, [C.c_char_p, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_char_p, C.c_int]),
+    "ptnn_text_round_f32": (C.c_int, [_fp, C.POINTER(C.c_double), C.c_int64, C.c_char_p]),
+    "ptnn_posterior_matrix": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_int]),
 }
 
 
@@ -129,6 +134,17 @@ def comm_unique_id():
     if lib.ptnn_comm_unique_id(buf, UNIQUE_ID_BYTES) < 0:
         raise PtnnError(lib.ptnn_last_error().decode())
     return buf.raw
+
+
+def comm_probe(devices):
+    """ptnn_comm_probe: one bounded RCCL round trip among `devices` IN THIS PROCESS -> seconds it took; raises PtnnError with the
+    stage that failed.  Callers want distributed.rccl_probe(), which runs this in a fresh child process."""
+    lib = load_library()
+    dev = np.ascontiguousarray(devices, dtype=np.int32)
+    sec = C.c_double()
+    if lib.ptnn_comm_probe(_ptr(dev, _ip), int(dev.size), C.byref(sec)) < 0:
+        raise PtnnError(lib.ptnn_last_error().decode())
+    return sec.value
 
 
 def comm_last_stage():
@@ -254,6 +270,12 @@ class Sampler:
         self._check(self.lib.ptnn_comm_stats(self.h, C.byref(a), C.byref(b), C.byref(r), C.byref(m)))
         return dict(bytes_sent=a.value, bytes_received=b.value, rounds=r.value, mode={0: "none", 1: "gather", 2: "boundary"}[m.value])
 
+    def comm_info(self):
+        """What is attached to the handle: transport, rank, ranks as the communicator reports them, device (ptnn_comm_info)."""
+        t, r, n, d = (C.c_int32() for _ in range(4))
+        self._check(self.lib.ptnn_comm_info(self.h, C.byref(t), C.byref(r), C.byref(n), C.byref(d)))
+        return dict(transport={0: "none", 1: "rccl", 2: "host"}[t.value], rank=r.value, nranks=n.value, device=d.value)
+
     def comm_finalize(self):
         self._check(self.lib.ptnn_comm_finalize(self.h))
 
@@ -319,6 +341,20 @@ class Sampler:
                                              _ptr(out["rmse_train"]), _ptr(out["rmse_test"]), _ptr(out["acc_train"]),
                                              _ptr(out["acc_test"]), _ptr(out["accept"], _ip)))
         return out
+
+    def trace_rows(self, row0=0, nrows=None):
+        """The scalar trace rows as the device keeps them (ptnn_get_trace_rows), [R, nrows, 8] float32."""
+        n = self.S - row0 if nrows is None else nrows
+        rows = np.empty((self.R, n, 8), np.float32)
+        self._check(self.lib.ptnn_get_trace_rows(self.h, int(row0), int(n), _ptr(rows)))
+        return rows
+
+    def eta_trace(self):
+        """Regression: eta = log tau^2 of the state recorded in every trace row, [R, S] (row i + 1 after MH step i; 0 before the
+        first accepted step); classification has no eta: None."""
+        if self.cfg.task != TASK_REG:
+            return None
+        return self.trace_rows()[:, :, 3].copy()
 
     def log_alpha(self, step0=0, nsteps=None):
         """log alpha of MH steps step0 .. step0+nsteps-1 as the kernel computed it, [R, nsteps] (row i + 1 belongs to step i)."""
@@ -410,44 +446,71 @@ class Sampler:
         return n.value, ms.value
 
 
-def savetxt(path, array, fmt):
-    """np.savetxt(path, array, fmt=fmt) for 1-D / 2-D float arrays, formatted by the C library (GIL released)."""
+def savetxt(path, array, fmt, append=False):
+    """np.savetxt(path, array, fmt=fmt) for 1-D / 2-D arrays, byte for byte, formatted by the C library (GIL released).  float32
+    arrays (the device's traces, also row-strided views of them) are written as they are; anything else goes through float64."""
     lib = load_library()
-    a = np.ascontiguousarray(array, dtype=np.float64)
-    if a.ndim == 1:
-        rows, cols = a.shape[0], 1
-    elif a.ndim == 2:
-        rows, cols = a.shape
-    else:
+    a = np.asarray(array)
+    if a.ndim not in (1, 2):
         raise ValueError("savetxt handles 1-D and 2-D arrays")
-    rc = lib.ptnn_savetxt(os.fsencode(path), a.ctypes.data_as(C.POINTER(C.c_double)), rows, cols, fmt.encode())
+    if a.dtype == np.float32 and a.size and a.strides[-1] == 4 and (a.ndim == 1 or (a.strides[0] % 4 == 0 and a.strides[0] >= 4 * a.shape[1])):
+        rows, cols, stride = (a.shape[0], 1, 1) if a.ndim == 1 else (a.shape[0], a.shape[1], a.strides[0] // 4)
+        rc = lib.ptnn_savetxt_f32(os.fsencode(path), a.ctypes.data_as(_fp), rows, cols, stride, fmt.encode(), int(bool(append)))
+    else:
+        if append:
+            raise ValueError("append mode takes float32 data")
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        rows, cols = (a.shape[0], 1) if a.ndim == 1 else a.shape
+        rc = lib.ptnn_savetxt(os.fsencode(path), a.ctypes.data_as(C.POINTER(C.c_double)), rows, cols, fmt.encode())
     if rc < 0:
         raise PtnnError(lib.ptnn_last_error().decode())
 
 
+def _chunks(n, threads, grain=65536):
+    k = max(1, min(int(threads), n // grain + 1))
+    b = np.linspace(0, n, k + 1).astype(np.int64)
+    return [(int(b[i]), int(b[i + 1])) for i in range(k) if b[i + 1] > b[i]]
+
+
 def text_round(array, fmt, threads=8):
-    """Values as np.loadtxt reads them back after np.savetxt(..., fmt=fmt): printf + strtod in the C library, chunked
-    over a few threads (ctypes releases the GIL)."""
+    """Values as np.loadtxt reads them back after np.savetxt(..., fmt=fmt), float64, in the C library (exact integer arithmetic
+    for the '%1.Nf' formats, no strings), chunked over a few threads (ctypes releases the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
     lib = load_library()
-    a = np.array(array, dtype=np.float64, order="C", copy=True)
-    flat = a.reshape(-1)
-    n = flat.shape[0]
+    src = np.asarray(array)
+    f32 = src.dtype == np.float32
+    src = np.ascontiguousarray(src, dtype=np.float32 if f32 else np.float64)
+    out = np.empty(src.shape, dtype=np.float64) if f32 else np.array(src, copy=True)
+    n = out.size
     if n == 0:
-        return a
-    nchunk = max(1, min(threads, n // 4096 + 1))
-    bounds = np.linspace(0, n, nchunk + 1).astype(np.int64)
+        return out
+    flat_in, flat = src.reshape(-1), out.reshape(-1)
+    dp = C.POINTER(C.c_double)
 
-    def work(k):
-        lo, hi = int(bounds[k]), int(bounds[k + 1])
-        if hi > lo:
-            rc = lib.ptnn_text_round(flat[lo:hi].ctypes.data_as(C.POINTER(C.c_double)), hi - lo, fmt.encode())
-            if rc < 0:
-                raise PtnnError(lib.ptnn_last_error().decode())
-
-    if nchunk == 1:
-        work(0)
+    def work(rng):
+        lo, hi = rng
+        if f32:
+            rc = lib.ptnn_text_round_f32(flat_in[lo:hi].ctypes.data_as(_fp), flat[lo:hi].ctypes.data_as(dp), hi - lo, fmt.encode())
+        else:
+            rc = lib.ptnn_text_round(flat[lo:hi].ctypes.data_as(dp), hi - lo, fmt.encode())
+        if rc < 0:
+            raise PtnnError(lib.ptnn_last_error().decode())
+    parts = _chunks(n, threads)
+    if len(parts) == 1:
+        work(parts[0])
     else:
-        with ThreadPoolExecutor(max_workers=nchunk) as ex:
-            list(ex.map(work, range(nchunk)))
-    return a
+        with ThreadPoolExecutor(max_workers=len(parts)) as ex:
+            list(ex.map(work, parts))
+    return out
+
+
+def posterior_matrix(pos_w, first_row, threads=8):
+    """pos_w float32 [R, S, P] -> float64 [P, R * (S - first_row)]: rows from first_row on, chains side by side, transposed
+    (what show_results returns as pos_w, REG:795-797, 848)."""
+    lib = load_library()
+    a = np.ascontiguousarray(pos_w, dtype=np.float32)
+    R, S, P = a.shape
+    out = np.empty((P, R * (S - first_row)), dtype=np.float64)
+    if lib.ptnn_posterior_matrix(a.ctypes.data_as(_fp), R, S, P, int(first_row), out.ctypes.data_as(C.POINTER(C.c_double)), int(threads)) < 0:
+        raise PtnnError(lib.ptnn_last_error().decode())
+    return out

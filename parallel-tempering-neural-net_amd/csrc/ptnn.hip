@@ -5,6 +5,7 @@
 // CLS = multicore-pt-classification/pt_classification.py:232-494, 668-776).
 #include "ptnn_shapes.hpp"
 #include "ptnn_comm.hpp"
+#include "ptnn_text.hpp"
 #include "../../include/ptnn.h"
 
 #include <algorithm>
@@ -1124,6 +1125,86 @@ int ptnn_comm_init(ptnn_handle* h, const void* unique_id, int nbytes, int rank, 
     return 0;
 }
 
+// One bounded round trip of RCCL among `devices` from THIS process: unique id, one ncclCommInitRank per device (a thread each),
+// a 4-byte all-gather, destroy.  Meant to be run in a fresh CHILD process before the long-lived one touches RCCL (Python:
+// distributed.rccl_probe): a bring-up that stalls or fails is then the child's, which is killed -- an RCCL left half
+// initialised in the caller's own process (a unique id that no ncclCommInitRank follows, helpers abandoned inside
+// ncclCommInitRank) can keep that process from exiting.  Honours $PTNN_COMM_FAULT like the real bring-up.
+int ptnn_comm_probe(const int32_t* devices, int n, double* seconds) {
+    if (!devices || n < 1 || n > 64) return fail(-1, "bad argument");
+    const double t0 = comm_clock();
+    const char* fault = std::getenv("PTNN_COMM_FAULT");
+    if (fault && std::strstr(fault, "ncclGetUniqueId")) return fail(-7, "ncclGetUniqueId failed: injected by $PTNN_COMM_FAULT");
+    char id[sizeof(ncclUniqueId)];
+    if (int rc = ptnn_comm_unique_id(id, (int)sizeof id); rc < 0) return rc;
+    if (fault && std::strstr(fault, "ncclCommInitRank")) return fail(-7, "ncclCommInitRank failed: injected by $PTNN_COMM_FAULT");
+    for (int a = 0; a < n; ++a)
+        for (int b = a + 1; b < n; ++b)
+            if (devices[a] == devices[b]) return fail(-1, "RCCL needs one distinct device per rank (device %d appears twice)", devices[a]);
+    std::string why;
+    const RcclApi* api = rccl_api(why);
+    if (!api) return fail(-7, "cannot load RCCL: %s", why.c_str());
+    struct Shared { ncclUniqueId id; std::vector<int> rc; std::vector<std::string> msg; };
+    auto sh = std::make_shared<Shared>();
+    std::memcpy(&sh->id, id, sizeof sh->id);
+    sh->rc.assign((size_t)n, -1); sh->msg.resize((size_t)n);
+    std::vector<int> devs(devices, devices + n);
+    comm_stage("probe: ncclCommInitRank x %d + one all-gather", n);
+    int r = 0;
+    const bool finished = run_bounded([api, sh, devs, n]() -> int {
+        std::vector<std::thread> th;
+        for (int k = 0; k < n; ++k)
+            th.emplace_back([api, sh, devs, n, k]() {
+                auto bad = [&](const char* what, const char* detail) { sh->msg[(size_t)k] = std::string(what) + ": " + detail; sh->rc[(size_t)k] = 1; };
+                if (hipSetDevice(devs[(size_t)k]) != hipSuccess) return bad("hipSetDevice", "failed");
+                ncclComm_t comm = nullptr;
+                ncclResult_t e = api->CommInitRank(&comm, n, sh->id, k);
+                if (e != ncclSuccess) return bad("ncclCommInitRank", api->GetErrorString(e));
+                hipStream_t st = nullptr;
+                int32_t* buf = nullptr;
+                bool ok = hipStreamCreate(&st) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&buf), sizeof(int32_t) * (size_t)n) == hipSuccess;
+                const int32_t mine = 1000 + k;
+                ok = ok && hipMemcpyAsync(buf + k, &mine, sizeof mine, hipMemcpyHostToDevice, st) == hipSuccess;
+                if (ok) {
+                    e = api->AllGather(buf + k, buf, sizeof(int32_t), ncclChar, comm, st);
+                    std::vector<int32_t> got((size_t)n, 0);
+                    ok = e == ncclSuccess && hipMemcpyAsync(got.data(), buf, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                         hipStreamSynchronize(st) == hipSuccess;
+                    for (int j = 0; ok && j < n; ++j) ok = got[(size_t)j] == 1000 + j;
+                    if (!ok) bad("ncclAllGather", e == ncclSuccess ? "wrong or missing data" : api->GetErrorString(e));
+                } else bad("hip", "stream / buffer set-up failed");
+                if (buf) (void)hipFree(buf);
+                if (st) (void)hipStreamDestroy(st);
+                (void)api->CommDestroy(comm);
+                if (ok) sh->rc[(size_t)k] = 0;
+            });
+        for (auto& t : th) t.join();
+        for (int k = 0; k < n; ++k) if (sh->rc[(size_t)k] != 0) return 1 + k;
+        return 0;
+    }, comm_timeout_s(), &r);
+    if (seconds) *seconds = comm_clock() - t0;
+    if (!finished) return fail(-7, "the RCCL probe over %d devices did not finish within %d s (last stage: %s)", n, (int)comm_timeout_s(), comm_last_stage().c_str());
+    if (r != 0) return fail(-7, "the RCCL probe failed on rank %d: %s", r - 1, sh->msg[(size_t)(r - 1)].c_str());
+    comm_stage("probe done");
+    return 0;
+}
+
+int ptnn_comm_info(ptnn_handle* h, int32_t* transport, int32_t* rank, int32_t* nranks, int32_t* device) {
+    if (!h) return fail(-1, "null handle");
+    if (transport) *transport = h->comm.kind;
+    if (rank) *rank = h->comm.kind == COMM_NONE ? 0 : h->comm.rank;
+    if (device) *device = h->cfg.device_id;
+    if (nranks) {
+        *nranks = h->comm.kind == COMM_NONE ? 1 : h->comm.nranks;
+        if (h->comm.kind == COMM_RCCL && h->comm.api && h->comm.api->CommCount && h->comm.nccl) {
+            int c = 0;                                         // what the communicator itself says, not what the caller passed in
+            if (h->comm.api->CommCount(h->comm.nccl, &c) != ncclSuccess) return fail(-7, "ncclCommCount failed");
+            *nranks = c;
+        }
+    }
+    return 0;
+}
+
 int ptnn_comm_last_stage(char* buf, int nbytes) {
     if (!buf || nbytes < 1) return fail(-1, "bad argument");
     const std::string s = comm_last_stage();
@@ -1365,6 +1446,9 @@ int ptnn_get_traces(ptnn_handle* h, int step0, int nsteps, float* pos_w, float* 
         for (int c = 0; c < 5; ++c)
             if (outs[c])
                 for (size_t k = 0; k < n; ++k) outs[c][k] = rows[k * TR_COUNT + cols[c]];
+        // a regression has no accuracy (acc_train[i+1] = 0 on every step, REG:403): its TR_ACC_TR slot records eta (ptnn_device.hpp:
+        // finish_eval<TASK, true>; ptnn_get_trace_rows shows it), the array of the reference's layout is zeros
+        if (acc_train && h->cfg.task == PTNN_TASK_REG) std::fill(acc_train, acc_train + n, 0.0f);
         if (accept_count)
             for (size_t k = 0; k < n; ++k) std::memcpy(&accept_count[k], &rows[k * TR_COUNT + TR_ACCEPT], sizeof(int32_t));
     }
@@ -1715,37 +1799,98 @@ static bool float_format_ok(const char* fmt) {
 int ptnn_text_round(double* values, int64_t n, const char* fmt) {
     if (!values || !fmt || n < 0) return fail(-1, "bad argument");
     if (!float_format_ok(fmt)) return fail(-1, "unsupported format '%s'", fmt);
-    char buf[512];
-    for (int64_t k = 0; k < n; ++k) {
-        std::snprintf(buf, sizeof buf, fmt, values[k]);
-        values[k] = std::strtod(buf, nullptr);
-    }
+    const ptnn_text::Format f = ptnn_text::parse_format(fmt);
+    for (int64_t k = 0; k < n; ++k) values[k] = ptnn_text::round_trip(values[k], f);
     return 0;
 }
+
+int ptnn_text_round_f32(const float* in, double* out, int64_t n, const char* fmt) {
+    if (!in || !out || !fmt || n < 0) return fail(-1, "bad argument");
+    if (!float_format_ok(fmt)) return fail(-1, "unsupported format '%s'", fmt);
+    const ptnn_text::Format f = ptnn_text::parse_format(fmt);
+    for (int64_t k = 0; k < n; ++k) out[k] = ptnn_text::round_trip((double)in[k], f);
+    return 0;
+}
+
+}  // extern "C" (the row writer below is a template)
+
+// rows [0, rows) of a matrix as np.savetxt writes them; value(r, c) yields the double to print, same_as_prev(r) whether row r
+// repeats row r - 1 bit for bit (its text is then copied, not formatted again)
+template <class Value, class SameAsPrev>
+static int write_text_rows(const char* path, int64_t rows, int64_t cols, const char* fmt, bool append, Value value, SameAsPrev same_as_prev) {
+    if (!float_format_ok(fmt)) return fail(-1, "unsupported format '%s'", fmt);
+    const ptnn_text::Format f = ptnn_text::parse_format(fmt);
+    FILE* fp = std::fopen(path, append ? "a" : "w");
+    if (!fp) return fail(-4, "cannot open %s for writing", path);
+    std::setvbuf(fp, nullptr, _IONBF, 0);                      // the block below is the buffer
+    const size_t line_cap = (size_t)cols * 401 + 2;
+    std::vector<char> buf(std::max<size_t>(4u << 20, 2 * line_cap));
+    std::vector<char> line(line_cap);
+    size_t used = 0, line_len = 0;
+    for (int64_t r = 0; r < rows; ++r) {
+        if (r == 0 || !same_as_prev(r)) {
+            char* o = line.data();
+            for (int64_t c = 0; c < cols; ++c) {
+                if (c) *o++ = ' ';
+                o = ptnn_text::put_value(o, value(r, c), f);
+            }
+            *o++ = '\n';
+            line_len = (size_t)(o - line.data());
+        }
+        if (buf.size() - used < line_len) {
+            if (std::fwrite(buf.data(), 1, used, fp) != used) { std::fclose(fp); return fail(-4, "write to %s failed", path); }
+            used = 0;
+        }
+        std::memcpy(buf.data() + used, line.data(), line_len);
+        used += line_len;
+    }
+    const bool wrote = std::fwrite(buf.data(), 1, used, fp) == used;
+    if (std::fclose(fp) != 0 || !wrote) return fail(-4, "write to %s failed", path);
+    return 0;
+}
+
+extern "C" {
 
 int ptnn_savetxt(const char* path, const double* data, int64_t rows, int64_t cols, const char* fmt) {
     if (!path || !data || !fmt) return fail(-1, "null argument");
     if (rows < 0 || cols < 1) return fail(-1, "bad shape %lld x %lld", (long long)rows, (long long)cols);
-    if (!float_format_ok(fmt)) return fail(-1, "unsupported format '%s'", fmt);
-    FILE* f = std::fopen(path, "w");
-    if (!f) return fail(-4, "cannot open %s for writing", path);
-    std::vector<char> buf(1 << 20);
-    size_t used = 0;
-    for (int64_t r = 0; r < rows; ++r) {
-        for (int64_t c = 0; c < cols; ++c) {
-            if (buf.size() - used < 512) {
-                if (std::fwrite(buf.data(), 1, used, f) != used) { std::fclose(f); return fail(-4, "write to %s failed", path); }
-                used = 0;
+    return write_text_rows(path, rows, cols, fmt, false, [&](int64_t r, int64_t c) { return data[r * cols + c]; },
+                           [&](int64_t r) { return std::memcmp(data + r * cols, data + (r - 1) * cols, (size_t)cols * sizeof(double)) == 0; });
+}
+
+int ptnn_savetxt_f32(const char* path, const float* data, int64_t rows, int64_t cols, int64_t row_stride, const char* fmt, int append) {
+    if (!path || !data || !fmt) return fail(-1, "null argument");
+    if (rows < 0 || cols < 1 || row_stride < cols) return fail(-1, "bad shape %lld x %lld (row stride %lld)", (long long)rows, (long long)cols, (long long)row_stride);
+    return write_text_rows(path, rows, cols, fmt, append != 0, [&](int64_t r, int64_t c) { return (double)data[r * row_stride + c]; },
+                           [&](int64_t r) { return std::memcmp(data + r * row_stride, data + (r - 1) * row_stride, (size_t)cols * sizeof(float)) == 0; });
+}
+
+int ptnn_posterior_matrix(const float* pos_w, int64_t n_chains, int64_t n_rows, int64_t n_param, int64_t first_row, double* out, int threads) {
+    // out[p][c * m + t] = pos_w[c][first_row + t][p], m = n_rows - first_row: the (P, R (S - b)) float64 matrix show_results
+    // returns (REG:795-797, 848: np.loadtxt of every chain's pos_w file, burn-in cut, chains side by side, transposed)
+    if (!pos_w || !out || n_chains < 1 || n_param < 1 || first_row < 0 || first_row > n_rows) return fail(-1, "bad argument");
+    const int64_t m = n_rows - first_row;
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n_chains));
+    auto work = [&](int t) {
+        for (int64_t c = t; c < n_chains; c += T) {
+            const float* src = pos_w + (c * n_rows + first_row) * n_param;
+            // blocks of rows: the block's source (bt x P floats) stays in cache while it is read P times with stride P
+            for (int64_t t0 = 0; t0 < m; t0 += 256) {
+                const int64_t bt = std::min<int64_t>(256, m - t0);
+                for (int64_t p = 0; p < n_param; ++p) {
+                    double* dst = out + p * (n_chains * m) + c * m + t0;
+                    const float* s = src + t0 * n_param + p;
+                    for (int64_t k = 0; k < bt; ++k) dst[k] = (double)s[k * n_param];
+                }
             }
-            if (c) buf[used++] = ' ';
-            const int w = std::snprintf(buf.data() + used, 400, fmt, data[r * cols + c]);
-            if (w < 0 || w >= 400) { std::fclose(f); return fail(-1, "value %g does not fit the text slot with format '%s'", data[r * cols + c], fmt); }
-            used += (size_t)w;
         }
-        buf[used++] = '\n';
+    };
+    if (T == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+        for (auto& x : th) x.join();
     }
-    const bool wrote = std::fwrite(buf.data(), 1, used, f) == used;
-    if (std::fclose(f) != 0 || !wrote) return fail(-4, "write to %s failed", path);
     return 0;
 }
 

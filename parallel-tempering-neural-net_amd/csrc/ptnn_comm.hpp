@@ -103,6 +103,7 @@ struct RcclApi {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;          // optional (ptnn_comm_info): null in a table that does not offer it
 };
 
 // A test may install its own function table (tests/native/comm_mock.cpp fills one with in-process fakes that record the call
@@ -110,14 +111,17 @@ struct RcclApi {
 inline const RcclApi*& rccl_api_override() { static const RcclApi* o = nullptr; return o; }
 
 // The ladder is sharded over the GPUs of ONE node (north_star), so the bootstrap of a communicator never needs a routable
-// interface or an InfiniBand probe: unless the caller has chosen otherwise, RCCL is told to bootstrap over loopback and to
-// leave the verbs devices alone -- two stages of ncclGetUniqueId / ncclCommInitRank whose duration depends on the box's
-// network set-up rather than on anything this library does.  $PTNN_COMM_KEEP_ENV=1 leaves the environment untouched.
+// interface or an InfiniBand probe: NCCL_SOCKET_IFNAME=lo and NCCL_IB_DISABLE=1 take out two stages of ncclGetUniqueId /
+// ncclCommInitRank whose duration depends on the box's network set-up rather than on anything this library does.  The LIBRARY
+// does not touch the environment (setenv is process-wide and not safe against a concurrent getenv of another thread; a later
+// multi-node NCCL user of the same process would silently be pinned to loopback): the callers that own their process set these
+// defaults before they start a thread -- distributed.single_node_rccl_env() for LadderGroup, bench.py at start-up -- and
+// INTEGRATION.md lists them.  Here the choice is only recorded in the stage log.
 inline void rccl_single_node_env() {
-    if (const char* k = std::getenv("PTNN_COMM_KEEP_ENV")) if (*k && *k != '0') return;
-    setenv("NCCL_SOCKET_IFNAME", "lo", 0);
-    setenv("NCCL_IB_DISABLE", "1", 0);
-    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);      // dmabuf IPC is all this pool's driver offers (no effect once HIP is up)
+    const char* ifn = std::getenv("NCCL_SOCKET_IFNAME");
+    const char* ib = std::getenv("NCCL_IB_DISABLE");
+    comm_stage("RCCL bootstrap environment: NCCL_SOCKET_IFNAME=%s NCCL_IB_DISABLE=%s", ifn ? ifn : "(unset: RCCL picks an interface)",
+               ib ? ib : "(unset)");
 }
 
 // dlopen once per process; returns nullptr and fills `why` when the library or a symbol is missing or the load does not finish
@@ -168,6 +172,7 @@ inline const RcclApi* rccl_api(std::string& why) {
             PTNN_RCCL_SYM(GroupEnd, "ncclGroupEnd")
             PTNN_RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef PTNN_RCCL_SYM
+            if (ok) api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.lib, "ncclCommCount"));
             if (!ok) { dlclose(api.lib); api.lib = nullptr; }
         }
     }

@@ -43,6 +43,7 @@ enum { SI_NACC = 0, SI_REC_ROW, SI_LG_COUNT, SI_LG_ACC, SI_COUNT = 4 };   // acc
 // scalar trace row of MH step i (row i + 1): what the per-chain result files need beside pos_w (REG:454-481) -- likeh_list
 // column 0 (REG:391 / CLS:404), rmse_train, rmse_test, acc_train, acc_test, accept_list (the count BEFORE the step, REG:380, as
 // int bits) -- plus the step's log alpha as the kernel computed it (diagnostic: the parity tests measure its fp32 error with it)
+// TR_ACC_TR of a REGRESSION (whose acc_train is identically 0, REG:403): eta of the recorded state (finish_eval<TASK, true>)
 // TR_SRC (int bits): compact traces only -- the trace row that holds this step's pos_w values (the step's own row when it was
 // accepted, else the row of the last accepted step: pos_w[i+1] = pos_w[i] on a reject, REG:417); 0 in the full layout
 enum { TR_LIKEH = 0, TR_RMSE_TR, TR_RMSE_TE, TR_ACC_TR, TR_ACC_TE, TR_ACCEPT, TR_LOGALPHA, TR_SRC, TR_COUNT = 8 };
@@ -1027,11 +1028,17 @@ __device__ __forceinline__ void finish_scores(const EvalSums& s, int Ntr, int Nt
         acc_te = 100.0f * (s.c_te / (float)Nte);
     }
 }
-template <int TASK>
+// REC (the step loops): regression has no accuracy -- acc_train is identically 0 in the reference (REG:403) -- so the slot
+// that carries it through the commit into the scalar trace row (TR_ACC_TR) carries the eta the proposal was evaluated with
+// instead: the recorded row of an accepted step then holds the chain's new eta, a rejected step repeats the recorded one.
+// ptnn_get_traces hands out zeros for a regression's acc_train; ptnn_get_trace_rows shows the raw row (the parity tests set
+// the oracle's state from it after every accepted step, tests/parity.py: follow_device_run).
+template <int TASK, bool REC = false>
 __device__ __forceinline__ void finish_eval(const EvalSums& s, int Ntr, int Nte, float eta, float& loglik,
                                             float& rmse_tr, float& rmse_te, float& acc_tr, float& acc_te) {
     loglik = finish_loglik<TASK>(s, Ntr, eta);
     finish_scores<TASK>(s, Ntr, Nte, rmse_tr, rmse_te, acc_tr, acc_te);
+    if (REC && TASK == TASK_REG) acc_tr = eta;
 }
 
 // Langevin proposal ratio (REG:336-347, Q6): [-0.5 d1 / step^2 + 0.5 d2] / adapttemp with d1 = |w - w_prop_gd|^2 and
@@ -1823,7 +1830,10 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& d
             prior_cur = prior_prop;
             eta = eta_pro;
             // the recorded scores live in wave 0 only: thread 0 writes them (trace row, state write-back)
-            if (wave == 0) finish_scores<TASK>(es, p.Ntr, p.Nte, rec_rmse_tr, rec_rmse_te, rec_acc_tr, rec_acc_te);   // REG: acc 0 (REG:403-404); CLS: accuracy (CLS:414-415)
+            if (wave == 0) {
+                finish_scores<TASK>(es, p.Ntr, p.Nte, rec_rmse_tr, rec_rmse_te, rec_acc_tr, rec_acc_te);   // REG: acc 0 (REG:403-404); CLS: accuracy (CLS:414-415)
+                if (TASK == TASK_REG) rec_acc_tr = eta;       // the regression's acc_train slot records eta (finish_eval<TASK, true>)
+            }
             gd_valid = lg ? 1 : 0;                        // w_prop_gd is langevin_gradient(new w): keep it as the cache
             const int old_cur = o_cur;
             o_cur = o_prop; o_rec = o_prop; o_prop = old_cur;   // old_cur is neither the new current nor the new recorded vector
@@ -2073,7 +2083,7 @@ __device__ __forceinline__ void segment_spec_body(const SegParams& p, const SegD
             gsync<true>();
             const EvalSums es = eval_rows<TASK, I, O, true>(my_fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, nullptr);
             float ll;
-            finish_eval<TASK>(es, p.Ntr, p.Nte, eta_x, ll, rm_tr, rm_te, ac_tr, ac_te);
+            finish_eval<TASK, true>(es, p.Ntr, p.Nte, eta_x, ll, rm_tr, rm_te, ac_tr, ac_te);
             lik_prop = ll / adapt_x;
             const float ssq = block_sumsq<true>(prop, P, nullptr);
             prior_prop = prior_value<TASK>(p, ssq, eta_x);
@@ -2543,7 +2553,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
                 gsync<true>();
                 const EvalSums es = eval_rows<TASK, I, O, true>(my_fw, xy, p.IPY, p.FWS, H, p.Ntr, Nall, nullptr);
                 float ll, rm_tr, rm_te, ac_tr, ac_te;
-                finish_eval<TASK>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
+                finish_eval<TASK, true>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
                 const float ssq = block_sumsq<true>(s_prop(s_), P, nullptr);
                 const float prior_prop = prior_value<TASK>(p, ssq, eta_pro);
                 // |noise|^2 of the Langevin ratio does not wait for the epoch: taken here, off the critical path (same
@@ -3587,7 +3597,7 @@ __device__ __forceinline__ void segment_wide_body(const SegParams& p, const SegD
             if (TASK == TASK_REG) eta_pro = fmaf(p.step_eta, n_eta, eta);
             const EvalSums es = wide_forward<TASK, I, O>(p, w_prop, fw, red, img_direct);
             float ll, rm_tr, rm_te, ac_tr, ac_te;
-            finish_eval<TASK>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
+            finish_eval<TASK, true>(es, p.Ntr, p.Nte, eta_pro, ll, rm_tr, rm_te, ac_tr, ac_te);
             const float lik_prop = ll / adapttemp;
             const float ssq = block_sum(ssq_part, red);
             const float prior_prop = prior_value<TASK>(p, ssq, eta_pro);
@@ -4212,6 +4222,16 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
     };
     int tpar = 0;
     if (ahead && i < step_end) { draw_tapes(tapes0, i, round_steps(i)); __syncthreads(); }
+#ifdef PTNN_STAMPS
+    // phases of a round, root group of replica 0: 0 loop head / switch, 1 tapes, 2 proposal, 3 forward pass, 4 publish + next tapes,
+    // 5 wait for the records, 6 decisions, 7 state + trace rows
+    const bool stamp_on = (lb == 0 && tid < WAVE);
+    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const unsigned long long stamp_t0 = stamp_last;
+    unsigned long long stamp_rounds = 0;
+#endif
     while (i < step_end) {
         const int dr = round_steps(i);
         float* const tapes = tapes0 + (size_t)tpar * D * (PS + 8);
@@ -4235,8 +4255,10 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
             lik = uni_f(finish_loglik<TASK>(sc, p.Ntr, eta));
             __syncthreads();
         }
+        STAMP(0);
         // 1. the random tapes of the dr steps (drawn during the previous round's exchange when LDS has room for two sets)
         if (!ahead) { draw_tapes(tapes, i, dr); __syncthreads(); }
+        STAMP(1);
         // 2. this node's proposal: the state after the accepted ancestors on its path, plus its own step
         const bool active = depth < dr;
         auto path_value = [&](int idx) {
@@ -4272,6 +4294,7 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
             }
         }
         __syncthreads();
+        STAMP(2);
         // 3. forward pass of the node's proposal (the cooperative kernel's phase B)
         float rv[TREE_FIELDS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (active) {
@@ -4284,7 +4307,9 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
             rv[0] = finish_loglik<TASK>(es, p.Ntr, eta) / adapttemp;
             rv[1] = prior_value<TASK>(p, ssq, eta);
             finish_scores<TASK>(es, p.Ntr, p.Nte, rv[2], rv[3], rv[4], rv[5]);
+            if (TASK == TASK_REG) rv[4] = eta;                // as finish_eval<TASK, true>
         }
+        STAMP(3);
         // 4. publish the record (idle nodes publish their tag too: everybody waits for everybody, which keeps the groups
         //    within one round of each other)
         granule_t* const xr = xrec + (size_t)par * (TREE_MAX_NODES + 1) * TREE_REC;
@@ -4296,6 +4321,7 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
         }
         // ... and while the records travel, the tapes of the next round (they depend on step numbers only)
         if (ahead && i + dr < step_end) draw_tapes(tapes0 + (size_t)(tpar ^ 1) * D * (PS + 8), i + dr, round_steps(i + dr));
+        STAMP(4);
         // 5. all records of the round
         bool ok = true;
         for (int q = tid; q < G * TREE_FIELDS; q += nthr) {
@@ -4305,6 +4331,7 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
             recs[nd_ * TREE_REC + f_] = v;
         }
         if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
+        STAMP(5);
         // 6. the dr decisions, by every thread alike: each against the likelihood / prior of the state the walk has reached
         unsigned accmask = 0, my_mask = 0;
         int my_acc_before = 0;
@@ -4331,6 +4358,7 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
             }
             nd = 2 * nd + (accept ? 1 : 0);
         }
+        STAMP(6);
         // 7. the new state, rebuilt from the tapes, and the trace rows (row of step i + l: the recorded vector after that
         //    step's decision = the state after it if anything was accepted up to there, else the old recorded vector)
         const bool write_row = g < dr;
@@ -4357,11 +4385,22 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
             if (write_row) prow[j] = rowv;
         }
         __syncthreads();                                    // the next round's tapes and proposals read what was just written
+        STAMP(7);
+#ifdef PTNN_STAMPS
+        stamp_rounds += 1;
+#endif
         i += dr;
         epoch += 1;
         par ^= 1;
         if (ahead) tpar ^= 1;
     }
+#ifdef PTNN_STAMPS
+    if (stamp_on && tid == 0) {
+        for (int q_ = 0; q_ < 9; ++q_) atomicAdd(p.stamps + q_, stamp_acc[q_]);
+        atomicAdd(p.stamps + 9, stamp_rounds);
+        atomicAdd(p.stamps + 10, __builtin_amdgcn_s_memtime() - stamp_t0);
+    }
+#endif
     if (failed) {
         if (tid == 0) atomicAdd(p.error_flag, 1);           // a bounded spin ran out: the host reports it
         return;

@@ -17,15 +17,133 @@ This module holds what the Python host needs around that:
 One process per GPU (bench.py under torch.distributed.run) needs none of it: each rank builds its `_lib.Sampler`, calls
 `comm_init(unique_id, rank, nranks)` and `run()`.
 """
+import atexit
+import json
 import os
 import queue
 import struct
+import subprocess
+import sys
 import threading
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
 from . import _lib
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAULT_STAGES = ("ncclGetUniqueId", "ncclCommInitRank")      # what $PTNN_COMM_FAULT can name (ptnn.hip parses it the same way)
+
+
+def injected_fault():
+    """The stages $PTNN_COMM_FAULT makes libptnn fail at (test hook), () when it names none the library knows."""
+    f = os.environ.get("PTNN_COMM_FAULT", "")
+    return tuple(st for st in FAULT_STAGES if st in f)
+
+
+def single_node_rccl_env(environ=None):
+    """RCCL defaults for a ladder sharded inside ONE node, set only where unset and only by callers that own their process
+    (LadderGroup before its first thread exists, bench.py at start-up; libptnn itself never touches the environment): bootstrap
+    over loopback, no InfiniBand probe -- two stages of ncclGetUniqueId / ncclCommInitRank whose duration otherwise depends on
+    the box's network set-up -- and dmabuf IPC, all this pool's driver offers.  $PTNN_COMM_KEEP_ENV=1 leaves everything alone."""
+    env = os.environ if environ is None else environ
+    if env.get("PTNN_COMM_KEEP_ENV", "0") not in ("", "0"):
+        return env
+    env.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    env.setdefault("NCCL_IB_DISABLE", "1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+_PROBE_CHILD = ("import json, os, sys; sys.path.insert(0, {root!r}); import ptnn_amd; from ptnn_amd import _lib\n"
+                "try:\n"
+                "    out = dict(ok=True, seconds=_lib.comm_probe({devices!r}))\n"
+                "except Exception as e:\n"
+                "    out = dict(ok=False, why=str(e), last_stage=_lib.comm_last_stage())\n"
+                "sys.stdout.write('PTNN_PROBE ' + json.dumps(out) + '\\n'); sys.stdout.flush()\n"
+                "os._exit(0 if out['ok'] else 3)\n")      # no interpreter teardown: a half-initialised RCCL must not hold the child
+
+
+def rccl_probe(devices, timeout_s=None):
+    """Does RCCL come up among `devices`?  Asked in a FRESH CHILD process (a new interpreter started with subprocess, never a
+    re-exec of this one), so that this process has not touched RCCL when the answer is no: a unique id that no ncclCommInitRank
+    follows, or init helpers abandoned inside RCCL, can keep the process they live in from exiting.  The child runs
+    ptnn_comm_probe (unique id, ncclCommInitRank per device, one all-gather, destroy) under libptnn's own bounds; this side
+    waits `timeout_s` (default $PTNN_COMM_TIMEOUT_S + 30, 150 s) and then kills that one pid.  -> (ok, text)."""
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("PTNN_COMM_TIMEOUT_S", "120")) + 30.0
+    env = single_node_rccl_env(dict(os.environ))
+    code = _PROBE_CHILD.format(root=_ROOT, devices=[int(d) for d in devices])
+    try:
+        child = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)
+    except OSError as e:
+        return False, f"could not start the probe process: {e}"
+    try:
+        out, err = child.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        child.kill()                                         # this pid only
+        child.communicate()
+        return False, f"the RCCL probe process did not finish within {timeout_s:g} s and was killed"
+    for line in out.splitlines():
+        if line.startswith("PTNN_PROBE "):
+            res = json.loads(line[len("PTNN_PROBE "):])
+            if res["ok"]:
+                return True, f"RCCL probe over devices {list(devices)}: {res['seconds']:.2f} s"
+            return False, f"{res['why']} (last stage: {res['last_stage']})"
+    return False, f"the RCCL probe process ended with code {child.returncode} and no verdict: {err.strip()[-300:]}"
+
+
+_hard_exit_armed = False
+
+
+def _arm_hard_exit():
+    """An RCCL bring-up failed INSIDE this process (after the child's probe had passed, or with the probe switched off): native
+    threads RCCL started may never end, and the C runtime would wait for them in its own exit handlers for ever (seen on the
+    test box: an ncclGetUniqueId that no ncclCommInitRank follows).  From here on the process leaves through os._exit: an
+    atexit hook runs the other Python exit handlers, flushes the standard streams and ends the process with the status
+    sys.exit() or an uncaught exception had asked for."""
+    global _hard_exit_armed
+    if _hard_exit_armed:
+        return
+    _hard_exit_armed = True
+    status = [0]
+    orig_exit, orig_hook = sys.exit, sys.excepthook
+
+    def _exit(code=0):
+        status[0] = code if isinstance(code, int) else (0 if code is None else 1)
+        orig_exit(code)
+
+    def _hook(*a):
+        status[0] = 1
+        orig_hook(*a)
+    sys.exit, sys.excepthook = _exit, _hook
+    leaving = [False]
+    orig_register = atexit.register
+
+    def register_once(fn, *a, **k):                          # handlers registered from now on run before _leave AND would be run again
+        ran = [False]                                        # by its _run_exitfuncs(): make them idempotent
+
+        def once(*aa, **kk):
+            if not ran[0]:
+                ran[0] = True
+                return fn(*aa, **kk)
+        orig_register(once, *a, **k)
+        return fn
+    atexit.register = register_once
+
+    def _leave():
+        if leaving[0]:
+            return
+        leaving[0] = True
+        try:
+            atexit._run_exitfuncs()                          # the handlers registered before this one
+        finally:
+            try:
+                sys.stdout.flush()
+                sys.stderr.flush()
+            finally:
+                os._exit(status[0])
+    orig_register(_leave)
 
 
 class TransportAborted(RuntimeError):
@@ -135,11 +253,16 @@ class LadderGroup:
             transport = "rccl" if distinct else "host"
         if transport not in ("rccl", "host"):
             raise ValueError("transport must be None, 'auto', 'rccl' or 'host'")
-        if transport == "rccl" and not distinct and not os.environ.get("PTNN_COMM_FAULT"):
-            # never attempted: two ranks of ONE process initialising RCCL on one device did not come back on the test box
+        if transport == "rccl" and not distinct and not injected_fault():
+            # never attempted: two ranks of ONE process initialising RCCL on one device did not come back on the test box.  The
+            # only way past this check is a $PTNN_COMM_FAULT that names a stage libptnn really fails at BEFORE ncclCommInitRank
+            # runs (tests of the fall-back on a one-GPU box); any other value of that variable leaves the check in force.
             raise ValueError("RCCL needs one distinct device per block; use transport='host' to rehearse on one GPU")
         self.transport = transport
         self.transport_note = None
+        self.rccl_probe_result = None
+        if transport == "rccl" and n > 1:
+            single_node_rccl_env()                           # before the first thread of this group exists
         self._pool = ThreadPoolExecutor(max_workers=n)
         self.shards = [None] * n
         self._tt = None                                      # ThreadTransport of a host-staged group
@@ -161,14 +284,29 @@ class LadderGroup:
                 # _each() collects every thread before the first error is raised.
                 # RCCL has never run on more than one GPU here: with `fallback` a failed bring-up (every stage bounded) moves the
                 # whole group to the host-staged transport, with a warning and `transport_note`, instead of ending the run.
-                try:
-                    uid = _lib.comm_unique_id()
-                    self._each(lambda k: self.shards[k].comm_init(uid, k, n))
-                except _lib.PtnnError as e:
+                # Before THIS process touches RCCL the same bring-up is rehearsed in a fresh child process (rccl_probe): when RCCL
+                # does not come up among these devices, the answer arrives without a half-initialised RCCL in the process that
+                # has to go on (and, one day, exit).  $PTNN_RCCL_PROBE=0 skips the rehearsal.
+                why = None
+                if os.environ.get("PTNN_RCCL_PROBE", "1") not in ("0", ""):
+                    ok, text = rccl_probe(self.devices)
+                    self.rccl_probe_result = (ok, text)
+                    if not ok:
+                        why = f"the probe in a child process failed, RCCL was not touched in this process: {text}"
+                if why is None:
+                    try:
+                        uid = _lib.comm_unique_id()
+                        self._each(lambda k: self.shards[k].comm_init(uid, k, n))
+                    except _lib.PtnnError as e:
+                        why = f"{e} (last stage: {_lib.comm_last_stage()})"
+                        _arm_hard_exit()                     # RCCL is partly up in this process: it may never let it exit
+                        if not fallback:
+                            raise
+                if why is not None:
                     if not fallback:
-                        raise
+                        raise _lib.PtnnError(why)
                     import warnings
-                    self.transport_note = f"host-staged after an RCCL bring-up failure: {e} (last stage: {_lib.comm_last_stage()})"
+                    self.transport_note = f"host-staged after an RCCL bring-up failure: {why}"
                     warnings.warn("LadderGroup: " + self.transport_note, RuntimeWarning, stacklevel=2)
                     for sh in self.shards:                   # a block whose own bring-up had returned: drop its communicator
                         try:
@@ -253,6 +391,9 @@ class LadderGroup:
 
     def comm_stats(self):
         return self._each(lambda k: self.shards[k].comm_stats()) if self.n > 1 else []
+
+    def comm_info(self):
+        return self._each(lambda k: self.shards[k].comm_info())
 
     def describe(self):
         return self.shards[0].describe()

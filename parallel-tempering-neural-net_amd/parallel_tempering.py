@@ -244,14 +244,19 @@ class ParallelTemperingBase:
             t2 = time.perf_counter()
         if self.label_swap:
             tr = self._stitch_by_temperature(tr)
-        if self.write_files:
-            self._write_chain_files(tr)
-        t3 = time.perf_counter()
-        out = self.show_results(tr)
-        t4 = time.perf_counter()
+        # the per-chain files (REG:454-481) and what show_results derives from them (REG:775-871) are independent of each other
+        # once the traces are on the host: one pool formats the 8 R + 3 files while this thread builds the return values
+        with ThreadPoolExecutor(max_workers=self.io_threads) as ex:
+            pending = self._write_chain_files(tr, ex) if self.write_files else []
+            t3 = time.perf_counter()
+            out = self.show_results(tr, _pool=ex, _pending=pending)
+            t4 = time.perf_counter()
+            for f in pending:
+                f.result()                                   # an I/O error of any file surfaces here
+        t5 = time.perf_counter()
         nlaunch, kms = self._sampler.kernel_time()
-        self.timings = dict(sampling_s=t1 - t0, fetch_s=t2 - t1, chain_files_s=t3 - t2, show_results_s=t4 - t3,
-                            segment_launches=nlaunch, segment_kernel_ms=kms,
+        self.timings = dict(sampling_s=t1 - t0, fetch_s=t2 - t1, chain_files_s=t3 - t2, show_results_s=t4 - t3, files_drain_s=t5 - t4,
+                            files_and_results_s=t5 - t2, segment_launches=nlaunch, segment_kernel_ms=kms,
                             samples_per_s=self.num_chains * (S - 1) / max(t1 - t0, 1e-12))
         pos_w, fx_train, fx_test, rmse_train, rmse_test, acc_train, acc_test, likelihood_vec, accept_vec, accept = out
         swap_perc = self.num_swap * 100 / self.total_swap_proposals            # ZeroDivisionError when no round ran (REG:769)
@@ -276,10 +281,12 @@ class ParallelTemperingBase:
         jobs = []
         for r, T in enumerate(self.temperatures):
             tn = str(T)
-            likeh = np.zeros((S, 2))
+            likeh = np.zeros((S, 2), dtype=np.float32)
             likeh[:, 0] = tr["likeh"][r]
             likeh[0, 1] = -100.0                                                 # row 0 = [-100, -100] (REG:293)
             acc_ratio = int(self._final_accepted[r]) / (S * 1.0) * 100                 # REG:447
+            # float32 arrays go to the C writer as they are (every value printed as the double it converts to, like np.savetxt);
+            # the biggest file first so that the pool's last job is a small one
             jobs += [
                 (f'{self.path}/posterior/pos_w/chain_{tn}.txt', tr["pos_w"][r], '%.18e'),
                 (f'{self.path}/predictions/rmse_test_chain_{tn}.txt', tr["rmse_test"][r], self.rmse_fmt),
@@ -292,44 +299,45 @@ class ParallelTemperingBase:
             ]
         return jobs
 
-    def _write_chain_files(self, tr):
+    def _write_chain_files(self, tr, pool):
+        """Queues every per-chain file on `pool`; returns the futures."""
         # accept_list[i+1] holds the count BEFORE step i (REG:380); the percentage file uses the final count
         self._final_accepted = self._sampler.state()["num_accepted"]
         if self.label_swap:                                  # per temperature: the count of the chain that holds it at the end
             self._final_accepted = self._final_accepted[self._final_holder]
         jobs = self._chain_file_jobs(tr)
-        with ThreadPoolExecutor(max_workers=self.io_threads) as ex:
-            list(ex.map(lambda j: _lib.savetxt(*j), jobs))
+        jobs.sort(key=lambda j: -np.asarray(j[1]).size)
+        return [pool.submit(_lib.savetxt, *j) for j in jobs]
 
     # ------------------------------------------------------------------ show_results (REG:775-871 / CLS:780-893)
     def _likelihood_rows(self, burnin):
         raise NotImplementedError
 
-    def show_results(self, tr=None):
+    def show_results(self, tr=None, _pool=None, _pending=None):
         if tr is None:
             tr = self._sampler.traces()
             if self.label_swap:
                 tr = self._stitch_by_temperature(tr)
         S, R, P = self.NumSamples, self.num_chains, self.num_param
         burnin = int(S * self.burn_in)
+        th = self.io_threads
         # the reference re-reads the per-chain text files, so every value below has been through their format
-        pos_w = tr["pos_w"][:, burnin:, :].astype(np.float64)                    # '%.18e' round-trips exactly
-        rmse_train = _text_round(tr["rmse_train"][:, burnin:], self.rmse_fmt)
-        rmse_test = _text_round(tr["rmse_test"][:, burnin:], self.rmse_fmt)
-        acc_train = _text_round(tr["acc_train"][:, burnin:], '%1.2f')
-        acc_test = _text_round(tr["acc_test"][:, burnin:], '%1.2f')
+        # ('%.18e' round-trips a float32 exactly: the posterior matrix is the traces themselves, cut, widened and transposed)
+        posterior = _lib.posterior_matrix(tr["pos_w"], burnin, th)              # (P, R (S - burnin)) float64
+        rmse_train = _text_round(tr["rmse_train"][:, burnin:], self.rmse_fmt, th)
+        rmse_test = _text_round(tr["rmse_test"][:, burnin:], self.rmse_fmt, th)
+        acc_train = _text_round(tr["acc_train"][:, burnin:], '%1.2f', th)
+        acc_test = _text_round(tr["acc_test"][:, burnin:], '%1.2f', th)
         accept_list = tr["accept"].astype(np.float64)
         lo = self._likelihood_rows(burnin)
-        likelihood_rep = np.zeros((R, S - lo, 2))
-        likelihood_rep[:, :, 0] = _text_round(tr["likeh"][:, lo:], '%1.4f')
+        likelihood_vec = np.zeros((R * (S - lo), 2))                             # rows: chain after chain
+        likelihood_vec[:, 0] = _text_round(tr["likeh"][:, lo:], '%1.4f', th).reshape(-1)
         if lo == 0:
-            likelihood_rep[:, 0, 1] = -100.0
+            likelihood_vec[::S, 1] = -100.0
         accept_percent = np.zeros((R, 1))                                        # never filled (REG:780,860)
 
         fx_train_all = np.zeros((R, S - burnin, np.asarray(self.traindata).shape[0]))
         fx_test_all = np.zeros((R, S - burnin, np.asarray(self.testdata).shape[0]))
-        posterior = pos_w.transpose(2, 0, 1).reshape(P, -1)
-        likelihood_vec = likelihood_rep.transpose(2, 0, 1).reshape(2, -1)
         rmse_train = rmse_train.reshape(R * (S - burnin), 1)
         acc_train = acc_train.reshape(R * (S - burnin), 1)
         rmse_test = rmse_test.reshape(R * (S - burnin), 1)
@@ -337,10 +345,14 @@ class ParallelTemperingBase:
         accept_vec = accept_list
         accept = np.sum(accept_percent) / R
         if self.write_files:
-            _lib.savetxt(self.path + '/likelihood.txt', likelihood_vec.T, '%1.5f')
-            _lib.savetxt(self.path + '/accept_list.txt', accept_list, '%1.2f')
-            _lib.savetxt(self.path + '/acceptpercent.txt', np.array([accept]), '%1.2f')
-        return (posterior, fx_train_all, fx_test_all, rmse_train, rmse_test, acc_train, acc_test, likelihood_vec.T,
+            jobs = [(self.path + '/likelihood.txt', likelihood_vec, '%1.5f'), (self.path + '/accept_list.txt', accept_list, '%1.2f'),
+                    (self.path + '/acceptpercent.txt', np.array([accept]), '%1.2f')]
+            if _pool is not None:
+                _pending.extend(_pool.submit(_lib.savetxt, *j) for j in jobs)
+            else:
+                for j in jobs:
+                    _lib.savetxt(*j)
+        return (posterior, fx_train_all, fx_test_all, rmse_train, rmse_test, acc_train, acc_test, likelihood_vec,
                 accept_vec, accept)
 
     def make_directory(self, directory):

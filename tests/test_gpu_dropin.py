@@ -40,7 +40,7 @@ def _run(key, tmp_path, **kw):
 _RUN_KW = {}
 
 
-@pytest.mark.parametrize("key", ["reg", "reg_nophantom", "cls", "cls_nophantom"])
+@pytest.mark.parametrize("key", ["reg", "reg_nophantom", "cls", "cls_nophantom", "reg_sunspot5"])
 def test_run_chains_return_tuple_matches_reference(key, tmp_path):
     g, pt, res = _run(key, tmp_path)
     names = ["pos_w", "fx_train", "fx_test", "rmse_train", "rmse_test", "acc_train", "acc_test", "likelihood_vec",
@@ -111,8 +111,31 @@ def test_zero_rounds_raises_like_the_reference(tmp_path):
         pt.run_chains()
 
 
+def _expected_driver_row(task, topo, train, test, R, maxtemp, NumSample, si, use_lg, lr, seed, burn_in, problem, col5, rmse_fmt):
+    """Columns 0..13 of the row main() writes (REG:1004-1052 / CLS:1090-1138), computed from an ORACLE run of the same experiment
+    on the same tape (the drop-in's defaults: shared noise tape, Philox stream-3 initial weights rounded to float32): the
+    statistics are taken over what show_results returns, i.e. the per-chain files after burn-in, read back through their text
+    format (REG:795-846)."""
+    import ptnn_oracle_c as orc_c
+    from ptnn_amd import _lib
+    pt = orc.PTOracle(task, topo, train, test, R, maxtemp, NumSample, si, use_lg=use_lg, l_prob=0.5, lr=lr, seed=seed, shared_noise=True)
+    w0 = np.stack([rep.w for rep in pt.replicas]).astype(np.float32).astype(np.float64)
+    orc_c.adopt(pt, w0=w0)
+    pt.run()
+    S = pt.S
+    b = int(S * burn_in)
+    metric, best = ("rmse", np.amin) if task == orc.TASK_REG else ("acc", np.amax)
+    stats = []
+    for part in ("train", "test"):
+        v = _lib.text_round(np.stack([getattr(rep, f"{metric}_{part}")[b:] for rep in pt.replicas]), rmse_fmt if metric == "rmse" else "%1.2f")
+        stats += [np.mean(v), np.std(v), best(v)]
+    accept_per = 100.0 * float(np.mean([rep.accept_list[S - 1] / S for rep in pt.replicas]))
+    return [problem, NumSample, maxtemp, si, col5, lr, *stats, pt.swap_perc, accept_per], pt
+
+
 def test_experiment_drivers(tmp_path):
-    """drivers.run_regression / run_classification: run-dir numbering, result.txt, master_result_file.txt (REG:1044-1061)."""
+    """drivers.run_regression / run_classification: run-dir numbering, result.txt, master_result_file.txt (REG:1044-1061) -- and the
+    VALUES of the row: columns 0..13 against the row computed from an oracle run of the same experiment (column 14 is minutes)."""
     import ptnn_amd
     from ptnn_amd import drivers
     d = parity.datasets()
@@ -125,6 +148,17 @@ def test_experiment_drivers(tmp_path):
         row = open(out["path"] + "/result.txt").read().split()
         assert len(row) == 15 and row[0] == "2.0000" and row[1] == "4000.0000" and row[3] == "10.0000"
         assert all(len(t.split(".")[1]) == 4 for t in row)
+        want, opt = _expected_driver_row(orc.TASK_REG, (4, 5, 1), d["sunspot_train"], d["sunspot_test"], 4, 2, 4000, 10, True, 0.1, 5 + k, 0.5,
+                                         2, 0.5, "%1.8f")
+        got = [float(t) for t in row[:14]]
+        # what the row prints: 4 decimals.  The chains follow the oracle's decisions (1000 steps per chain: a coin flip inside the
+        # fp32 error of log alpha is possible, not expected), so the RMSE statistics agree to the print resolution and the two
+        # percentages exactly (they are ratios of decision counts)
+        np.testing.assert_allclose(got[:6], want[:6], atol=5.1e-5)
+        same_decisions = out["pt"].num_swap == opt.num_swap and int(round(got[13] * 1000 * 4 / 100)) == int(sum(rep.accept_list[-1] for rep in opt.replicas))
+        np.testing.assert_allclose(got[6:12], want[6:12], atol=1.01e-4 if same_decisions else 5e-3, err_msg=f"RMSE statistics of the row, run {k}")
+        np.testing.assert_allclose(got[12:14], want[12:14], atol=5.1e-5 if same_decisions else 1.0, err_msg=f"swap % / accept % of the row, run {k}")
+        assert same_decisions, "the device took a decision the oracle did not within 4 x 1000 steps (possible, but look at it)"
     master = open(base + "master_result_file.txt").read().strip().splitlines()
     assert len(master) == 2 and master[0].split()[-1] == "Sunspot_0" and master[1].split()[-1] == "Sunspot_1"
     assert len(master[0].split()) == 16
@@ -134,6 +168,13 @@ def test_experiment_drivers(tmp_path):
     row = open(out["path_db"] + "/result.txt").read().split()
     assert len(row) == 15 and row[0] == "3.00" and row[2] == "10.00" and row[3] == "20.00"
     assert 0.0 <= float(row[6]) <= 100.0 and 0.0 <= float(row[12]) <= 100.0
+    want, opt = _expected_driver_row(orc.TASK_CLS, (4, 12, 3), d["iris_train"], d["iris_test"], 4, 10, 4000, 20, False, 0.01, 7, 0.5, 3, 0.0, None)
+    got = [float(t) for t in row[:14]]
+    np.testing.assert_allclose(got[:6], want[:6], atol=5.1e-3)
+    # CLS prints 2 decimals; accuracies are multiples of 100 / rows, so one data row predicted differently on some recorded steps
+    # moves a mean by well under a point
+    np.testing.assert_allclose(got[6:12], want[6:12], atol=0.5, err_msg="accuracy statistics of the row")
+    np.testing.assert_allclose(got[12:14], want[12:14], atol=1.0, err_msg="swap % / accept % of the row")
 
 
 def test_streaming_run_chains_equals_resident(tmp_path):
@@ -257,3 +298,70 @@ def test_sharded_handle_without_communicator_is_refused():
     with pytest.raises(_lib.PtnnError, match="equal contiguous blocks"):
         s.comm_init_host(0, 2, lambda b: None, lambda m: None)      # this handle is rank 1 of 2, not rank 0
     s.close()
+
+
+def test_bench_run_bare_starts_its_ranks_and_reports_what_the_communicator_saw(tmp_path):
+    """`python3 bench.py --gpus 2` WITHOUT a launcher (what a driver that runs the N = 1 line as `python3 bench.py --gpus 1` would
+    do for N > 1): the script starts its own two ranks before anything touches the GPU, relays rank 0's one JSON line and ends
+    with status 0.  On this one-GPU box both ranks share GPU 0, so RCCL is not attempted (it refuses two ranks on a device) and the
+    line NAMES the host-staged fall-back; the ranks, devices, bytes and rounds in `comm` are what the communicators report."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(parity.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["config"]["replicas"] == 128
+    c = out["comm"]
+    assert c["nranks_seen"] == 2 and c["transport"] == "host" and c["device_ids"] == [0, 0] and c["launcher"] == "self"
+    assert "RCCL needs one device per rank" in out["config"]["transport_note"]
+    assert c["rounds"] == 100 * (1 + 2) and sum(c["bytes_sent"]) == sum(c["bytes_received"]) > 0      # cumulative: 1 warm-up + 2 timed runs
+    # strong scaling: the workload's 64 replicas in total, 32 per rank
+    r = subprocess.run([sys.executable, os.path.join(parity.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--scaling", "strong"], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["config"]["replicas"] == 64 and out["config"]["replicas_per_gpu"] == 32 and out["comm"]["nranks_seen"] == 2
+
+
+_EXIT_CHILD = """
+import os, sys, warnings
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+import numpy as np
+import ptnn_amd, parity
+from ptnn_amd import distributed, _lib
+from ptnn_amd.pt_timeseries_regression import ParallelTempering
+orig = distributed.LadderGroup.__init__
+def forced(self, devices, **kw):
+    kw["transport"], kw["fallback"] = "rccl", True
+    orig(self, devices, **kw)
+    sys.stdout.write("TRANSPORT %s | %s\\n" % (self.transport, self.transport_note)); sys.stdout.flush()
+distributed.LadderGroup.__init__ = forced
+d = parity.datasets()
+pt = ParallelTempering(True, 0.1, d["sunspot_train"], d["sunspot_test"], [4, 5, 1], 4, 2, 400, 10, 0.5, {path!r}, seed=3, devices=[0, 0], write_files=False)
+warnings.simplefilter("ignore")
+pt.initialize_chains(0.5)
+res = pt.run_chains()
+print("DONE swap_perc %.3f armed %s" % (res[8], distributed._hard_exit_armed), flush=True)
+"""
+
+
+@pytest.mark.parametrize("probe", ["1", "0"])
+def test_process_exits_after_an_rccl_bring_up_that_fails_half_way(tmp_path, probe):
+    """The case the fall-back exists for, end to end in a process of its own: ncclGetUniqueId REALLY runs (RCCL loaded, its bootstrap
+    listener started), then ncclCommInitRank fails ($PTNN_COMM_FAULT=ncclCommInitRank).  With the probe (default) that happens in a
+    throw-away child and the drop-in's process never touches RCCL; with $PTNN_RCCL_PROBE=0 it happens in the drop-in's own process,
+    which then leaves through the hard exit LadderGroup arms.  Either way run_chains() completes on the host-staged transport and
+    THE PROCESS EXITS (a half-initialised RCCL kept it alive before)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PTNN_COMM_FAULT="ncclCommInitRank", PTNN_RCCL_PROBE=probe, PTNN_COMM_TIMEOUT_S="60")
+    code = _EXIT_CHILD.format(root=parity.ROOT, tests=os.path.join(parity.ROOT, "tests"), path=str(tmp_path))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)      # TimeoutExpired = it did not exit
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    assert "TRANSPORT host | host-staged after an RCCL bring-up failure" in r.stdout and "ncclCommInitRank" in r.stdout, r.stdout
+    assert ("RCCL was not touched in this process" in r.stdout) == (probe == "1")
+    assert f"armed {probe == '0'}" in r.stdout, r.stdout

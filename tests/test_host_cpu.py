@@ -220,3 +220,73 @@ def test_problem_loaders_follow_the_reference_rules():
         assert set(np.unique(a[:, 16])) <= set(range(10))
     with pytest.raises(KeyError):
         drivers.load_classification_problem("mnist", REF_CLS)
+
+
+def test_bench_starts_its_own_ranks_when_run_bare(capfd):
+    """`python3 bench.py --gpus N` without a launcher (WORLD_SIZE unset): the plan is N fresh processes of the same script with the
+    same arguments and the launcher's environment variables; rank 0's stdout is relayed as is, the others' to stderr, and the
+    exit status is the worst child's.  (The GPU side of it runs on the box: tests/test_gpu_dropin.py.)"""
+    import sys
+    import bench
+    plans = bench.launch_plan(["--gpus", "4", "--steps", "3", "--workload", "iris16"], 4, master_port=29999, environ={"FOO": "1", "WORLD_SIZE": "9"},
+                              python="py", script="bench.py")
+    assert len(plans) == 4
+    for r, (cmd, env) in enumerate(plans):
+        assert cmd == ["py", "bench.py", "--gpus", "4", "--steps", "3", "--workload", "iris16"]
+        assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"], env["MASTER_PORT"]) == (str(r), str(r), "4", "127.0.0.1", "29999")
+        assert env["FOO"] == "1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["PTNN_BENCH_SELF_LAUNCHED"] == "1"
+    auto = bench.launch_plan([], 2, environ={})
+    assert auto[0][1]["MASTER_PORT"] == auto[1][1]["MASTER_PORT"] and 1024 < int(auto[0][1]["MASTER_PORT"]) < 65536
+    child = "import os, sys; r = int(os.environ['RANK']); print('line of rank', r, 'of', os.environ['WORLD_SIZE']); sys.exit(3 if r == 1 else 0)"
+    fake = [([sys.executable, "-c", child], dict(os.environ, RANK=str(r), WORLD_SIZE="3")) for r in range(3)]
+    rc = bench.self_launch([], 3, plans=fake)
+    out, err = capfd.readouterr()
+    assert rc == 3 and out == "line of rank 0 of 3\n"
+    assert "[rank 1] line of rank 1 of 3" in err and "[rank 2] line of rank 2 of 3" in err
+
+
+@pytest.mark.parametrize("fmt", ["%.18e", "%1.8f", "%1.2f", "%1.4f", "%1.5f", "%.6e", "%10.3f", "%+.3e", "%.0f", "%1.18f"])
+def test_fast_text_path_is_numpy_byte_for_byte(pt, tmp_path, fmt):
+    """The result files are formatted by exact integer arithmetic instead of printf (csrc/ptnn_text.hpp): the bytes must be
+    np.savetxt's for float32 traces (also strided views, repeated rows, append mode) and for arbitrary doubles -- ties (decimal
+    halves that ARE binary fractions round to even), carries (9.99..5 -> 1.0e+01), zeros of both signs, denormals, huge and tiny
+    magnitudes (those take the printf fall-back), non-finite values -- and the read-back value must be np.loadtxt's."""
+    from ptnn_amd import _lib
+    rng = np.random.default_rng(11)
+    mags = 10.0 ** rng.integers(-12, 12, size=(400, 31))
+    f32 = (rng.normal(size=(400, 31)) * mags).astype(np.float32)
+    f32[5:9] = f32[4]                                        # repeated rows (rejected MH steps)
+    f32[100] = [0.0, -0.0, 0.125, 0.375, 2.5, 3.5, -0.5, 0.5, 1.5, 9.5, 99.5, 0.001953125, 999999.5, 9.9999995, 99999.996, 1e-45, 3.4e38,
+                -3.4e38, 1.17549435e-38, 0.1, 0.2, 0.3, 1.0, -1.0, 10.0, 100.0, 1e10, 1e-10, 123456.789, 7.0, 0.999999]
+    special = np.array([0.005, 0.015, 0.025, 2.675, 1e300, -1e300, 5e-324, 2.2250738585072014e-308, np.nan, np.inf, -np.inf, 0.5, 1.5, 2.5,
+                        9.9999999999999995e22, 999999999999999868928.0, 0.99999999999999989, 9.995, 9.9995, 99.99995, 1e22, 1e23, 123456789.125])
+    f64 = np.concatenate([rng.normal(size=4000) * 10.0 ** rng.integers(-25, 25, size=4000), special, f32[100].astype(np.float64)])
+    for arr in (f32, f32[:, :5], f32[::3, 2:9], f32[:, 0], f64, f64.reshape(-1, 2)[:1000]):
+        a, b = tmp_path / "a.txt", tmp_path / "b.txt"
+        np.savetxt(a, arr, fmt=fmt)
+        _lib.savetxt(str(b), arr, fmt)
+        assert a.read_bytes() == b.read_bytes(), (fmt, arr.dtype, arr.shape)
+    # append mode = one file written in windows
+    a, b = tmp_path / "a.txt", tmp_path / "b.txt"
+    np.savetxt(a, f32, fmt=fmt)
+    _lib.savetxt(str(b), f32[:150], fmt)
+    _lib.savetxt(str(b), f32[150:151], fmt, append=True)
+    _lib.savetxt(str(b), f32[151:], fmt, append=True)
+    assert a.read_bytes() == b.read_bytes()
+    # the value np.loadtxt reads back
+    fin = f64[np.isfinite(f64)]
+    for arr in (f32, fin):
+        np.savetxt(a, arr, fmt=fmt)
+        back = np.loadtxt(a).reshape(arr.shape)
+        got = _lib.text_round(arr, fmt, threads=3)
+        assert got.dtype == np.float64 and np.array_equal(back, got), fmt
+
+
+def test_posterior_matrix_is_the_transposed_burn_in_cut(pt):
+    from ptnn_amd import _lib
+    rng = np.random.default_rng(2)
+    for R, S, P, b in ((3, 50, 7, 25), (5, 1000, 31, 500), (2, 9, 4, 0), (1, 5, 3, 5)):
+        pos_w = rng.normal(size=(R, S, P)).astype(np.float32)
+        want = pos_w[:, b:, :].astype(np.float64).transpose(2, 0, 1).reshape(P, -1)
+        for threads in (1, 4):
+            assert np.array_equal(_lib.posterior_matrix(pos_w, b, threads), want)

@@ -123,6 +123,30 @@ def test_forced_decisions_are_reported_not_hidden():
     np.testing.assert_allclose(n.pos_w[:7], c.pos_w[:7], rtol=1e-12)
 
 
+def test_set_state_continues_from_the_given_state():
+    """CReplica.set_state / the sync rows of run(): the chain continues from the imposed (w, eta) with likelihood and prior
+    re-evaluated there -- a chain synced to ITSELF (its own rows, rounded to float32 like a device's) stays within float32
+    rounding of the free chain, and set_state reproduces what a fresh chain computes for that state."""
+    d = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "datasets.npz")))
+    args = (orc.TASK_REG, (4, 5, 1), d["sunspot_train"], d["sunspot_test"])
+    w0 = orc.PhiloxTape(9).w_init(0, 31)
+    a = orc_c.CReplica(*args, w0, 1.3, 80, True, 0.5, 0.1, 9, 0)
+    ra = a.run(0, 79)
+    b = orc_c.CReplica(*args, w0, 1.3, 80, True, 0.5, 0.1, 9, 0)
+    rows = a.pos_w.astype(np.float32)
+    rb = b.run(0, 79, force=ra["natural"], sync_w=rows[1:80])
+    assert (rb["natural"] == ra["natural"]).all()
+    np.testing.assert_allclose(b.pos_w, a.pos_w, rtol=0, atol=3e-7)          # one float32 rounding of a weight of size ~ 1
+    np.testing.assert_allclose(rb["logalpha"], ra["logalpha"], rtol=0, atol=2e-6 * np.max(ra["scale"]))
+    assert np.array_equal(b.w.astype(np.float32), rows[79])                    # the state IS the imposed row (last accepted one)
+    # set_state against a fresh chain started in that state: the same likelihood / prior (fresh chains compute eta from the
+    # residual variance, so hand it that eta)
+    c = orc_c.CReplica(*args, b.w, 1.3, 80, True, 0.5, 0.1, 9, 0)
+    c.adapttemp = b.adapttemp                                                  # past the switch at 0.6 S (R10)
+    c.set_state(b.w, eta=b.eta)
+    assert c.likelihood == pytest.approx(b.likelihood, rel=1e-13) and c.prior_current == pytest.approx(b.prior_current, rel=1e-13)
+
+
 class _OracleAsDevice:
     """A finished oracle run dressed as a `_lib.Sampler` (traces, log alpha, swap log, counters): lets the follow-mode checker of
     tests/parity.py be exercised without a GPU."""
@@ -162,7 +186,10 @@ def test_follow_mode_checker_on_an_oracle_run(datasets, task):
     fake = _OracleAsDevice(dev, o.logalpha[:, :S - 1])
     rep = parity.follow_device_run(fake, fake.traces(), orc_c.adopt(orc.PTOracle(*args, use_lg=lg, lr=lr, seed=seed)), "self ")
     assert rep["forced_mh"] == 0 and rep["forced_swap_pairs"] == 0 and rep["steps"] == R * (S - 1) and rep["steps_over_bound"] == 0
-    assert dev.rounds_done == int(S / si)
+    assert rep["synced"] and dev.rounds_done == int(S / si)
+    # the drift form (decisions imposed, states free) on the same 'device'
+    rep = parity.follow_device_run(fake, fake.traces(), orc_c.adopt(orc.PTOracle(*args, use_lg=lg, lr=lr, seed=seed)), "self ", sync=False)
+    assert rep["forced_mh"] == 0 and rep["steps_over_bound"] == 0 and not rep["synced"]
     # a decision that is no coin flip: flip the accept counter trail of one chain at its most decided step
     tr = fake.traces()
     margin = np.abs(o.logalpha[2, :S - 2] - o.logu[2, :S - 2])
