@@ -225,7 +225,8 @@ def cpu_baseline(wl, train, test, n_steps=101):
                   "sample": f"{R} replicas x MH steps 0..{n_c - 1}, {cores} processes, {sum(t for t, _ in res_c):.1f} s of CPU work"}
     except Exception as e:                                      # noqa: BLE001  (no compiler on the box: the numpy leg stands alone)
         c_port = {"error": repr(e)}
-    return {"value": value, "unit": "samples/s", "cores": cores, "kind": "port", "c_port": c_port,
+    return {"value": value, "unit": f"samples/s (MH steps 0..{n_steps - 1} of every replica: the first swap interval only)", "cores": cores, "kind": "port",
+            "c_port": c_port,
             "port_over_reference": PORT_OVER_REFERENCE,
             "reference_equivalent": value / PORT_OVER_REFERENCE,
             "port_over_reference_source": "BASELINE.md 3.2 / DESIGN.md 8: the reference and the faithful oracle timed on identical work in "
@@ -533,6 +534,18 @@ def main():
             # build, no assumed clock)
             epoch_ms = s.time_sgd_epoch(lad.w0[0], reps=200)
             extras["dependent_chain"] = dependent_chain(s.traces(pos_w=False)["accept"], si, info["slots_per_round"], epoch_ms)
+        if info["schedule"] == "prefetching-tree":
+            # what a round of the tree cannot do without, timed inside a kernel of this process: one forward pass of a node's proposal
+            # by one work-group, and one record granule from one work-group to another (through the path the records take)
+            fw_ms, hop_ms, local = s.time_tree_round(lad.w0[0], reps=200, xcd_local=True)
+            depth = info["slots_per_round"]
+            rounds = -(-si // depth)                            # a round commits `depth` steps whatever the decisions
+            extras["tree_round"] = {"forward_pass_ms": fw_ms, "record_hop_ms": hop_ms, "records_through_xcd_l2": local, "steps_per_round": depth,
+                                    "rounds_per_interval": rounds, "floor_ms_per_interval": rounds * (fw_ms + hop_ms),
+                                    "source": "measured in this process: ptnn_time_tree_round, 200 forward passes of one work-group / 200 granule "
+                                              "round trips between two work-groups of one XCD, in-kernel constant-rate counter",
+                                    "note": "a round = every node's forward pass at the same time, then every work-group needs every record: "
+                                            "no schedule of this tree is faster than rounds x (one forward pass + one record hop)"}
         if a.workload == "sunspot64" and not a.rw and not a.replicas:
             # the other noise mode on the same workload: a few whole runs, timed the same way
             other = 1 - a.shared_noise
@@ -569,7 +582,8 @@ def main():
                 tm = pt.timings
                 extras["end_to_end"] = {"run_chains_s": d3, "value": R * (S - 1) / d3, "unit": "samples/s",
                                         "sampling_s": tm.get("sampling_s"), "trace_download_s": tm.get("fetch_s"),
-                                        "result_files_s": tm.get("chain_files_s"), "show_results_s": tm.get("show_results_s"),
+                                        "files_and_results_s": tm.get("files_and_results_s"), "show_results_s": tm.get("show_results_s"),
+                                        "files_queue_s": tm.get("chain_files_s"), "files_drain_s": tm.get("files_drain_s"),
                                         "result_file_bytes": nbytes,
                                         "pcie_inclusive_samples_per_s": R * (S - 1) / max((tm.get("sampling_s") or 0) + (tm.get("fetch_s") or 0), 1e-9),
                                         "note": "the drop-in ParallelTempering(...).run_chains() of this workload, files included; reported, "
@@ -585,12 +599,14 @@ def main():
         P = lad.P
         # mandatory HBM traffic of one MH step of one replica = the trace row the result files require,
         # 4 (P + 7) bytes (pos_w row + likeh + 2 rmse + 2 acc + accept count); a swap round adds 4 (P + 2) per replica
-        bytes_per_launch = R * steps_per_launch * 4 * (P + 7) + R * 4 * (P + 2)
+        rounds_per_launch = rounds * K / max(launches, 1)            # a persistent launch holds every swap round of its run
+        bytes_per_launch = R * steps_per_launch * 4 * (P + 7) + rounds_per_launch * R * 4 * (P + 2)
         flops_per_launch = R * steps_per_launch * flops_per_step(wl["topo"], train.shape[0], test.shape[0], 0.5 if wl["lg"] else 0.0)
         traffic, traffic_tag = pmc_traffic(a.workload, info["kernel"]) if (a.schedule, a.waves, a.groups, a.rw, a.bf16, a.replicas) == (0, 0, 0, False, False, 0) and N == 1 else (None, None)
         roof = {"bound": "hbm", "achieved": bytes_per_launch / avg_launch_s / 1e9 if launches else 0.0, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "traffic": traffic, "kernel": info["kernel"], "avg_launch_ms": avg_launch_s * 1e3,
-                "launches": launches, "mh_steps_per_launch": steps_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
+                "launches": launches, "mh_steps_per_launch": steps_per_launch, "swap_rounds_per_launch": rounds_per_launch,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
                 "traffic_source": f"profiles/current_pmc_{a.workload}.json ({traffic_tag}: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch, "
                                   "separate passes of this command)" if traffic else None,
                 "valu_tflops": flops_per_launch / avg_launch_s / 1e12 if launches else 0.0,
@@ -608,6 +624,20 @@ def main():
                              "sgd_epoch_ms": dc["sgd_epoch_ms"],
                              "note": "floor = (accepted steps of the slowest replica of an interval, mean over the run's intervals) x one "
                                      "sequential SGD epoch timed in this process; measured = dominant kernel time per swap interval"}
+        trd = extras.get("tree_round")
+        if trd and launches:
+            intervals_per_launch = max(1.0, steps_per_launch / si)
+            measured = avg_launch_s * 1e3 / intervals_per_launch
+            roof["tree"] = {"floor_ms": trd["floor_ms_per_interval"], "measured_ms": measured, "frac": trd["floor_ms_per_interval"] / measured if measured else None,
+                            "unit": "ms per swap interval", "forward_pass_ms": trd["forward_pass_ms"], "record_hop_ms": trd["record_hop_ms"],
+                            "rounds_per_interval": trd["rounds_per_interval"],
+                            "note": "floor = rounds per interval x (one forward pass of a node by one work-group + one record granule between two "
+                                    "work-groups), both timed in this process; measured = dominant kernel time per swap interval"}
+        # ONE number per configuration: the fraction of the bound that actually binds this schedule
+        if "chain" in roof:
+            roof["binding"] = {"kind": "dependent chain of sequential SGD epochs", "frac": roof["chain"]["frac"], "see": "roofline.chain"}
+        elif "tree" in roof:
+            roof["binding"] = {"kind": "rounds of the prefetching tree (forward pass + record exchange)", "frac": roof["tree"]["frac"], "see": "roofline.tree"}
         roof["note"] = ("instruction-issue / dependent-chain bound by construction (sequential SGD rows, arithmetic intensity far "
                         "above the machine balance); the HBM fraction is reported because BASELINE.json asks for it")
         if info.get("forward_mfma"):
@@ -632,6 +662,10 @@ def main():
                 roof["mfma"]["pipe"] = {"achieved": R * steps_per_launch * pipe / avg_launch_s / 1e12 if launches else 0.0,
                                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s (bf16, padded tiles, 6 products)"}
                 roof["mfma"]["pipe"]["frac"] = roof["mfma"]["pipe"]["achieved"] / MFMA_BF16_PEAK_TFLOPS
+        if "binding" not in roof:
+            # cooperative and wide schedules: every CU runs one chain's step; what binds is vector issue (sigmoid / W2 epilogue, SGD
+            # rows), not the matrix pipe
+            roof["binding"] = {"kind": "fp32 vector issue on the busy CUs", "frac": roof["valu_frac_of_busy_cus"], "see": "roofline.valu_frac_of_busy_cus"}
         out = {
             "metric": "MCMC samples/sec (all replicas) + swap-accept rate; " + ("Sunspot 64-replica FNN" if a.workload == "sunspot64" else wl["desc"]),
             "value": value, "unit": "samples/s", "n_gpus": N, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,

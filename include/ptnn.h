@@ -288,6 +288,12 @@ int ptnn_langevin_gradient(ptnn_handle *h, const float *w_in, int n, float *w_ou
  * ms_per_epoch[2]: [0] one epoch; [1] wide nets (n_hidden > 64) only: a PAIR of epochs run through one row loop (what two Langevin
  * steps of one speculative window cost together), else 0. */
 int ptnn_time_sgd_epoch(ptnn_handle *h, const float *w, int reps, double *ms_per_epoch);
+/* What a round of the prefetching-tree schedule cannot do without, timed on the device (in-kernel constant-rate counter, `reps`
+ * repetitions): ms[0] = one forward pass over all rows with the likelihood and prior sums by one work-group of the handle's block
+ * size (what a node does between its proposal and its record); ms[1] = one {tag, value} granule from one work-group to another,
+ * one way (half a round trip between two work-groups of one XCD), through the XCD's L2 when xcd_local != 0 and the two groups
+ * report the same XCC id (ms[2] = 1), else through the agent-scope path.  bench.py's roofline.tree floor is made of these. */
+int ptnn_time_tree_round(ptnn_handle *h, const float *w, int reps, int xcd_local, double *ms);
 /* the random tape of MH step `step` of global replica `replica`: noise [P] normals, scal[3] = {lx, u, n_eta} */
 int ptnn_tape(ptnn_handle *h, int replica, int step, float *noise, float *scal);
 

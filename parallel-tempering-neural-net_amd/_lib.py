@@ -88,6 +88,7 @@ SYMBOLS = {
     "ptnn_evaluate": (C.c_int, [C.c_void_p, _fp, _fp, C.c_int, _fp]),
     "ptnn_langevin_gradient": (C.c_int, [C.c_void_p, _fp, C.c_int, _fp]),
     "ptnn_time_sgd_epoch": (C.c_int, [C.c_void_p, _fp, C.c_int, C.POINTER(C.c_double)]),
+    "ptnn_time_tree_round": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "ptnn_tape": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp, _fp]),
     "ptnn_describe": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "ptnn_kernel_time": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -422,6 +423,13 @@ class Sampler:
         ms = (C.c_double * 2)()
         self._check(self.lib.ptnn_time_sgd_epoch(self.h, _ptr(w), int(reps), ms))
         return (ms[0], ms[1]) if pair else ms[0]
+
+    def time_tree_round(self, w, reps=200, xcd_local=True):
+        """(forward pass ms, one granule one way ms, went through the XCD's L2?) -- ptnn_time_tree_round."""
+        w = _f32(w).reshape(-1)
+        ms = (C.c_double * 3)()
+        self._check(self.lib.ptnn_time_tree_round(self.h, _ptr(w), int(reps), int(bool(xcd_local)), ms))
+        return ms[0], ms[1], bool(ms[2])
 
     def tape(self, replica, step):
         noise, scal = np.empty(self.P, np.float32), np.empty(3, np.float32)

@@ -160,6 +160,7 @@ struct ptnn_handle {
         p.L_raw = (cfg.swap_rule == 1) ? d_L_raw : nullptr; p.prior_post = d_prior_post;
         p.tr_pos_w = d_pos_w; p.tr_scal = d_scal; p.PW = PW;
         p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.xverdict = d_xverdict; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.noise_shared = cfg.shared_noise ? 1 : 0; p.pk_nred = pk_nred; p.xt = d_xt; p.xs = reinterpret_cast<const uint4*>(d_xs); p.Npad = Npad; p.fw_mfma = fw_mfma; p.xy_global = xy_global ? 1 : 0; p.forward_bf16 = cfg.forward_bf16 == 1 ? 1 : 0; p.tree_ahead = tree_ahead ? 1 : 0; p.compact = compact ? 1 : 0;
+        { const char* e = std::getenv("PTNN_XCD_GRANULES"); p.xcd_granules = (e && e[0] == '0') || cfg.shared_device ? 0 : 1; }
         // wide nets over several work-groups: a window of 16 steps lets the groups balance Langevin (10 units) against random-walk
         // (1) steps (measured on config 5: 8 steps 0.680 M, 12: 0.692 M, 16: 0.698 M samples/s; wide nets accept 1 - 5 %, so little of
         // a window is thrown away); random-walk-only runs have nothing to balance and a longer window only wastes what follows an accept
@@ -372,6 +373,12 @@ int resolve_persistent(ptnn_handle* h) {
     if ((e && e[0] == '0') || h->cfg.shared_device) return 0;     // grid barriers want every work-group resident: not on a shared GPU
     const int G = ((h->speculative || h->tree || h->wide) ? h->groups : 1);
     if (G > 1 && !(e && e[0] == '1')) return 0;
+    // One barrier per round (G == 1) leaves the posted scalars single-buffered: a work-group that has left the barrier reads all R of
+    // them into LDS at once (cascade_lds), and the next write to any of them comes a whole swap interval later, at the end of the
+    // writer's next interval.  The invariant "no resident work-group falls a whole interval behind between leaving a barrier and its
+    // next few loads" holds with orders of magnitude to spare for intervals of tens of microseconds; for intervals of a few MH steps
+    // of a small net it is not worth relying on: those runs take one launch per interval (a kernel boundary orders everything).
+    if (h->cfg.swap_interval < 8 && !(e && e[0] == '1')) return 0;
     // kernels compiled without the interval loop (ptnn_device.hpp: persistent_loop<false>)
     if ((h->speculative && !h->packed) || h->tree || (h->packed && h->groups > 1)) return 0;
     if (h->packed && !(h->shape->loops & 2)) return 0;
@@ -1678,8 +1685,10 @@ static int run_model(ptnn_handle* h, int mode, const float* w_in, const float* t
         HIP_TRY(hipMemcpy(d_tau, tau_sq, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMalloc(&d_out, out_floats * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(d_out, 0, out_floats * sizeof(float), h->stream));
     const SegParams p = h->seg_params();
-    hipLaunchKernelGGL(h->wide ? h->shape->model_wide : h->shape->model, dim3(n), dim3(h->model_threads), h->model_lds, h->stream, p,
+    // mode 4 (ptnn_time_tree_round): ONE input row, but 9 blocks -- blocks 0 and 8 share an XCD under the round-robin dispatch
+    hipLaunchKernelGGL(h->wide ? h->shape->model_wide : h->shape->model, dim3(mode == 4 ? 9 : n), dim3(h->model_threads), h->model_lds, h->stream, p,
                        mode, d_w, d_tau, d_out, a0, a1);
     HIP_TRY(hipGetLastError());
     if (int rc = wait_stream(h)) return rc;
@@ -1716,6 +1725,26 @@ int ptnn_time_sgd_epoch(ptnn_handle* h, const float* w, int reps, double* ms_per
     ms_per_epoch[0] = ticks(0) / (double)khz / (double)reps;
     // wide nets (n_hidden > 64): [1] = a PAIR of epochs through one row loop (sgd_sweep_wide_pair); narrow nets: 0
     ms_per_epoch[1] = h->wide ? ticks(2) / (double)khz / (double)reps : 0.0;
+    return 0;
+}
+
+int ptnn_time_tree_round(ptnn_handle* h, const float* w, int reps, int xcd_local, double* ms) {
+    if (!h || !w || !ms || reps < 1) return fail(-1, "bad argument");
+    if (h->wide) return fail(-3, "the prefetching tree runs nets of up to 64 hidden units");
+    float out[64] = {0.f};
+    if (int rc = run_model(h, 4, w, nullptr, 1, out, 64, reps, xcd_local ? 1 : 0)) return rc;
+    int khz = 0;
+    HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->cfg.device_id));
+    if (khz <= 0) return fail(-2, "the device reports no wall clock rate");
+    if (out[4] != 1.0f) return fail(-2, "the granule round trips between two work-groups timed out");
+    auto ticks = [&](int k) {
+        unsigned lo, hi;
+        std::memcpy(&lo, &out[k], 4); std::memcpy(&hi, &out[k + 1], 4);
+        return (double)(((unsigned long long)hi << 32) | lo);
+    };
+    ms[0] = ticks(0) / (double)khz / (double)reps;             // one forward pass + likelihood + prior sums of a whole work-group
+    ms[1] = ticks(2) / (double)khz / (double)reps / 2.0;       // one granule, one way (half a round trip)
+    ms[2] = (double)out[5];                                    // 1: the round trips went through the XCD's L2
     return 0;
 }
 

@@ -27,6 +27,17 @@ namespace ptnn {
 constexpr int TASK_REG = 0;
 constexpr int TASK_CLS = 1;
 constexpr int WAVE = 64;
+// Diagnostic hooks.  The product build contains none of the diagnostic code: STAMP / FW_DBG / PTNN_DIAG expand to nothing.  A
+// diagnostic build (-DPTNN_STAMPS, profiles/tools/build_stamps.sh; never the product) includes ptnn_diag.hpp, which holds the
+// bodies: in-kernel cycle stamps per phase of a round, summed into SegParams::stamps and read back by ptnn_debug_stamps.
+#ifdef PTNN_STAMPS
+#include "ptnn_diag.hpp"
+#else
+#define STAMP(slot) do { } while (0)
+#define FW_DBG(q_) do { } while (0)
+#define PTNN_DIAG(name)
+#endif
+
 constexpr int MAX_WAVES = 8;            // waves per work-group: 2 per SIMD, 256 VGPRs each
 constexpr int MAX_THREADS = MAX_WAVES * WAVE;
 
@@ -102,6 +113,7 @@ struct SegParams {
     int forward_bf16;        // 1: forward GEMM operands rounded to bf16 (fp32 accumulate); 0: exact fp32 MFMA
     int* seg_progress;       // pinned host word or null (RCCL communicator attached): block 0 stores seg_ordinal when this launch ends
     int seg_ordinal;         // with a swap round due -- "the collective of round seg_ordinal - 1 is next on the stream" (ptnn.hip: wait_stream)
+    int xcd_granules;        // 1: work-groups of a replica that find themselves on one XCD exchange through its L2 (granule_*_xcd); 0: always agent scope
     int compact;             // wide nets, all rows resident (trace_cap == S): a REJECTED step writes no pos_w row, only the index of the
                              // row it repeats (TR_SRC); ptnn_get_traces fills the rows in.  A 70 KB copy per rejected step otherwise.
 };
@@ -1267,13 +1279,6 @@ __device__ __forceinline__ void split_weights(uint4* as, int H, F wval) {
     }
 }
 
-#ifdef PTNN_STAMPS
-static __device__ unsigned long long fw_dbg[8];              // diagnostic build: cycles of the phases of eval_rows_mfma_coop (block 0, wave 0)
-#define FW_DBG(q_) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-                        fw_dbg[q_] += t_ - fw_t; fw_t = t_; } } while (0)
-#else
-#define FW_DBG(q_) do { } while (0)
-#endif
 template <int TASK, int I, int O, bool LEAN = false>
 __device__ __forceinline__ EvalSums eval_rows_mfma_coop(const float* __restrict__ wl, const float* __restrict__ xt,
                                                         float* __restrict__ part, const float* __restrict__ xy, int IPY,
@@ -1284,9 +1289,7 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_coop(const float* __restrict_
     const int col = lane & 31, half = lane >> 5;
     const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
     const int ntiles = (H + 31) >> 5;
-#ifdef PTNN_STAMPS
-    unsigned long long fw_t = __builtin_amdgcn_s_memtime();
-#endif
+    PTNN_DIAG(fw_begin);
     // phase 1: one unit = 32 data rows x 32 hidden units (11 row blocks x 2 tiles for Ionosphere).  With two tiles the waves
     // split between them, so a wave keeps ONE tile's operands -- the weights (A), biases and W2 rows of its 32 hidden units --
     // in registers for all of its row blocks, and only the data columns (B) change.  Up to three row blocks run at once:
@@ -1434,9 +1437,7 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_split(const float* __restrict
     const int oW2 = I * H, oB1 = oW2 + H * O, oB2 = oB1 + H;
     const int ntiles = (H + 31) >> 5, Hpad = ntiles << 5;
     float* __restrict__ part = sl.part;
-#ifdef PTNN_STAMPS
-    unsigned long long fw_t = __builtin_amdgcn_s_memtime();
-#endif
+    PTNN_DIAG(fw_begin);
     const int nrb = Npad >> 5;
     const int tsplit = (ntiles == 2 && nw >= 2) ? 2 : 1;
     const int t0 = (tsplit == 2) ? (wave & 1) : 0, tcount = (tsplit == 2) ? 1 : ntiles;
@@ -1539,11 +1540,7 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_split(const float* __restrict
                 if (half == 0) part[((size_t)t * Npad + n) * O + o] = tot;
             }
         };
-#if PTNN_ABLATE == 5
-        if (false) {
-#else
         if (rb0 < nrb) {
-#endif
             BFrag bcur, bnxt;
             load_b(rb0, bcur);
             int rb = rb0, nx = rb0 + rbstride;
@@ -1576,11 +1573,7 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_split(const float* __restrict
     float b2[O];
 #pragma unroll
     for (int o = 0; o < O; ++o) b2[o] = wl[oB2 + o];
-#if PTNN_ABLATE == 3
-    for (int n = threadIdx.x; n < 0; n += blockDim.x) {
-#else
     for (int n = threadIdx.x; n < Nall; n += blockDim.x) {
-#endif
         float tot[O];
 #pragma unroll
         for (int o = 0; o < O; ++o) {
@@ -1615,30 +1608,12 @@ __device__ __forceinline__ EvalSums eval_rows_mfma_split(const float* __restrict
         else { a_te += a; b_te += bb; c_te += c; }
     }
     FW_DBG(2);
-#if PTNN_ABLATE == 4
-    EvalSums es_; es_.a_tr = a_tr; es_.b_tr = b_tr; es_.c_tr = c_tr; es_.a_te = a_te; es_.b_te = b_te; es_.c_te = c_te;
-#else
     const EvalSums es_ = reduce_eval<TASK, false, LEAN>(a_tr, b_tr, c_tr, a_te, b_te, c_te, red, extra);
-#endif
     FW_DBG(3);
     return es_;
 }
 
 
-// Diagnostic build only (-DPTNN_STAMPS): wave 0 of the first work-group of replica 0 adds up shader-clock cycles per phase
-// of a round and writes the sums to p.stamps at the end.  In the product build no stamp executes.
-#ifdef PTNN_STAMPS
-#define STAMP(slot)                                                                          \
-    do {                                                                                     \
-        if (stamp_on) {                                                                      \
-            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                      \
-            __builtin_amdgcn_s_waitcnt(0xC07F);                                              \
-            stamp_acc[slot] += t_ - stamp_last; stamp_last = t_;                             \
-        }                                                                                    \
-    } while (0)
-#else
-#define STAMP(slot) do { } while (0)
-#endif
 
 template <int TASK, int I, int O>
 __device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& dyn, const int step_begin, const int n_steps) {
@@ -1699,13 +1674,7 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& d
         nacc = si[SI_NACC]; gd_valid = dyn.gd_valid[r]; lg_count = si[SI_LG_COUNT];
     }
 
-#ifdef PTNN_STAMPS
-    const bool stamp_on = (blockIdx.x == 0 && tid < WAVE);
-    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    const unsigned long long stamp_t0 = stamp_last;
-#endif
+    PTNN_DIAG(coop_begin);
     const size_t trow = (size_t)r * p.trace_cap;        // traces are rings of trace_cap rows per replica (== S unless streaming)
     // A step is three phases between two work-group barriers (a random-walk step; a Langevin step adds its SGD epochs):
     //   A  proposal and its packed forward image in one pass over the weights
@@ -1786,9 +1755,7 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& d
         } else if (p.fw_mfma) {
             for (int j = tid; j < P; j += nthr) w_prop[j] = fmaf(p.step_w, noise[j], w_cur[j]);
             // the split image of W1 is formed from the same expression, so nobody waits for w_prop
-#if PTNN_ABLATE != 6
             if constexpr (SplitK<I>::OK) { if (split) split_weights<I>(sl.as, H, [&](int idx) { return fmaf(p.step_w, noise[idx], w_cur[idx]); }); }
-#endif
         } else {
             propose_build_fw<I, O>(w_cur, noise, p.step_w, w_prop, l.fw, H, p.FWS);
         }
@@ -1802,9 +1769,6 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& d
         if (i + 1 < step_end) {
             float* const nn = l.noise + (par ^ 1) * (PS + 8);
             float* const ns = l.scal + (par ^ 1) * (PS + 8);
-#if PTNN_ABLATE == 1
-            if (i == step_begin)                            // timing experiment: the tape of one step only (results are garbage)
-#endif
             {
             if (!tape_one_wave) tape_step(p, gid, i + 1, nn, ns);
             else if (wave == nwaves - 1) tape_step<true>(p, gid, i + 1, nn, ns);
@@ -1846,9 +1810,6 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& d
         ring_pos = (ring_pos + 1 == p.trace_cap) ? 0 : ring_pos + 1;
         float* prow = p.tr_pos_w + tpos * (size_t)p.PW;
         const float* const w_rec = wbuf + o_rec;
-#if PTNN_ABLATE == 2
-        if (i == step_begin)
-#endif
         for (int j = tid; j < p.PW; j += nthr) prow[j] = (j < P) ? w_rec[j] : 0.0f;
         if (tid == 0) {
             store_trace_row(p.tr_scal + tpos * TR_COUNT, (TASK == TASK_REG) ? lik_prop : lik_prop * adapttemp /* REG:391 / CLS:404 */,
@@ -1856,14 +1817,7 @@ __device__ __forceinline__ void segment_body(const SegParams& p, const SegDyn& d
         }
         STAMP(6);                                         // trace row
     }
-#ifdef PTNN_STAMPS
-    if (stamp_on && (tid & 63) == 0 && p.stamps) {
-        for (int q_ = 0; q_ < 9; ++q_) atomicAdd(p.stamps + q_, stamp_acc[q_]);
-        atomicAdd(p.stamps + 9, (unsigned long long)n_steps);
-        atomicAdd(p.stamps + 10, __builtin_amdgcn_s_memtime() - stamp_t0);
-        if (tid == 0) for (int q_ = 0; q_ < 8; ++q_) { atomicAdd(p.stamps + 150 + q_, fw_dbg[q_]); fw_dbg[q_] = 0; }
-    }
-#endif
+    PTNN_DIAG(coop_flush);
 
     // write the chain state back and post the swap scalars
     __syncthreads();
@@ -1917,6 +1871,55 @@ __device__ __forceinline__ bool granule_wait(const granule_t* g, unsigned epoch,
     }
     return false;
 }
+// The same granule between work-groups that are KNOWN to sit on one XCD (they share its L2): non-temporal store and load
+// (`nt`: neither written through to memory like the agent-scope store, nor served from the reader's L1 like a plain or sc0 load).
+// Measured (profiles/tools/micro/granule_pingpong.hip, profiles/r04_granule_pingpong.txt): one way 227 ns instead of 588 ns, and no
+// fabric traffic (the agent-scope pair costs ~32 B written + ~64 B fetched per message); between two XCDs an nt store never arrives.
+// So: only after the work-groups have compared their XCC ids through the agent-scope path (xcc_id below; the tree does it in the
+// first round of every launch).
+__device__ __forceinline__ int xcc_id() {
+    int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 0xf;
+}
+__device__ __forceinline__ void granule_store_xcd(granule_t* g, unsigned epoch, float v) {
+    const granule_t x = ((granule_t)epoch << 32) | (granule_t)__builtin_bit_cast(unsigned, v);
+    asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(g), "v"(x) : "memory");
+}
+__device__ __forceinline__ bool granule_wait_xcd(const granule_t* g, unsigned epoch, float& v, unsigned limit = SPIN_LIMIT) {
+    for (unsigned spins = 0; spins < limit; ++spins) {
+        granule_t x;
+        asm volatile("global_load_dwordx2 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(g) : "memory");
+        if ((unsigned)(x >> 32) == epoch) { v = __builtin_bit_cast(float, (unsigned)x); return true; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+// Do the G work-groups of a replica share an XCD?  Asked once per launch, before the first round: every group stores its XCC id
+// with an AGENT-scope store (write-through: it reaches memory, and it is in the writer's L2) into its own granule of `ids`, and
+// reads the others' with `nt` loads.  On one XCD those loads hit the common L2: everybody sees G equal ids -- without a byte of
+// fabric traffic for the polling (agent-scope polling of the same granules was most of what the tree still fetched per launch).
+// A group on ANOTHER XCD reads a different id, or a line its own L2 fetched too early and keeps (then the bounded wait runs out):
+// either way it answers no, and so does everybody who waits for it -- the verdict is the same in every group, because "all G ids
+// equal mine, seen through L2" can only hold for all of them at once.  `tmp`: G floats of LDS; ends with a work-group barrier.
+constexpr unsigned XCD_HANDSHAKE_SPINS = 1u << 15;          // a few milliseconds: the groups of one launch start microseconds apart
+__device__ __forceinline__ bool xcd_handshake_strided(granule_t* ids, int stride, int G, int grp, unsigned tag, float* tmp) {
+    const int my_xcc = xcc_id();
+    if (threadIdx.x == 0) granule_store(ids + (size_t)grp * stride, tag, (float)my_xcc);
+    if ((int)threadIdx.x < G) {
+        float v = -1.0f;
+        if (!granule_wait_xcd(ids + (size_t)threadIdx.x * stride, tag, v, XCD_HANDSHAKE_SPINS)) v = -2.0f;
+        tmp[threadIdx.x] = v;
+    }
+    __syncthreads();
+    bool same = true;
+    for (int g_ = 0; g_ < G; ++g_) same = same && (tmp[g_] == (float)my_xcc);
+    __syncthreads();
+    return same;
+}
+__device__ __forceinline__ bool xcd_handshake(granule_t* ids, int G, int grp, unsigned tag, float* tmp) {
+    return xcd_handshake_strided(ids, 1, G, grp, tag, tmp);
+}
 
 
 // Work-groups are dispatched round-robin to the 8 XCDs (each with its own L2).  The work-groups of ONE replica exchange records
@@ -1937,10 +1940,7 @@ __device__ __forceinline__ int xcd_block(int G) {
 template <int TASK, int I, int O>
 __device__ __forceinline__ void segment_spec_body(const SegParams& p, const SegDyn& dyn, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-#ifdef PTNN_STAMPS
-    const unsigned long long stamp_entry = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
+    PTNN_DIAG(spec_entry);
     const int G = p.G;
     const int lb = xcd_block(G);
     const int r = lb / G, grp = lb - r * G;
@@ -2015,16 +2015,7 @@ __device__ __forceinline__ void segment_spec_body(const SegParams& p, const SegD
         nacc = uni_i(si[SI_NACC]); gd_valid = uni_i(dyn.gd_valid[r]); lg_count = uni_i(si[SI_LG_COUNT]); lg_acc = uni_i(si[SI_LG_ACC]);
     }
 
-#ifdef PTNN_STAMPS
-    const bool stamp_on = (blockIdx.x == 0 && wave == 0);
-    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    unsigned long long stamp_rounds = 0;
-    const unsigned long long stamp_t0 = stamp_last;
-    const unsigned long long stamp_rt0 = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
+    PTNN_DIAG(spec_begin);
     const size_t trow = (size_t)r * p.trace_cap;        // traces are rings of trace_cap rows per replica (== S unless streaming)
     const int end = step_begin + n_steps;
     int i = step_begin;
@@ -2034,9 +2025,7 @@ __device__ __forceinline__ void segment_spec_body(const SegParams& p, const SegD
     STAMP(0);                                             // launch prologue: staging, start-up
     while (i < end) {
         epoch += 1;
-#ifdef PTNN_STAMPS
-        stamp_rounds += 1;
-#endif
+        PTNN_DIAG(count_round);
         if (i == p.switch_step) {
             // R10 (REG:320-324): canonical from here on; re-evaluate the current w with the LAST PROPOSED tau (Q9)
             if (wave == 0) {
@@ -2278,25 +2267,7 @@ __device__ __forceinline__ void segment_spec_body(const SegParams& p, const SegD
         par ^= 1;
         STAMP(8);                                         // commit: trace rows, state update
     }
-#ifdef PTNN_STAMPS
-    if (stamp_on && lane == 0 && p.stamps) {
-        for (int q_ = 0; q_ < 9; ++q_) atomicAdd(p.stamps + q_, stamp_acc[q_]);
-        atomicAdd(p.stamps + 9, stamp_rounds);
-        atomicAdd(p.stamps + 10, __builtin_amdgcn_s_memtime() - stamp_t0);          // shader clock ticks
-        atomicAdd(p.stamps + 11, __builtin_amdgcn_s_memrealtime() - stamp_rt0);     // 100 MHz ticks
-    }
-    if (tid == 0 && p.stamps) {                               // 100 MHz timeline of this work-group: entry, loop start, loop end
-        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-        atomicMin(p.stamps + 12, stamp_entry);
-        atomicMax(p.stamps + 13, stamp_rt0 - stamp_entry);      // longest prologue
-        atomicMax(p.stamps + 14, now - stamp_rt0);              // longest round loop
-        atomicMax(p.stamps + 15, now);                          // last loop end
-    }
-    if (grp == 0 && tid == 0 && p.stamps && r < 64) {        // per-replica totals: cycles in the round loop, rounds
-        atomicAdd(p.stamps + 16 + 2 * r, __builtin_amdgcn_s_memtime() - stamp_t0);
-        atomicAdd(p.stamps + 17 + 2 * r, stamp_rounds);
-    }
-#endif
+    PTNN_DIAG(spec_flush);
 
     if (failed) {
         if (tid == 0) atomicAdd(p.error_flag, 1);           // a bounded spin ran out: the host reports it
@@ -2436,14 +2407,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
         nacc = uni_i(si[SI_NACC]); gd_valid = uni_i(dyn.gd_valid[r]); lg_count = uni_i(si[SI_LG_COUNT]); lg_acc = uni_i(si[SI_LG_ACC]);
     }
 
-#ifdef PTNN_STAMPS
-    const bool stamp_on = (blockIdx.x == 0 && wave == 0);
-    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    unsigned long long stamp_rounds = 0, stamp_eval = 0;
-    const unsigned long long stamp_t0 = stamp_last;
-#endif
+    PTNN_DIAG(pack_begin);
     const size_t trow = (size_t)r * p.trace_cap;
     const int end = step_begin + n_steps;
     const bool sweeping = p.use_lg != 0;
@@ -2483,6 +2447,13 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
     };
     fill_ring(step_begin, step_begin + RING, wave, nwaves);
     int ring_hi = step_begin + RING;                        // first step whose tape is not in the ring yet
+    // MULTI: when the work-groups of this replica share an XCD, the rounds' verdicts and the accepted step travel through that XCD's L2
+    // (granule_*_xcd); asked once per launch (xcd_handshake; tag epoch_base: the rounds use epoch_base + 1 ...; granules 32 .. 32 + G of
+    // the verdict row, which the rounds never touch)
+    bool xcd_local = false;
+    if constexpr (MULTI) {
+        if (p.xcd_granules) xcd_local = xcd_handshake(xv + 32, G, grp, dyn.epoch_base, gverd);
+    }
     __syncthreads();
     while (i < end && !failed) {
         if (MULTI) { epoch += 1; }
@@ -2502,9 +2473,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
         int kt = min(KT, end - i);                          // steps of this round's window (all work-groups of the replica)
         if (p.switch_step > i) kt = min(kt, p.switch_step - i);
         const int k = MULTI ? max(0, min(PK_SLOTS, kt - s0)) : kt;   // ... of which this work-group computes slots s0 .. s0 + k - 1
-#ifdef PTNN_STAMPS
-        stamp_rounds += 1;
-#endif
+        PTNN_DIAG(count_round);
         STAMP(0);
         if (sweeping && !gd_valid) {                       // chain start, or w arrived from another GPU
             if (wave == 0) sgd_sweep_dispatch<TASK, I, O>(w_cur, w_gd, xy, p.data, p.Ntr, H, p.lr);
@@ -2531,9 +2500,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
             }
         }
         STAMP(3);                                           // sweep
-#ifdef PTNN_STAMPS
-        const unsigned long long ev_t0 = __builtin_amdgcn_s_memtime();
-#endif
+        PTNN_DIAG(pack_eval_begin);
         if (ev_i >= 0) {
             for (int s_ = ev_i; s_ < k; s_ += ev_n) {
                 const int j = i + s0 + s_;
@@ -2572,9 +2539,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
             fill_ring(ring_hi, i + RING, ev_i, ev_n);
         }
         ring_hi = i + RING;
-#ifdef PTNN_STAMPS
-        if (ev_i == 0) stamp_eval += __builtin_amdgcn_s_memtime() - ev_t0;
-#endif
+        PTNN_DIAG(pack_eval_end);
         __syncthreads();
         STAMP(4);                                           // waiting for the forward passes
         // phase 3: Metropolis-Hastings ratio of every slot
@@ -2618,15 +2583,17 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
             // every work-group posts its verdict; one with an accepted slot posts that slot's scalars and vectors with it (it may not
             // be the window's first: the readers take the winner's only)
             granule_t* const xv_r = xv + (size_t)xpar * MAX_SLOTS;
-            if (tid == 0) granule_store(xv_r + grp, epoch, (float)ml);
+            auto gstore = [&](granule_t* g_, float v_) { if (xcd_local) granule_store_xcd(g_, epoch, v_); else granule_store(g_, epoch, v_); };
+            auto gwait = [&](const granule_t* g_, float& v_) { return xcd_local ? granule_wait_xcd(g_, epoch, v_) : granule_wait(g_, epoch, v_); };
+            if (tid == 0) gstore(xv_r + grp, (float)ml);
             if (ml >= 0) {
-                if (tid < SL_COUNT) granule_store(xsl + ((size_t)xpar * MAX_SLOTS + grp) * SL_COUNT + tid, epoch, sm[tid]);
+                if (tid < SL_COUNT) gstore(xsl + ((size_t)xpar * MAX_SLOTS + grp) * SL_COUNT + tid, sm[tid]);
                 granule_t* const xo = xwv + ((size_t)xpar * G + grp) * 2 * PS;
-                for (int e = tid; e < 2 * PS; e += nthr) granule_store(xo + e, epoch, wacc[e]);
+                for (int e = tid; e < 2 * PS; e += nthr) gstore(xo + e, wacc[e]);
             }
             if (tid < G) {
                 float v = 0.0f;
-                if (!granule_wait(xv_r + tid, epoch, v)) v = -2.0f;
+                if (!gwait(xv_r + tid, v)) v = -2.0f;
                 gverd[tid] = v;
             }
             __syncthreads();
@@ -2643,13 +2610,13 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
                 bool ok = true;
                 if (tid < SL_COUNT) {
                     float v;
-                    ok = granule_wait(xsl + ((size_t)xpar * MAX_SLOTS + win) * SL_COUNT + tid, epoch, v);
+                    ok = gwait(xsl + ((size_t)xpar * MAX_SLOTS + win) * SL_COUNT + tid, v);
                     win_s[tid] = v;
                 }
                 const granule_t* const xi = xwv + ((size_t)xpar * G + win) * 2 * PS;
                 for (int e = tid; e < 2 * PS; e += nthr) {
                     float v;
-                    ok = granule_wait(xi + e, epoch, v) && ok;
+                    ok = gwait(xi + e, v) && ok;
                     win_v[e] = v;
                 }
                 failed = __syncthreads_or(ok ? 0 : 1) != 0;
@@ -2711,18 +2678,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
         if (tpos0 >= p.trace_cap) tpos0 -= p.trace_cap;
         STAMP(6);                                           // commit
     }
-#ifdef PTNN_STAMPS
-    if (stamp_on && lane == 0 && p.stamps) {
-        for (int q_ = 0; q_ < 9; ++q_) atomicAdd(p.stamps + q_, stamp_acc[q_]);
-        atomicAdd(p.stamps + 9, stamp_rounds);
-        atomicAdd(p.stamps + 10, __builtin_amdgcn_s_memtime() - stamp_t0);
-    }
-    if (blockIdx.x == 0 && ev_i == 0 && lane == 0 && p.stamps) atomicAdd(p.stamps + 11, stamp_eval);
-    if (tid == 0 && p.stamps && r < 64) {
-        atomicAdd(p.stamps + 16 + 2 * r, __builtin_amdgcn_s_memtime() - stamp_t0);
-        atomicAdd(p.stamps + 17 + 2 * r, stamp_rounds);
-    }
-#endif
+    PTNN_DIAG(pack_flush);
 
     if (failed) {
         if (tid == 0) atomicAdd(p.error_flag, 1);           // a bounded spin ran out: the host reports it
@@ -4146,27 +4102,37 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
     // what the scoring reads as xy[n * stride + I]
     const float* const ysrc = mfma ? xy - I : xy;
     const int ystride = mfma ? 1 : p.IPY;
-    if (mfma) {
-        for (int n = tid; n < Nall; n += nthr) xy[n] = p.data[(size_t)n * p.IPY + I];
-    } else {
-        const float4* src = reinterpret_cast<const float4*>(p.data);
-        float4* dst = reinterpret_cast<float4*>(xy);
-        for (int e = tid; e < ((Nall + 2) * p.IPY) >> 2; e += nthr) dst[e] = src[e];
-    }
     float* gw = dyn.w_state + (size_t)r * PS;
-    for (int j = tid; j < PS; j += nthr) {
-        w_cur[j] = gw[j];
-        rec_w[j] = p.rec_w[(size_t)r * PS + j];
-    }
-    if constexpr (SplitK<I>::OK) {
-        if (split) {
-            sl = carve_split<I>(xt_l, O, H, p.Npad);
-            stage_split_data<I>(sl, p.data, p.IPY, Nall, p.Npad);
+    auto stage = [&]() {                                   // the launch's working set: global memory -> LDS
+        if (mfma) {
+            for (int n = tid; n < Nall; n += nthr) xy[n] = p.data[(size_t)n * p.IPY + I];
+        } else {
+            const float4* src = reinterpret_cast<const float4*>(p.data);
+            float4* dst = reinterpret_cast<float4*>(xy);
+            for (int e = tid; e < ((Nall + 2) * p.IPY) >> 2; e += nthr) dst[e] = src[e];
         }
-    }
-    if (p.fw_mfma == 1)
-        for (int e = tid; e < I * p.Npad; e += nthr) xt_l[e] = p.xt[e];
+        for (int j = tid; j < PS; j += nthr) {
+            w_cur[j] = gw[j];
+            rec_w[j] = p.rec_w[(size_t)r * PS + j];
+        }
+        if constexpr (SplitK<I>::OK) {
+            if (split) {
+                sl = carve_split<I>(xt_l, O, H, p.Npad);
+                stage_split_data<I>(sl, p.data, p.IPY, Nall, p.Npad);
+            }
+        }
+        if (p.fw_mfma == 1)
+            for (int e = tid; e < I * p.Npad; e += nthr) xt_l[e] = p.xt[e];
+    };
+    stage();
     __syncthreads();
+    // When all groups of the replica sit on one XCD (xcd_block arranges that wherever the grid allows; asked once per launch:
+    // xcd_handshake, granule 7 of every node's record row, which the records do not use), the records travel through that XCD's L2
+    // alone (granule_store_xcd / granule_wait_xcd), else through the agent-scope path.  (Letting the root group stage first, so
+    // that the other 14 hit the lines it brought into the L2, was measured: no less fetched, 1 % slower -- what this kernel still
+    // fetches per launch is its own code and the data image once per XCD, profiles/README.md.)
+    granule_t* const xrec = reinterpret_cast<granule_t*>(p.xslots) + (size_t)r * 2 * (TREE_MAX_NODES + 1) * TREE_REC;
+    const bool xcd_local = p.xcd_granules != 0 && xcd_handshake_strided(xrec + 7, TREE_REC, G, g, dyn.epoch_base, recs);
 
     const float T = p.temps[r];
     float eta = 0.0f;                                      // classification: no noise parameter
@@ -4190,7 +4156,6 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
     lik = uni_f(lik); prior_cur = uni_f(prior_cur); nacc = uni_i(nacc);
     rec_rmse_tr = uni_f(rec_rmse_tr); rec_rmse_te = uni_f(rec_rmse_te); rec_acc_tr = uni_f(rec_acc_tr); rec_acc_te = uni_f(rec_acc_te);
 
-    granule_t* const xrec = reinterpret_cast<granule_t*>(p.xslots) + (size_t)r * 2 * (TREE_MAX_NODES + 1) * TREE_REC;
     const size_t trow = (size_t)r * p.trace_cap;
     const int step_end = step_begin + n_steps;
     const int nq1 = ((P + 3) >> 2) + 1;
@@ -4222,16 +4187,7 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
     };
     int tpar = 0;
     if (ahead && i < step_end) { draw_tapes(tapes0, i, round_steps(i)); __syncthreads(); }
-#ifdef PTNN_STAMPS
-    // phases of a round, root group of replica 0: 0 loop head / switch, 1 tapes, 2 proposal, 3 forward pass, 4 publish + next tapes,
-    // 5 wait for the records, 6 decisions, 7 state + trace rows
-    const bool stamp_on = (lb == 0 && tid < WAVE);
-    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    const unsigned long long stamp_t0 = stamp_last;
-    unsigned long long stamp_rounds = 0;
-#endif
+    PTNN_DIAG(tree_begin);
     while (i < step_end) {
         const int dr = round_steps(i);
         float* const tapes = tapes0 + (size_t)tpar * D * (PS + 8);
@@ -4317,7 +4273,8 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
             float v = rv[0];
 #pragma unroll
             for (int f = 1; f < TREE_FIELDS; ++f) v = (tid == f) ? rv[f] : v;
-            granule_store(xr + (size_t)g * TREE_REC + tid, epoch, v);
+            if (xcd_local) granule_store_xcd(xr + (size_t)g * TREE_REC + tid, epoch, v);
+            else granule_store(xr + (size_t)g * TREE_REC + tid, epoch, v);
         }
         // ... and while the records travel, the tapes of the next round (they depend on step numbers only)
         if (ahead && i + dr < step_end) draw_tapes(tapes0 + (size_t)(tpar ^ 1) * D * (PS + 8), i + dr, round_steps(i + dr));
@@ -4327,10 +4284,11 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
         for (int q = tid; q < G * TREE_FIELDS; q += nthr) {
             const int nd_ = q / TREE_FIELDS, f_ = q - nd_ * TREE_FIELDS;
             float v = 0.0f;
-            ok = granule_wait(xr + (size_t)nd_ * TREE_REC + f_, epoch, v) && ok;
+            ok = (xcd_local ? granule_wait_xcd(xr + (size_t)nd_ * TREE_REC + f_, epoch, v) : granule_wait(xr + (size_t)nd_ * TREE_REC + f_, epoch, v)) && ok;
             recs[nd_ * TREE_REC + f_] = v;
         }
         if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
+
         STAMP(5);
         // 6. the dr decisions, by every thread alike: each against the likelihood / prior of the state the walk has reached
         unsigned accmask = 0, my_mask = 0;
@@ -4359,6 +4317,7 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
             nd = 2 * nd + (accept ? 1 : 0);
         }
         STAMP(6);
+        STAMP(6);
         // 7. the new state, rebuilt from the tapes, and the trace rows (row of step i + l: the recorded vector after that
         //    step's decision = the state after it if anything was accepted up to there, else the old recorded vector)
         const bool write_row = g < dr;
@@ -4386,21 +4345,13 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
         }
         __syncthreads();                                    // the next round's tapes and proposals read what was just written
         STAMP(7);
-#ifdef PTNN_STAMPS
-        stamp_rounds += 1;
-#endif
+        PTNN_DIAG(count_round);
         i += dr;
         epoch += 1;
         par ^= 1;
         if (ahead) tpar ^= 1;
     }
-#ifdef PTNN_STAMPS
-    if (stamp_on && tid == 0) {
-        for (int q_ = 0; q_ < 9; ++q_) atomicAdd(p.stamps + q_, stamp_acc[q_]);
-        atomicAdd(p.stamps + 9, stamp_rounds);
-        atomicAdd(p.stamps + 10, __builtin_amdgcn_s_memtime() - stamp_t0);
-    }
-#endif
+    PTNN_DIAG(tree_flush);
     if (failed) {
         if (tid == 0) atomicAdd(p.error_flag, 1);           // a bounded spin ran out: the host reports it
         return;
@@ -4445,8 +4396,58 @@ __global__ void __launch_bounds__(MAX_THREADS) model_kernel(const SegParams p, c
         float4* dst = reinterpret_cast<float4*>(l.xy);
         for (int e = tid; e < ((Nall + 2) * p.IPY) >> 2; e += nthr) dst[e] = src[e];
     }
-    for (int j = tid; j < p.P; j += nthr) l.w_cur[j] = w_in[(size_t)b * p.P + j];
+    for (int j = tid; j < p.P; j += nthr) l.w_cur[j] = w_in[(size_t)(mode == 4 ? 0 : b) * p.P + j];
     __syncthreads();
+    if (mode == 4) {
+        // The two things a round of the prefetching tree cannot do without, timed with the constant-rate counter (ptnn_time_tree_round;
+        // bench.py's roofline.tree): (a) block 0: a0 times what a node does between its proposal and its record -- the packed
+        // forward image, the forward pass over all rows, the likelihood and the prior's sum of squares in the same reduction;
+        // (b) blocks 0 and 8 -- one XCD under the round-robin dispatch -- a0 round trips of one granule through the path the
+        // tree's records take (a1 = 1: through the XCD's L2 when both blocks report the same XCC id, else agent scope).
+        granule_t* const ga = reinterpret_cast<granule_t*>(out + 16);
+        granule_t* const gb = ga + 8;                          // its own 64-byte line
+        if (b == 0) {
+            unsigned long long t_fw = 0, t_rt = 0;
+            float keep = 0.0f;
+            const unsigned long long t0 = wall_clock64();
+            for (int rep = 0; rep < a0; ++rep) {
+                build_fw<I, O>(l.w_cur, l.fw, p.H, p.FWS);
+                __syncthreads();
+                float ssq = 0.0f;
+                for (int j = tid; j < p.P; j += nthr) ssq = fmaf(l.w_cur[j], l.w_cur[j], ssq);
+                const EvalSums es = eval_rows<TASK, I, O, false, true>(l.fw, l.xy, p.IPY, p.FWS, p.H, p.Ntr, Nall, l.red, ssq);
+                keep += finish_loglik<TASK>(es, p.Ntr, 0.0f) + prior_value<TASK>(p, ssq, 0.0f);
+                __syncthreads();
+            }
+            t_fw = wall_clock64() - t0;
+            int ok = 1, local = 0;
+            if (tid == 0) {
+                float v = 0.0f;
+                granule_store(ga, 0x51000000u, (float)xcc_id());
+                ok = granule_wait(gb, 0x51000000u, v) ? 1 : 0;
+                local = (a1 != 0 && ok && (int)v == xcc_id()) ? 1 : 0;
+                const unsigned long long t1 = wall_clock64();
+                for (int k = 1; k <= a0 && ok; ++k) {
+                    if (local) { granule_store_xcd(ga, 0x51000000u + k, 1.0f); ok = granule_wait_xcd(gb, 0x51000000u + k, v) ? 1 : 0; }
+                    else { granule_store(ga, 0x51000000u + k, 1.0f); ok = granule_wait(gb, 0x51000000u + k, v) ? 1 : 0; }
+                }
+                t_rt = wall_clock64() - t1;
+                out[0] = __uint_as_float((unsigned)(t_fw & 0xffffffffull)); out[1] = __uint_as_float((unsigned)(t_fw >> 32));
+                out[2] = __uint_as_float((unsigned)(t_rt & 0xffffffffull)); out[3] = __uint_as_float((unsigned)(t_rt >> 32));
+                out[4] = (float)ok; out[5] = (float)local; out[6] = keep;
+            }
+        } else if (b == 8 && tid == 0) {
+            float v = 0.0f;
+            int ok = granule_wait(ga, 0x51000000u, v) ? 1 : 0;
+            const int local = (a1 != 0 && ok && (int)v == xcc_id()) ? 1 : 0;
+            granule_store(gb, 0x51000000u, (float)xcc_id());
+            for (int k = 1; k <= a0 && ok; ++k) {
+                if (local) { ok = granule_wait_xcd(ga, 0x51000000u + k, v) ? 1 : 0; granule_store_xcd(gb, 0x51000000u + k, 1.0f); }
+                else { ok = granule_wait(ga, 0x51000000u + k, v) ? 1 : 0; granule_store(gb, 0x51000000u + k, 1.0f); }
+            }
+        }
+        return;
+    }
     if (mode == 1) {
         if (tid < WAVE) sgd_sweep_dispatch<TASK, I, O>(l.w_cur, l.w_gd, l.xy, p.data, p.Ntr, p.H, p.lr);
         __syncthreads();
@@ -4492,8 +4493,11 @@ __global__ void __launch_bounds__(MAX_THREADS) model_kernel(const SegParams p, c
 // barrier (the other work-groups of a replica re-stage the moved row), and the next interval.  All R x G work-groups must be
 // resident (the host checks the occupancy of THIS kernel and otherwise launches one interval at a time with pp.swap_inside = 0,
 // pp.end = the end of the interval, followed by swap_kernel: the round-2 shape); the barrier spins are bounded like every other
-// cross-work-group wait and a timeout surfaces through the error flag.  Bit-identical to the per-interval launches by
-// construction: an interval runs the same body from the same global state, the round runs the same swap_block.
+// cross-work-group wait and a timeout surfaces through the error flag.  Identical to the per-interval launches because an interval
+// runs the same body from the same global state and the round runs the same swap_block -- under ONE timing invariant where a round
+// has a single barrier (one work-group per replica): the posted scalars (L_handoff / L_final / L_raw) are single-buffered, every
+// work-group copies all of them into LDS right after the barrier (cascade_lds), and the next write to any of them is a whole swap
+// interval away.  The host only takes this shape for intervals of 8 MH steps or more (ptnn.hip: resolve_persistent).
 // ------------------------------------------------------------------------------------------------
 struct PersistParams {
     int end;                 // MH steps are run up to here (exclusive)

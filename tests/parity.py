@@ -462,7 +462,7 @@ def follow_device_run(s, tr, pt, label="", threads=8, row_rtol=None, row_atol=No
             for nm in ("acc_train", "acc_test", "rmse_train", "rmse_test"):
                 n_rows = (pt.train if nm.endswith("train") else pt.test).shape[0]
                 rows_close(tr[nm][r], getattr(rep, nm), 0.0, (300.0 / n_rows + 1e-3) if nm.startswith("acc") else 0.08, nm[:4] + "_abs_excess")
-    if probing:
+    if os.environ.get("PTNN_PARITY_PROBE"):
         import json
         with open(os.environ["PTNN_PARITY_PROBE"], "a") as f:
             f.write(json.dumps(dict(label=label + "follow rows", **report)) + "\n")

@@ -290,3 +290,21 @@ def test_posterior_matrix_is_the_transposed_burn_in_cut(pt):
         want = pos_w[:, b:, :].astype(np.float64).transpose(2, 0, 1).reshape(P, -1)
         for threads in (1, 4):
             assert np.array_equal(_lib.posterior_matrix(pos_w, b, threads), want)
+
+
+def test_recorded_bf16_study_meets_its_stated_bounds():
+    """profiles/r04_bf16_study.json (BASELINE config 5's fp32 vs bf16 tolerance study, recorded on the MI355X by
+    profiles/tools/bf16_study.py: 128 chains x 200 steps per forward mode, every accepted step's log-likelihood against the float64
+    oracle at identical inputs) against the bounds the GPU test holds a live, smaller run to."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpu_parity_bounds", os.path.join(ROOT, "tests", "test_gpu_parity.py"))
+    src = open(spec.origin).read()
+    ns = {}
+    a = src.index("BF16_STUDY_BOUNDS = {")
+    b = src.index("def test_config5_bf16_forward_tolerance_study")
+    exec(src[a:b], ns)                                       # the bounds table and its checker: plain Python, no GPU import
+    study = json.load(open(os.path.join(ROOT, "profiles", "r04_bf16_study.json")))
+    ns["check_bf16_study"](study, decisions_min=128 * 200)
+    m = study["modes"]
+    assert m["split"]["flips"] == 0 and m["exact"]["flips"] == 0 and m["split"]["chains_identical_to_exact"] == 128
+    assert m["bf16"]["chains_identical_to_exact"] < 128 and m["bf16"]["flips"] > 0
