@@ -268,15 +268,20 @@ def dependent_chain(tr_accept, si, slots, epoch_ms):
                     "and every accepted Langevin step costs one more sequential SGD epoch whatever the number of speculative slots"}
 
 
-def pmc_traffic(workload, kernel):
+def pmc_traffic(workload, kernel, steps_per_launch):
     """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate passes of this same command, gfx950 FETCH_SIZE x2 correction applied; profiles/summarize.py)."""
+    WRITE_SIZE in separate passes of this same command, gfx950 FETCH_SIZE x2 correction applied; profiles/summarize.py) -- only
+    when "a launch" meant the same number of MH steps there as in this run (a schedule that has since moved from one launch per
+    swap interval to one per run must be profiled again)."""
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", f"current_pmc_{workload}.json")))
+        then = pmc.get("mh_steps_per_launch") or (pmc.get("bench_kt") or {}).get("roofline", {}).get("mh_steps_per_launch")
+        if then and abs(then - steps_per_launch) > 0.01 * steps_per_launch:
+            return None, None
         stem = kernel.split("::")[-1].split("<")[0] + "<"
         for kn, e in pmc["kernels"].items():
             if stem in kn and "hbm_bytes_per_launch" in e:
-                return e["hbm_bytes_per_launch"], pmc.get("tag")
+                return e["hbm_bytes_per_launch"], f"{pmc.get('tag')}, commit {pmc.get('commit')}"
     except Exception:
         pass
     return None, None
@@ -602,7 +607,7 @@ def main():
         rounds_per_launch = rounds * K / max(launches, 1)            # a persistent launch holds every swap round of its run
         bytes_per_launch = R * steps_per_launch * 4 * (P + 7) + rounds_per_launch * R * 4 * (P + 2)
         flops_per_launch = R * steps_per_launch * flops_per_step(wl["topo"], train.shape[0], test.shape[0], 0.5 if wl["lg"] else 0.0)
-        traffic, traffic_tag = pmc_traffic(a.workload, info["kernel"]) if (a.schedule, a.waves, a.groups, a.rw, a.bf16, a.replicas) == (0, 0, 0, False, False, 0) and N == 1 else (None, None)
+        traffic, traffic_tag = pmc_traffic(a.workload, info["kernel"], steps_per_launch) if (a.schedule, a.waves, a.groups, a.rw, a.bf16, a.replicas) == (0, 0, 0, False, False, 0) and N == 1 else (None, None)
         roof = {"bound": "hbm", "achieved": bytes_per_launch / avg_launch_s / 1e9 if launches else 0.0, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "traffic": traffic, "kernel": info["kernel"], "avg_launch_ms": avg_launch_s * 1e3,
                 "launches": launches, "mh_steps_per_launch": steps_per_launch, "swap_rounds_per_launch": rounds_per_launch,

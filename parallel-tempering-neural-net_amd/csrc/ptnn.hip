@@ -372,17 +372,22 @@ int resolve_persistent(ptnn_handle* h) {
     const char* e = std::getenv("PTNN_PERSISTENT");
     if ((e && e[0] == '0') || h->cfg.shared_device) return 0;     // grid barriers want every work-group resident: not on a shared GPU
     const int G = ((h->speculative || h->tree || h->wide) ? h->groups : 1);
-    if (G > 1 && !(e && e[0] == '1')) return 0;
+    // The prefetching tree runs its swap rounds inside the launch by itself (segment_tree_body: the root groups exchange scalars and
+    // state rows as granules, no grid barrier): the reference's cascade without label swapping, a ladder that is not sharded, and as
+    // many replicas as the cascade has room for in the record area of LDS.  One launch per run then, unless $PTNN_PERSISTENT=0.
+    const bool tree_inside = h->tree && h->cfg.swap_rule == 0 && !h->cfg.label_swap && h->d_xw != nullptr &&
+                             h->cfg.n_replicas_local == h->cfg.n_replicas_global && h->cfg.n_replicas_global <= TREE_PERSIST_MAX_R;
+    if (G > 1 && !tree_inside && !(e && e[0] == '1')) return 0;
     // One barrier per round (G == 1) leaves the posted scalars single-buffered: a work-group that has left the barrier reads all R of
     // them into LDS at once (cascade_lds), and the next write to any of them comes a whole swap interval later, at the end of the
     // writer's next interval.  The invariant "no resident work-group falls a whole interval behind between leaving a barrier and its
     // next few loads" holds with orders of magnitude to spare for intervals of tens of microseconds; for intervals of a few MH steps
     // of a small net it is not worth relying on: those runs take one launch per interval (a kernel boundary orders everything).
-    if (h->cfg.swap_interval < 8 && !(e && e[0] == '1')) return 0;
+    if (h->cfg.swap_interval < 8 && !tree_inside && !(e && e[0] == '1')) return 0;
     // kernels compiled without the interval loop (ptnn_device.hpp: persistent_loop<false>)
-    if ((h->speculative && !h->packed) || h->tree || (h->packed && h->groups > 1)) return 0;
+    if ((h->speculative && !h->packed) || (h->tree && !tree_inside) || (h->packed && h->groups > 1)) return 0;
     if (h->packed && !(h->shape->loops & 2)) return 0;
-    if (!h->wide && !h->packed && !h->speculative && !(h->shape->loops & 1)) return 0;
+    if (!h->wide && !h->packed && !h->speculative && !h->tree && !(h->shape->loops & 1)) return 0;
     const size_t swap_lds = (size_t)(3 * h->cfg.n_replicas_global + 1) * sizeof(float);
     if (swap_lds > h->seg_lds) {
         if (swap_lds > 152 * 1024) return 0;
@@ -886,6 +891,13 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
             const size_t ng = (size_t)Rl * 2 * (TREE_MAX_NODES + 1) * TREE_REC;
             HIP_TRY(hipMalloc(&h->d_xslots, ng * sizeof(unsigned long long)));
             HIP_TRY(hipMemset(h->d_xslots, 0, ng * sizeof(unsigned long long)));
+            // granules of the in-launch swap rounds (two parities), when the whole ladder is on this handle
+            if (h->d_xw) { HIP_TRY(hipFree(h->d_xw)); h->d_xw = nullptr; }
+            if (h->cfg.n_replicas_local == h->cfg.n_replicas_global) {
+                const size_t nxg = 2 * tree_xchg_granules(h->cfg.n_replicas_global, h->PS);
+                HIP_TRY(hipMalloc(&h->d_xw, nxg * sizeof(unsigned long long)));
+                HIP_TRY(hipMemset(h->d_xw, 0, nxg * sizeof(unsigned long long)));
+            }
             h->epoch_base = 1;                                  // tag 0 = never written
         } else if (explicit_tree) {
             return fail(-3, "tree schedule: %d replicas x %d work-groups of %d threads cannot all be resident on %d CUs (or need more than "

@@ -1871,10 +1871,11 @@ __device__ __forceinline__ bool granule_wait(const granule_t* g, unsigned epoch,
     }
     return false;
 }
-// The same granule between work-groups that are KNOWN to sit on one XCD (they share its L2): non-temporal store and load
-// (`nt`: neither written through to memory like the agent-scope store, nor served from the reader's L1 like a plain or sc0 load).
-// Measured (profiles/tools/micro/granule_pingpong.hip, profiles/r04_granule_pingpong.txt): one way 227 ns instead of 588 ns, and no
-// fabric traffic (the agent-scope pair costs ~32 B written + ~64 B fetched per message); between two XCDs an nt store never arrives.
+// The same granule between work-groups that are KNOWN to sit on one XCD (they share its L2): a plain store (into that L2, not
+// written through to memory like the agent-scope store) and a non-temporal load (`nt`: not served from the reader's L1 like a plain or
+// sc0 load).  Measured (profiles/tools/micro/granule_pingpong.hip, profiles/r04_granule_pingpong.txt): one way 241 ns instead of
+// 508 - 588 ns, and no fabric traffic (the agent-scope pair costs ~32 B written + ~64 B fetched per message); between two XCDs such a
+// store never arrives.
 // So: only after the work-groups have compared their XCC ids through the agent-scope path (xcc_id below; the tree does it in the
 // first round of every launch).
 __device__ __forceinline__ int xcc_id() {
@@ -1884,7 +1885,11 @@ __device__ __forceinline__ int xcc_id() {
 }
 __device__ __forceinline__ void granule_store_xcd(granule_t* g, unsigned epoch, float v) {
     const granule_t x = ((granule_t)epoch << 32) | (granule_t)__builtin_bit_cast(unsigned, v);
-    asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(g), "v"(x) : "memory");
+    // a plain store: write-through the CU's L1 into the XCD's L2, where the line stays (write-back, ordinary replacement) and is
+    // rewritten two rounds later.  With `nt` on the STORE the line is marked evict-first: under the stream of trace rows every
+    // granule went out to memory on its own (Iris, one launch per run: 131 MB written per run against 77 MB of trace rows; the
+    // agent-scope path 118 MB) -- profiles/README.md, r04d vs r04e.  The polling LOAD keeps `nt` (it must not be served from L1).
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(g), "v"(x) : "memory");
 }
 __device__ __forceinline__ bool granule_wait_xcd(const granule_t* g, unsigned epoch, float& v, unsigned limit = SPIN_LIMIT) {
     for (unsigned spins = 0; spins < limit; ++spins) {
@@ -3826,10 +3831,11 @@ struct SwapParams {
 __host__ __device__ inline int xchg_row_floats(int PS) { return (2 * PS + 4 + 3) & ~3; }
 
 // sSrc has R + 1 ints: the last one carries the number of accepted swaps
-__device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, float* sL, float* sU, int* sSrc) {
+// have_L: sL already holds the R posted scalars (the tree's in-launch swap round reads them from granules)
+__device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, float* sL, float* sU, int* sSrc, bool have_L = false) {
     const int R = sp.R;
     for (int k = threadIdx.x; k < R; k += blockDim.x) {
-        sL[k] = sp.L[(size_t)(sp.label_mode ? sp.slot_cur[k] : k) * sp.L_stride];    // k is a temperature index
+        if (!have_L) sL[k] = sp.L[(size_t)(sp.label_mode ? sp.slot_cur[k] : k) * sp.L_stride];    // k is a temperature index
         if (k < R - 1) {
             uint32_t x[4];
             philox4x32_10((uint32_t)k, (uint32_t)round, 0u, STREAM_SWAP, sp.seed_lo, sp.seed_hi, x);
@@ -4071,6 +4077,48 @@ __host__ __device__ inline size_t tree_lds_floats(int Nall, int IPY, int PS, int
            MAX_WAVES * 8 + (size_t)(TREE_MAX_NODES + 1) * TREE_REC;
 }
 
+// What a launch that spans several swap intervals needs to know (persistent_loop at the end of this file; the tree body runs its
+// own swap rounds and reads it too)
+struct PersistParams {
+    int end;                 // MH steps are run up to here (exclusive)
+    int swap_inside;         // 1: the swap rounds between the intervals run inside this launch
+    int task, si;            // hand-off rule (Q10): REG after step i when i % si == 0 and i != 0; CLS when (i + 1) % si == 0
+    int round0;              // index of the first swap round of this launch
+    int flip0, lflip0;       // which state / label-map buffers are current at entry
+    int nblocks;             // work-groups of the grid
+    unsigned* barrier;       // [nblocks] phase every work-group has reached, zero at launch
+    float* state[2];
+    float* gd[2];
+    int* gd_valid[2];
+    int* label[2];
+    int* slot_of[2];
+    SwapParams sp;           // everything of a round that does not flip
+};
+
+// The PersistParams of the launch, read from the kernel-argument segment where it lies (second argument, behind SegParams) through
+// a pointer the optimiser cannot see through: every use re-loads the few words it needs (scalar loads from the constant cache)
+// instead of keeping ~60 words of it live across the interval body -- hoisted out of the loop they were spilled into vector
+// registers and, in the two kernels closest to the register ceiling, on into scratch.
+typedef __attribute__((address_space(4))) const PersistParams* persist_cptr;
+__device__ __forceinline__ persist_cptr persist_args() {
+    constexpr size_t off = (sizeof(SegParams) + alignof(PersistParams) - 1) & ~(alignof(PersistParams) - 1);
+    unsigned long long a = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + off;
+    asm volatile("" : "+s"(a));
+    return (persist_cptr)(uintptr_t)a;
+}
+
+typedef __attribute__((address_space(4))) const SegParams* seg_cptr;
+__device__ __forceinline__ seg_cptr seg_args() {
+    unsigned long long a = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(a));
+    return (seg_cptr)(uintptr_t)a;
+}
+
+// Granules of the tree's in-launch swap round, per parity: R posted scalars (padded to 8), R state rows for the other replicas' root
+// groups, R rows {flag, new state} from every root to its own siblings
+__host__ __device__ inline size_t tree_xchg_granules(int R, int PS) { return (size_t)((R + 7) & ~7) + (size_t)R * PS + (size_t)R * (PS + 8); }
+constexpr int TREE_PERSIST_MAX_R = ((TREE_MAX_NODES + 1) * TREE_REC - 1) / 3;      // the cascade's 3 R + 1 floats live in the record area of LDS
+
 template <int TASK, int I, int O>
 __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegDyn& dyn, const int step_begin, const int n_steps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -4163,10 +4211,24 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
     int par = 0;
     bool failed = false;
     int i = step_begin;
+    // One launch for several swap intervals (PersistParams::swap_inside; the host takes this shape when the whole grid is resident):
+    // the swap round after a hand-off step runs inside the launch, below.  ho_next = the next hand-off step (Q10: REG after step i
+    // when i % si == 0 and i != 0, CLS when (i + 1) % si == 0), as persistent_loop and ptnn_run find it.
+    persist_cptr const pp = persist_args();
+    const bool swap_inside = pp->swap_inside != 0;
+    const int si_ = pp->si;
+    auto next_handoff = [&](int cur) {
+        if (TASK == TASK_REG) { const int c1 = cur > 1 ? cur : 1; return ((c1 + si_ - 1) / si_) * si_; }
+        return ((cur + si_) / si_) * si_ - 1;
+    };
+    int ho_next = swap_inside ? next_handoff(step_begin) : 0x7fffffff;
+    int nx = 0;                                             // swap rounds done inside this launch
     // steps of the round that starts at step `first`: a round never crosses the temperature switch (its re-evaluation opens one)
+    // nor a hand-off
     auto round_steps = [&](int first) {
         int n = min(D, step_end - first);
         if (p.switch_step > first) n = min(n, p.switch_step - first);
+        if (swap_inside && ho_next >= first) n = min(n, ho_next - first + 1);
         return n;
     };
     // the random tapes of `count` steps from `first` (tape_step's body, flattened over (step, counter quad))
@@ -4350,6 +4412,63 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
         epoch += 1;
         par ^= 1;
         if (ahead) tpar ^= 1;
+        if (swap_inside && i == ho_next + 1 && ho_next < step_end) {
+            // ---- the swap round of this hand-off (REG:427-437 <-> 719-752), inside the launch.  The ROOT group of every replica
+            // posts its scalar (Q11) and its state row as granules (agent scope: the other replicas sit on other XCDs), reads all R
+            // scalars, computes the cascade (the code swap_kernel runs: cascade_lds on the same uniforms), fetches the row of its
+            // source replica and hands {moved?, new state} to its own siblings -- through the XCD's L2 when they share it.  The
+            // likelihood and prior stay the ones of the state that left (Q12).  Granules are two-deep by round parity: a root posts
+            // round k + 2 only after it has read every scalar of round k + 1, which their owners post after reading round k.
+            const int Rg = pp->sp.R;
+            const unsigned xtag = dyn.epoch_base + (unsigned)nx + 1u;
+            granule_t* const xl = p.xw + (size_t)(nx & 1) * tree_xchg_granules(Rg, PS);
+            granule_t* const xst = xl + ((Rg + 7) & ~7);
+            granule_t* const xsb = xst + (size_t)Rg * PS + (size_t)gid * (PS + 8);
+            auto gstore = [&](granule_t* g_, float v_) { if (xcd_local) granule_store_xcd(g_, xtag, v_); else granule_store(g_, xtag, v_); };
+            auto gwait = [&](const granule_t* g_, float& v_) { return xcd_local ? granule_wait_xcd(g_, xtag, v_) : granule_wait(g_, xtag, v_); };
+            bool ok = true;
+            if (g == 0) {
+                if (tid == 0) granule_store(xl + gid, xtag, (TASK == TASK_REG) ? lik * T : lik);
+                for (int j = tid; j < PS; j += nthr) granule_store(xst + (size_t)gid * PS + j, xtag, (j == P) ? eta : ((j < P) ? w_cur[j] : 0.0f));
+                float* const sL = recs;
+                float* const sU = recs + Rg;
+                int* const sSrc = reinterpret_cast<int*>(recs + 2 * Rg);
+                for (int k = tid; k < Rg; k += nthr) { float v = 0.0f; ok = granule_wait(xl + k, xtag, v) && ok; sL[k] = v; }
+                if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
+#if defined(__HIP_DEVICE_COMPILE__)
+                const SwapParams sp = pp->sp;
+#else
+                const SwapParams sp{};
+#endif
+                const int round = pp->round0 + nx;
+                const int nsw = cascade_lds(sp, round, sL, sU, sSrc, true);
+                const int src = sSrc[gid];
+                if (gid == sp.first_global) {                // replica 0's root keeps the books (swap_block: b == 0)
+                    if (sp.src_log && round < sp.log_capacity)
+                        for (int k = tid; k < Rg; k += nthr) sp.src_log[(size_t)round * Rg + k] = sSrc[k];
+                    if (tid == 0) { sp.counters[0] += nsw; sp.counters[1] += Rg - 1; }
+                }
+                __syncthreads();                            // sSrc has been read: the record area is free again
+                if (src != gid) {
+                    for (int j = tid; j < PS; j += nthr) { float v = 0.0f; ok = granule_wait(xst + (size_t)src * PS + j, xtag, v) && ok; w_cur[j] = v; }
+                    if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
+                    for (int j = tid; j < PS; j += nthr) gstore(xsb + 8 + j, w_cur[j]);
+                }
+                if (tid == 0) gstore(xsb, (src != gid) ? 1.0f : 0.0f);
+            } else {
+                if (tid == 0) { float mv = 0.0f; ok = gwait(xsb, mv); red[0] = mv; }
+                if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
+                if (red[0] != 0.0f) {
+                    for (int j = tid; j < PS; j += nthr) { float v = 0.0f; ok = gwait(xsb + 8 + j, v) && ok; w_cur[j] = v; }
+                    if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
+                }
+            }
+            __syncthreads();
+            if (TASK == TASK_REG) eta = uni_f(w_cur[P]);    // eta travels with the state (REG:436-437)
+            nx += 1;
+            ho_next = next_handoff(i);
+            // the tapes drawn ahead for the next round were cut at the hand-off like this one: nothing to redo
+        }
     }
     PTNN_DIAG(tree_flush);
     if (failed) {
@@ -4357,8 +4476,9 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
         return;
     }
     if (g == 0) {
+        float* const gw_end = swap_inside ? pp->state[(pp->flip0 + nx) & 1] + (size_t)r * PS : gw;     // every in-launch round flips the host's buffers
         for (int j = tid; j < PS; j += nthr) {
-            gw[j] = (j == P) ? eta : w_cur[j];
+            gw_end[j] = (j == P) ? eta : w_cur[j];
             p.rec_w[(size_t)r * PS + j] = rec_w[j];
         }
         if (tid == 0) {
@@ -4499,22 +4619,6 @@ __global__ void __launch_bounds__(MAX_THREADS) model_kernel(const SegParams p, c
 // work-group copies all of them into LDS right after the barrier (cascade_lds), and the next write to any of them is a whole swap
 // interval away.  The host only takes this shape for intervals of 8 MH steps or more (ptnn.hip: resolve_persistent).
 // ------------------------------------------------------------------------------------------------
-struct PersistParams {
-    int end;                 // MH steps are run up to here (exclusive)
-    int swap_inside;         // 1: the swap rounds between the intervals run inside this launch
-    int task, si;            // hand-off rule (Q10): REG after step i when i % si == 0 and i != 0; CLS when (i + 1) % si == 0
-    int round0;              // index of the first swap round of this launch
-    int flip0, lflip0;       // which state / label-map buffers are current at entry
-    int nblocks;             // work-groups of the grid
-    unsigned* barrier;       // [nblocks] phase every work-group has reached, zero at launch
-    float* state[2];
-    float* gd[2];
-    int* gd_valid[2];
-    int* label[2];
-    int* slot_of[2];
-    SwapParams sp;           // everything of a round that does not flip
-};
-
 // Grid barrier without a read-modify-write: every work-group owns one slot and stores the phase it has reached (distinct
 // addresses: nothing serialises -- 256 agent-scope atomic adds on ONE counter cost more than the launch boundary this replaces),
 // wave 0 polls all slots (lane = slot) until every one has reached the phase.  Bounded like every cross-work-group wait.
@@ -4539,25 +4643,6 @@ __device__ __forceinline__ bool grid_barrier(unsigned* slots, int nblocks, unsig
     bad = __syncthreads_or(bad);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");              // nothing cached from before the others arrived
     return bad == 0;
-}
-
-// The PersistParams of the launch, read from the kernel-argument segment where it lies (second argument, behind SegParams) through
-// a pointer the optimiser cannot see through: every use re-loads the few words it needs (scalar loads from the constant cache)
-// instead of keeping ~60 words of it live across the interval body -- hoisted out of the loop they were spilled into vector
-// registers and, in the two kernels closest to the register ceiling, on into scratch.
-typedef __attribute__((address_space(4))) const PersistParams* persist_cptr;
-__device__ __forceinline__ persist_cptr persist_args() {
-    constexpr size_t off = (sizeof(SegParams) + alignof(PersistParams) - 1) & ~(alignof(PersistParams) - 1);
-    unsigned long long a = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + off;
-    asm volatile("" : "+s"(a));
-    return (persist_cptr)(uintptr_t)a;
-}
-
-typedef __attribute__((address_space(4))) const SegParams* seg_cptr;
-__device__ __forceinline__ seg_cptr seg_args() {
-    unsigned long long a = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(a));
-    return (seg_cptr)(uintptr_t)a;
 }
 
 // LOOP = false: one interval per launch and nothing else (the two schedules with several work-groups per replica and the most

@@ -65,6 +65,7 @@ def main():
     ks = glob.glob(os.path.join(src, "kt", "**", "*_kernel_stats.csv"), recursive=True)[0]
     shutil.copy(ks, os.path.join(here, f"{tag}_kernel_stats.csv"))
     out = {"tag": tag, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, + --kernel-trace --stats pass",
+           "commit": os.environ.get("PTNN_COMMIT"),         # the commit the three passes ran (exported by whoever calls collect.sh; the GPU box has no .git)
            "kernels": {}}
     for j in ("kt", "fetch", "write"):
         p = os.path.join(src, j + ".log")
@@ -77,6 +78,8 @@ def main():
         out["command"] = open(cmd).read().strip()
     # ---- timed launches only, from the kernel trace of the --stats pass
     bench = out.get("bench_kt")
+    if bench:
+        out["mh_steps_per_launch"] = bench.get("roofline", {}).get("mh_steps_per_launch")     # what "per launch" means in this file
     tr = glob.glob(os.path.join(src, "kt", "**", "*_kernel_trace.csv"), recursive=True)
     if bench and tr:
         roof = bench["roofline"]

@@ -15,20 +15,20 @@
 typedef unsigned long long u64;
 constexpr unsigned SPIN_LIMIT = 1u << 20;
 
-enum { V_AGENT = 0, V_WORKGROUP, V_SYSTEM, V_ASM_SC0, V_ASM_SC1, V_ASM_SC0SC1, V_ASM_NT, V_ASM_PLAIN_ST_SC0_LD, V_COUNT };
+enum { V_AGENT = 0, V_WORKGROUP, V_SYSTEM, V_ASM_SC0, V_ASM_SC1, V_ASM_SC0SC1, V_ASM_NT, V_ASM_PLAIN_ST_SC0_LD, V_PLAIN_ST_NT_LD, V_SC0_ST_NT_LD, V_NT_ST_SC1_LD, V_COUNT };
 static const char* NAMES[V_COUNT] = {"atomic relaxed, agent scope (the product's)", "atomic relaxed, workgroup scope", "atomic relaxed, system scope",
                                      "asm store sc0 / load sc0", "asm store sc1 / load sc1", "asm store sc0 sc1 / load sc0 sc1", "asm store nt / load nt",
-                                     "asm store (no bits) / load sc0"};
+                                     "asm store (no bits) / load sc0", "asm store (no bits) / load nt", "asm store sc0 / load nt", "asm store nt / load sc1"};
 
 template <int V>
 __device__ __forceinline__ void g_store(u64* p, u64 x) {
     if (V == V_AGENT) __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else if (V == V_WORKGROUP) __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else if (V == V_SYSTEM) __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    else if (V == V_ASM_SC0) asm volatile("global_store_dwordx2 %0, %1, off sc0" ::"v"(p), "v"(x) : "memory");
+    else if (V == V_ASM_SC0 || V == V_SC0_ST_NT_LD) asm volatile("global_store_dwordx2 %0, %1, off sc0" ::"v"(p), "v"(x) : "memory");
     else if (V == V_ASM_SC1) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
     else if (V == V_ASM_SC0SC1) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(x) : "memory");
-    else if (V == V_ASM_NT) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(x) : "memory");
+    else if (V == V_ASM_NT || V == V_NT_ST_SC1_LD) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(p), "v"(x) : "memory");
     else asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(x) : "memory");
 }
 template <int V>
@@ -38,7 +38,7 @@ __device__ __forceinline__ u64 g_load(const u64* p) {
     else if (V == V_WORKGROUP) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else if (V == V_SYSTEM) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     else if (V == V_ASM_SC0 || V == V_ASM_PLAIN_ST_SC0_LD) asm volatile("global_load_dwordx2 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(p) : "memory");
-    else if (V == V_ASM_SC1) asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(p) : "memory");
+    else if (V == V_ASM_SC1 || V == V_NT_ST_SC1_LD) asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(p) : "memory");
     else if (V == V_ASM_SC0SC1) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(p) : "memory");
     else asm volatile("global_load_dwordx2 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(p) : "memory");
     return x;
@@ -102,5 +102,6 @@ int main(int argc, char** argv) {
     unsigned base = 16;
 #define RUN(V) if (only < 0 || only == V) run<V>(d, d_out, reps, base);
     RUN(V_AGENT) RUN(V_WORKGROUP) RUN(V_SYSTEM) RUN(V_ASM_SC0) RUN(V_ASM_SC1) RUN(V_ASM_SC0SC1) RUN(V_ASM_NT) RUN(V_ASM_PLAIN_ST_SC0_LD)
+    RUN(V_PLAIN_ST_NT_LD) RUN(V_SC0_ST_NT_LD) RUN(V_NT_ST_SC1_LD)
     return 0;
 }

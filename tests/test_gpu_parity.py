@@ -799,7 +799,7 @@ def test_checkpoint_resume_continues_bit_for_bit(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["sunspot_packed", "iris_coop", "ions_coop", "wide_res_g2", "sunspot_labels", "sunspot_evenodd"])
+@pytest.mark.parametrize("case", ["sunspot_packed", "iris_coop", "ions_coop", "wide_res_g2", "sunspot_labels", "sunspot_evenodd", "iris_tree", "cancer_tree_g7"])
 def test_one_launch_per_run_equals_one_launch_per_interval(case, monkeypatch):
     """The persistent launch (every segment kernel loops over the swap intervals, grid barriers and the swap round inside:
     persistent_loop) against the round-2 shape (one launch per interval + swap_kernel, $PTNN_PERSISTENT=0): traces, swap log,
@@ -872,6 +872,25 @@ def test_sgd_epoch_timer_reports_a_plausible_epoch():
     t3 = s.time_sgd_epoch(philox.initial_weights(3, 0, 31), reps=100)
     s.close()
     assert 1.7 * t1 < t3 < 2.3 * t1, (t1, t3)
+
+
+@pytest.mark.gpu
+def test_tree_round_timer_reports_plausible_parts():
+    """ptnn_time_tree_round (the two units of bench.py's roofline.tree): one forward pass of the 4-12-3 net over Iris' 150 rows by one
+    work-group takes 0.5 - 6 us on an MI355X (measured 1.7 us), one record granule from one work-group to another 0.1 - 2 us
+    (measured 0.28 us through the XCD's L2, 0.59 us through the agent-scope path), and the L2 path is not the slower one."""
+    d = ds()
+    from ptnn_amd import philox
+    s = parity.make_sampler(orc.TASK_CLS, (4, 12, 3), d["iris_train"], d["iris_test"], R_local=16, R_global=16, first=0, S=40, si=10,
+                            use_lg=False, lr=0.01, seed=3)
+    w = philox.initial_weights(3, 0, 99)
+    fw, hop, local = s.time_tree_round(w, reps=200, xcd_local=True)
+    fw2, hop_agent, local2 = s.time_tree_round(w, reps=200, xcd_local=False)
+    s.close()
+    assert 0.0005 < fw < 0.006 and abs(fw - fw2) < 0.2 * fw, (fw, fw2)
+    assert 0.0001 < hop < 0.002 and 0.0001 < hop_agent < 0.002 and not local2, (hop, hop_agent, local, local2)
+    if local:                                                # blocks 0 and 8 of the timing launch did share an XCD
+        assert hop < 1.1 * hop_agent, (hop, hop_agent)
 
 
 @pytest.mark.gpu
