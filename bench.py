@@ -318,8 +318,9 @@ def self_launch(argv, n, plans=None):
 
     def pump(r, p):
         for line in p.stdout:
-            (sys.stdout if r == 0 else sys.stderr).write(line if r == 0 else f"[rank {r}] {line}")
-            (sys.stdout if r == 0 else sys.stderr).flush()
+            mine = r == 0 and line.lstrip().startswith("{")      # rank 0's JSON line and nothing else goes to this process's stdout
+            (sys.stdout if mine else sys.stderr).write(line if mine else f"[rank {r}] {line}")
+            (sys.stdout if mine else sys.stderr).flush()
     threads = [threading.Thread(target=pump, args=(r, p), daemon=True) for r, p in enumerate(procs)]
     for t in threads:
         t.start()
@@ -416,7 +417,17 @@ def main():
         dm0.single_node_rccl_env()               # this process is the bench's own: loopback bootstrap, no verbs probe, dmabuf IPC
         import torch
         import torch.distributed as dist
-        dist.init_process_group("gloo")          # rendezvous only: unique id, barrier, max of the times
+        # rendezvous only: unique id, barrier, max of the times.  gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected
+        # to ..."): the line this script prints must be the only thing there, so file descriptor 1 points at stderr while gloo comes up
+        sys.stdout.flush()
+        fd1 = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            os.dup2(fd1, 1)
+            os.close(fd1)
         ngpu = torch.cuda.device_count()         # counting devices does not initialise the GPU
         device = local_rank % max(ngpu, 1)       # a one-GPU box rehearsing N ranks puts them all on GPU 0
         torch.cuda.set_device(device)

@@ -237,12 +237,13 @@ def test_bench_starts_its_own_ranks_when_run_bare(capfd):
         assert env["FOO"] == "1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["PTNN_BENCH_SELF_LAUNCHED"] == "1"
     auto = bench.launch_plan([], 2, environ={})
     assert auto[0][1]["MASTER_PORT"] == auto[1][1]["MASTER_PORT"] and 1024 < int(auto[0][1]["MASTER_PORT"]) < 65536
-    child = "import os, sys; r = int(os.environ['RANK']); print('line of rank', r, 'of', os.environ['WORLD_SIZE']); sys.exit(3 if r == 1 else 0)"
+    child = ("import os, sys; r = int(os.environ['RANK']); print('[lib] chatter of rank', r); "
+             "print('{\"line of rank\": %d, \"of\": %s}' % (r, os.environ['WORLD_SIZE'])); sys.exit(3 if r == 1 else 0)")
     fake = [([sys.executable, "-c", child], dict(os.environ, RANK=str(r), WORLD_SIZE="3")) for r in range(3)]
     rc = bench.self_launch([], 3, plans=fake)
     out, err = capfd.readouterr()
-    assert rc == 3 and out == "line of rank 0 of 3\n"
-    assert "[rank 1] line of rank 1 of 3" in err and "[rank 2] line of rank 2 of 3" in err
+    assert rc == 3 and out == '{"line of rank": 0, "of": 3}\n'         # rank 0's JSON line, nothing else
+    assert '[rank 1] {"line of rank": 1, "of": 3}' in err and '[rank 2] {"line of rank": 2' in err and "[rank 0] [lib] chatter of rank 0" in err
 
 
 @pytest.mark.parametrize("fmt", ["%.18e", "%1.8f", "%1.2f", "%1.4f", "%1.5f", "%.6e", "%10.3f", "%+.3e", "%.0f", "%1.18f"])
