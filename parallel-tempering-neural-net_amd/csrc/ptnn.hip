@@ -95,7 +95,7 @@ struct ptnn_handle {
     int blocks_per_cu = 0;          // occupancy of the segment kernel as the runtime reports it (0 = not queried)
     unsigned epoch_base = 0;
     int num_cus = 0;
-    unsigned long long *d_xslots = nullptr, *d_xw = nullptr, *d_xverdict = nullptr;
+    unsigned long long *d_xslots = nullptr, *d_xw = nullptr, *d_xverdict = nullptr, *d_xswap = nullptr;
     int* d_error = nullptr;
     float *h_stage = nullptr, *d_stage = nullptr;   // initial weights + temperatures on their way to the device (ptnn_set_state)
     int* h_progress = nullptr;      // pinned host word: swap rounds the device has completed (swap_kernel stores it)
@@ -160,7 +160,15 @@ struct ptnn_handle {
         p.L_raw = (cfg.swap_rule == 1) ? d_L_raw : nullptr; p.prior_post = d_prior_post;
         p.tr_pos_w = d_pos_w; p.tr_scal = d_scal; p.PW = PW;
         p.G = groups; p.epoch_base = epoch_base; p.xslots = d_xslots; p.xw = d_xw; p.xverdict = d_xverdict; p.error_flag = d_error; p.stamps = d_stamps; p.wide_scratch = d_wide_scratch; p.noise_shared = cfg.shared_noise ? 1 : 0; p.pk_nred = pk_nred; p.xt = d_xt; p.xs = reinterpret_cast<const uint4*>(d_xs); p.Npad = Npad; p.fw_mfma = fw_mfma; p.xy_global = xy_global ? 1 : 0; p.forward_bf16 = cfg.forward_bf16 == 1 ? 1 : 0; p.tree_ahead = tree_ahead ? 1 : 0; p.compact = compact ? 1 : 0;
-        { const char* e = std::getenv("PTNN_XCD_GRANULES"); p.xcd_granules = (e && e[0] == '0') || cfg.shared_device ? 0 : 1; }
+        {
+            // records through the XCD's L2: asked for only where xcd_block (ptnn_device.hpp) can put a replica's work-groups on one XCD --
+            // a grid of 8 k blocks with k a multiple of the groups per replica; elsewhere the in-kernel handshake could only time out
+            const char* e = std::getenv("PTNN_XCD_GRANULES");
+            const int grid_ = cfg.n_replicas_local * groups;
+            const bool can = groups > 1 && (grid_ & 7) == 0 && ((grid_ >> 3) % groups) == 0;
+            p.xcd_granules = ((e && e[0] == '0') || cfg.shared_device || !can) ? 0 : 1;
+        }
+        p.xswap = d_xswap;
         // wide nets over several work-groups: a window of 16 steps lets the groups balance Langevin (10 units) against random-walk
         // (1) steps (measured on config 5: 8 steps 0.680 M, 12: 0.692 M, 16: 0.698 M samples/s; wide nets accept 1 - 5 %, so little of
         // a window is thrown away); random-walk-only runs have nothing to balance and a longer window only wastes what follows an accept
@@ -367,6 +375,17 @@ int finish_stream(ptnn_handle* h) {
 // work-group per replica (packed, cooperative, one-group wide: one barrier per round; Sunspot + 2.6 %, Ionosphere + 0.2 %); with
 // several work-groups per replica a round needs a second rendezvous and the launch boundary it replaces is cheaper (Iris tree
 // - 5 %, Mackey-Glass - 2 %, profiles/r03_persistent_ab.json).  $PTNN_PERSISTENT=0: never; =1: wherever resident.
+// Granules of the swap rounds a multi-group launch runs by itself (ptnn_device.hpp: segment_tree_body, segment_pack_body<MULTI>): two
+// parities of swap_xchg_granules(R, row); only when the whole ladder is on this handle (a sharded ladder exchanges through its communicator)
+int alloc_swap_granules(ptnn_handle* h, int row) {
+    if (h->d_xswap) { HIP_TRY(hipFree(h->d_xswap)); h->d_xswap = nullptr; }
+    if (h->cfg.n_replicas_local != h->cfg.n_replicas_global) return 0;
+    const size_t n = 2 * swap_xchg_granules(h->cfg.n_replicas_global, row);
+    HIP_TRY(hipMalloc(&h->d_xswap, n * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->d_xswap, 0, n * sizeof(unsigned long long)));
+    return 0;
+}
+
 int resolve_persistent(ptnn_handle* h) {
     h->persistent = false;
     const char* e = std::getenv("PTNN_PERSISTENT");
@@ -375,18 +394,22 @@ int resolve_persistent(ptnn_handle* h) {
     // The prefetching tree runs its swap rounds inside the launch by itself (segment_tree_body: the root groups exchange scalars and
     // state rows as granules, no grid barrier): the reference's cascade without label swapping, a ladder that is not sharded, and as
     // many replicas as the cascade has room for in the record area of LDS.  One launch per run then, unless $PTNN_PERSISTENT=0.
-    const bool tree_inside = h->tree && h->cfg.swap_rule == 0 && !h->cfg.label_swap && h->d_xw != nullptr &&
-                             h->cfg.n_replicas_local == h->cfg.n_replicas_global && h->cfg.n_replicas_global <= TREE_PERSIST_MAX_R;
-    if (G > 1 && !tree_inside && !(e && e[0] == '1')) return 0;
+    const bool whole = h->cfg.swap_rule == 0 && !h->cfg.label_swap && h->d_xswap != nullptr && h->cfg.n_replicas_local == h->cfg.n_replicas_global;
+    const bool tree_inside = h->tree && whole && h->cfg.n_replicas_global <= TREE_PERSIST_MAX_R;
+    // ... and so does the packed round over several CUs (segment_pack_body<MULTI>; the cascade's 3 R + 1 floats live in the slots' area)
+    const bool packm_inside = h->packed && h->groups > 1 && whole &&
+                              (size_t)(3 * h->cfg.n_replicas_global + 1) <= (size_t)pack_slots(h->pk_nred) * pack_slot_floats(h->PS);
+    const bool own_rounds = tree_inside || packm_inside;
+    if (G > 1 && !own_rounds && !(e && e[0] == '1')) return 0;
     // One barrier per round (G == 1) leaves the posted scalars single-buffered: a work-group that has left the barrier reads all R of
     // them into LDS at once (cascade_lds), and the next write to any of them comes a whole swap interval later, at the end of the
     // writer's next interval.  The invariant "no resident work-group falls a whole interval behind between leaving a barrier and its
     // next few loads" holds with orders of magnitude to spare for intervals of tens of microseconds; for intervals of a few MH steps
     // of a small net it is not worth relying on: those runs take one launch per interval (a kernel boundary orders everything).
-    if (h->cfg.swap_interval < 8 && !tree_inside && !(e && e[0] == '1')) return 0;
+    if (h->cfg.swap_interval < 8 && !own_rounds && !(e && e[0] == '1')) return 0;
     // kernels compiled without the interval loop (ptnn_device.hpp: persistent_loop<false>)
-    if ((h->speculative && !h->packed) || (h->tree && !tree_inside) || (h->packed && h->groups > 1)) return 0;
-    if (h->packed && !(h->shape->loops & 2)) return 0;
+    if ((h->speculative && !h->packed) || (h->tree && !tree_inside) || (h->packed && h->groups > 1 && !packm_inside)) return 0;
+    if (h->packed && h->groups == 1 && !(h->shape->loops & 2)) return 0;
     if (!h->wide && !h->packed && !h->speculative && !h->tree && !(h->shape->loops & 1)) return 0;
     const size_t swap_lds = (size_t)(3 * h->cfg.n_replicas_global + 1) * sizeof(float);
     if (swap_lds > h->seg_lds) {
@@ -537,7 +560,7 @@ int ptnn_destroy(ptnn_handle* h) {
         if (hipStreamQuery(h->stream) == hipErrorNotReady) return fail(-7, "the stream of a failed communicator did not drain: handle leaked");
     }
     void* ptrs[] = {h->d_data, h->d_state[0], h->d_state[1], h->d_rec_w, h->d_gd_w[0], h->d_gd_w[1], h->d_gd_valid[0], h->d_gd_valid[1], h->d_st_f, h->d_st_i, h->d_temps,
-                    h->d_L_handoff, h->d_L_final, h->d_L_raw, h->d_prior_post, h->d_temps_global, h->d_pos_w, h->d_scal, h->d_src, h->d_label[0], h->d_label[1], h->d_slot_of[0], h->d_slot_of[1], h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_xverdict, h->d_stamps, h->d_wide_scratch, h->d_xt, h->d_xs, h->d_barrier};
+                    h->d_L_handoff, h->d_L_final, h->d_L_raw, h->d_prior_post, h->d_temps_global, h->d_pos_w, h->d_scal, h->d_src, h->d_label[0], h->d_label[1], h->d_slot_of[0], h->d_slot_of[1], h->d_src_log, h->d_counters, h->d_error, h->d_xslots, h->d_xw, h->d_xverdict, h->d_xswap, h->d_stamps, h->d_wide_scratch, h->d_xt, h->d_xs, h->d_barrier};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (h->h_src) (void)hipHostFree(h->h_src);
@@ -744,6 +767,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
                 HIP_TRY(hipMemset(h->d_xslots, 0, ns * sizeof(unsigned long long)));
                 HIP_TRY(hipMemset(h->d_xw, 0, nx * sizeof(unsigned long long)));
                 HIP_TRY(hipMemset(h->d_xverdict, 0, nvd * sizeof(unsigned long long)));
+                if (int rc = alloc_swap_granules(h, 2 * h->PS + 8)) return rc;     // in-launch swap rounds: state + cached gradient + flag
                 h->epoch_base = 1;                              // tag 0 = never written
             }
         }
@@ -892,12 +916,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
             HIP_TRY(hipMalloc(&h->d_xslots, ng * sizeof(unsigned long long)));
             HIP_TRY(hipMemset(h->d_xslots, 0, ng * sizeof(unsigned long long)));
             // granules of the in-launch swap rounds (two parities), when the whole ladder is on this handle
-            if (h->d_xw) { HIP_TRY(hipFree(h->d_xw)); h->d_xw = nullptr; }
-            if (h->cfg.n_replicas_local == h->cfg.n_replicas_global) {
-                const size_t nxg = 2 * tree_xchg_granules(h->cfg.n_replicas_global, h->PS);
-                HIP_TRY(hipMalloc(&h->d_xw, nxg * sizeof(unsigned long long)));
-                HIP_TRY(hipMemset(h->d_xw, 0, nxg * sizeof(unsigned long long)));
-            }
+            if (int rc = alloc_swap_granules(h, h->PS)) return rc;
             h->epoch_base = 1;                                  // tag 0 = never written
         } else if (explicit_tree) {
             return fail(-3, "tree schedule: %d replicas x %d work-groups of %d threads cannot all be resident on %d CUs (or need more than "

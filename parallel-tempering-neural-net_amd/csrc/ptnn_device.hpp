@@ -114,6 +114,7 @@ struct SegParams {
     int* seg_progress;       // pinned host word or null (RCCL communicator attached): block 0 stores seg_ordinal when this launch ends
     int seg_ordinal;         // with a swap round due -- "the collective of round seg_ordinal - 1 is next on the stream" (ptnn.hip: wait_stream)
     int xcd_granules;        // 1: work-groups of a replica that find themselves on one XCD exchange through its L2 (granule_*_xcd); 0: always agent scope
+    unsigned long long* xswap;    // granules of the swap rounds a multi-group launch runs by itself (tree, packed multi-CU): 2 x swap_xchg_granules, or null
     int compact;             // wide nets, all rows resident (trace_cap == S): a REJECTED step writes no pos_w row, only the index of the
                              // row it repeats (TR_SRC); ptnn_get_traces fills the rows in.  A 70 KB copy per rejected step otherwise.
 };
@@ -121,7 +122,11 @@ struct SegParams {
 // What changes from one swap interval to the next inside one launch (persistent_loop): which of the two state buffers is
 // current, and where the granule tags continue.  Kept apart from SegParams so that the kernel argument itself stays constant (a
 // modified copy of it, live across the whole interval, cost ~60 scalar registers and pushed two kernels into scratch).
+struct PersistParams;
+typedef __attribute__((address_space(4))) const PersistParams* persist_cptr;
 struct SegDyn {
+    persist_cptr pp;         // the launch's PersistParams (kernel-argument segment), found by the KERNEL and handed down: a body that the
+                             // compiler does not inline (many-class heads) must not look for the kernel arguments itself
     float* w_state;          // current (w, eta) rows [Rl][PS]
     float* gd_w;             // cached langevin_gradient(w) [Rl][PS]
     int* gd_valid;           // [Rl]
@@ -1907,7 +1912,7 @@ __device__ __forceinline__ bool granule_wait_xcd(const granule_t* g, unsigned ep
 // A group on ANOTHER XCD reads a different id, or a line its own L2 fetched too early and keeps (then the bounded wait runs out):
 // either way it answers no, and so does everybody who waits for it -- the verdict is the same in every group, because "all G ids
 // equal mine, seen through L2" can only hold for all of them at once.  `tmp`: G floats of LDS; ends with a work-group barrier.
-constexpr unsigned XCD_HANDSHAKE_SPINS = 1u << 15;          // a few milliseconds: the groups of one launch start microseconds apart
+constexpr unsigned XCD_HANDSHAKE_SPINS = 1u << 13;          // about a millisecond: the groups of one launch start microseconds apart
 __device__ __forceinline__ bool xcd_handshake_strided(granule_t* ids, int stride, int G, int grp, unsigned tag, float* tmp) {
     const int my_xcc = xcc_id();
     if (threadIdx.x == 0) granule_store(ids + (size_t)grp * stride, tag, (float)my_xcc);
@@ -1938,6 +1943,166 @@ __device__ __forceinline__ int xcd_block(int G) {
     return (G > 1 && (nb & 7) == 0 && ((nb >> 3) % G) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;   // G == 1: block = replica, as the one-group bodies take it
 #endif
 }
+
+// ------------------------------------------------------------------------------------------------
+// R12 swap cascade (REG:659-690, 741-748): one sequential bubble pass over the ladder.  Every block recomputes it
+// (R <= a few thousand scalars), then block b moves the (w, eta) row for local replica b.
+// ------------------------------------------------------------------------------------------------
+struct SwapParams {
+    int R, Rl, first_global, PS;
+    uint32_t seed_lo, seed_hi;
+    const float* L;            // [R] posted scalars
+    const float* cur;          // [Rl][PS]
+    float* next;               // [Rl][PS]
+    const float* gd_cur;       // [Rl][PS] cached langevin_gradient(w) rows, travel with w inside one GPU
+    float* gd_next;            // [Rl][PS]
+    const int* gd_valid_cur;   // [Rl]
+    int* gd_valid_next;        // [Rl]
+    int* src_out;              // [R] (may be null)
+    long long* counters;       // [0] num_swap, [1] total_swap_proposals
+    int* src_log;              // [max_rounds][R] (may be null)
+    int log_capacity;
+    // swap_rule 1: even/odd Metropolis exchange exp((1/T_k - 1/T_k+1)(L_k+1 - L_k)) on untempered log-likelihoods; the
+    // moved state brings its likelihood and prior along (no stale values), no phantom round
+    int rule, canonical;       // canonical: the chains are past the temperature switch (likelihoods untempered)
+    const float* L_raw;        // [R]
+    const float* prior_post;   // [R]
+    const float* temps_global; // [R]
+    float* st_f;               // [Rl][SF_COUNT]
+    // gathered exchange (ladder sharded over GPUs): every rank holds, after one all-gather, the exchange rows of ALL replicas
+    // xchg[R][XS] = { state row (PS) | cached-gradient row (PS) | gradient valid | posted L | pad }
+    float* xchg;               // null: single-GPU / point-to-point modes
+    int XS;
+    int L_stride;              // 1, or XS when L (and, swap_rule 1, L_raw / prior_post) are read from the exchange rows
+    // label swapping (SURVEY 8f-4, not in the reference): the chains stay where they are and the TEMPERATURES move.  label[slot] =
+    // temperature index the chain in that slot holds, slot_of[temperature] = its inverse, both over the whole ladder and replicated
+    // on every rank; the cascade runs over temperature indices, the round only rewrites the maps, the temperature of the local
+    // slots and (before the temperature switch) the tempering of their likelihoods.  Nothing but L crosses a GPU boundary.
+    int label_mode;
+    const int* label_cur;      // [R]
+    const int* slot_cur;       // [R]
+    int* label_next;           // [R]
+    int* slot_next;            // [R]
+    float* temps_local;        // [Rl] temperature of the local slots (what the segment kernels read)
+    int* progress;             // pinned host word (or null): block 0 stores round + 1 when the round is through -- what the bounded
+                               // waits of a communicator handle watch (ptnn.hip: wait_stream)
+};
+__host__ __device__ inline int xchg_row_floats(int PS) { return (2 * PS + 4 + 3) & ~3; }
+
+// sSrc has R + 1 ints: the last one carries the number of accepted swaps
+// have_L: sL already holds the R posted scalars (the tree's in-launch swap round reads them from granules)
+__device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, float* sL, float* sU, int* sSrc, bool have_L = false) {
+    const int R = sp.R;
+    for (int k = threadIdx.x; k < R; k += blockDim.x) {
+        if (!have_L) sL[k] = sp.L[(size_t)(sp.label_mode ? sp.slot_cur[k] : k) * sp.L_stride];    // k is a temperature index
+        if (k < R - 1) {
+            uint32_t x[4];
+            philox4x32_10((uint32_t)k, (uint32_t)round, 0u, STREAM_SWAP, sp.seed_lo, sp.seed_hi, x);
+            // rule 0 compares in the log domain (below): ln(2 u) is computed here, by all threads at once, instead of an exp inside
+            // the sequential chain
+            sU[k] = (sp.rule == 1) ? u23(x[0]) : logf_fast(2.0f * u23(x[0]));
+        }
+    }
+    __syncthreads();
+    if (sp.rule == 1) {
+        // independent pairs (k, k+1), k of the round's parity
+        for (int k = threadIdx.x; k < R; k += blockDim.x) sSrc[k] = k;
+        if (threadIdx.x == 0) sSrc[R] = 0;
+        __syncthreads();
+        for (int k = (round & 1) + 2 * threadIdx.x; k < R - 1; k += 2 * blockDim.x) {
+            const int s0 = sp.label_mode ? sp.slot_cur[k] : k, s1 = sp.label_mode ? sp.slot_cur[k + 1] : k + 1;
+            const float d = (1.0f / sp.temps_global[k] - 1.0f / sp.temps_global[k + 1]) *
+                            (sp.L_raw[(size_t)s1 * sp.L_stride] - sp.L_raw[(size_t)s0 * sp.L_stride]);
+            const float pr = (d != d) ? 1.0f : fminf(1.0f, expf_fast(fminf(d, 80.0f)));
+            if (sU[k] < pr) { sSrc[k] = k + 1; sSrc[k + 1] = k; atomicAdd(&sSrc[R], 1); }
+        }
+        __syncthreads();
+        return sSrc[R];
+    }
+    // REG:674-679: swap iff u < min(1, 0.5 exp(min(709, L[k+1] - L[c]))).  u < 1 always, so the outer min never binds, and with
+    // u > 0 the test is ln(2 u) < min(709, L[k+1] - L[c]) -- subtract, clamp, compare, no transcendental.
+    //
+    // The bubble pass is sequential only through WHICH state is being carried: while the carried state is c, the tests of the
+    // pairs ahead are all against the same L[c], i.e. independent.  Wave 0 takes the pairs 64 at a time (lane = pair), tests
+    // all of them against the current carried L with one compare, and a ballot finds the first pair where it fails: the
+    // carried state is dropped there (src[k] = c), the next state is picked up (its L comes from that lane's register) and
+    // the lanes behind it are re-tested -- one iteration per DROP, not per pair, plus one per 64 pairs.  Wave-uniform control
+    // throughout.  (Round 1 walked the pairs one by one in thread 0 of every block, with an exp, a branch and an LDS store per
+    // pair: 95 ns per pair -- 6.1 us per round at R = 64, 40 us at 256, 72 us at 1024; independent forward scans from every
+    // start + pointer doubling were tried and are worse, because the reference's rule accepts 60 - 98 % of the swaps and the runs
+    // are long.)
+    if (threadIdx.x < WAVE) {
+        const int lane = threadIdx.x;
+        int c = 0, nsw = 0;
+        float Lc = sL[0];
+        for (int k0 = 0; k0 < R - 1; k0 += WAVE) {
+            const int k = k0 + lane;
+            const bool valid = k < R - 1;
+            const float Ln = valid ? sL[k + 1] : 0.0f;
+            const float tk = valid ? sU[k] : 0.0f;
+            unsigned long long todo = __ballot(valid);
+            unsigned long long swapped = 0ull;
+            while (todo) {
+                float d = Ln - Lc;
+                d = (d < 709.0f) ? d : 709.0f;              // python min(709, nan) == 709
+                const unsigned long long fail = __ballot(!(tk < d)) & todo;
+                if (!fail) { swapped |= todo; break; }       // the carried state passes every remaining pair of this window
+                const int j = __ffsll((long long)fail) - 1;  // first pair where it is dropped
+                swapped |= todo & ((1ull << j) - 1ull);
+                if (lane == j) sSrc[k] = c;                  // slot k0 + j receives the carried state ...
+                c = k0 + j + 1;                              // ... and the state of the next slot is picked up
+                Lc = __shfl(Ln, j);
+                todo &= (j == 63) ? 0ull : ~((2ull << j) - 1ull);
+            }
+            if (valid && ((swapped >> lane) & 1ull)) sSrc[k] = k + 1;
+            nsw += __popcll(swapped);
+        }
+        if (lane == 0) { sSrc[R - 1] = c; sSrc[R] = nsw; }
+    }
+    __syncthreads();
+    return sSrc[R];
+}
+
+// What a launch that spans several swap intervals needs to know (persistent_loop at the end of this file; the tree body runs its
+// own swap rounds and reads it too)
+struct PersistParams {
+    int end;                 // MH steps are run up to here (exclusive)
+    int swap_inside;         // 1: the swap rounds between the intervals run inside this launch
+    int task, si;            // hand-off rule (Q10): REG after step i when i % si == 0 and i != 0; CLS when (i + 1) % si == 0
+    int round0;              // index of the first swap round of this launch
+    int flip0, lflip0;       // which state / label-map buffers are current at entry
+    int nblocks;             // work-groups of the grid
+    unsigned* barrier;       // [nblocks] phase every work-group has reached, zero at launch
+    float* state[2];
+    float* gd[2];
+    int* gd_valid[2];
+    int* label[2];
+    int* slot_of[2];
+    SwapParams sp;           // everything of a round that does not flip
+};
+
+// The PersistParams of the launch, read from the kernel-argument segment where it lies (second argument, behind SegParams) through
+// a pointer the optimiser cannot see through: every use re-loads the few words it needs (scalar loads from the constant cache)
+// instead of keeping ~60 words of it live across the interval body -- hoisted out of the loop they were spilled into vector
+// registers and, in the two kernels closest to the register ceiling, on into scratch.
+__device__ __forceinline__ persist_cptr persist_args() {
+    constexpr size_t off = (sizeof(SegParams) + alignof(PersistParams) - 1) & ~(alignof(PersistParams) - 1);
+    unsigned long long a = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + off;
+    asm volatile("" : "+s"(a));
+    return (persist_cptr)(uintptr_t)a;
+}
+
+typedef __attribute__((address_space(4))) const SegParams* seg_cptr;
+__device__ __forceinline__ seg_cptr seg_args() {
+    unsigned long long a = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(a));
+    return (seg_cptr)(uintptr_t)a;
+}
+
+// Granules of a swap round that a launch with several work-groups per replica runs by itself (tree, packed multi-CU), per parity:
+// R posted scalars (padded to 8), R rows of `row` floats for the other replicas' root groups (the state; with a cached gradient:
+// state, gradient, its valid flag), R rows {flag, the same row} from every root to its own siblings
+__host__ __device__ inline size_t swap_xchg_granules(int R, int row) { return (size_t)((R + 7) & ~7) + (size_t)R * row + (size_t)R * (row + 8); }
 
 // p.G work-groups (one per CU) cooperate on one replica: work-group g, wave v owns speculative slot g*NW + v.
 // Every work-group keeps its own LDS copy of the chain state and applies the same commits, so the copies never
@@ -2460,6 +2625,18 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
         if (p.xcd_granules) xcd_local = xcd_handshake(xv + 32, G, grp, dyn.epoch_base, gverd);
     }
     __syncthreads();
+    // MULTI, one launch for several swap intervals (PersistParams::swap_inside): the swap round after a hand-off step runs inside the
+    // launch, at the end of the round loop below -- the same protocol as the tree's (segment_tree_body), with the cached gradient and
+    // its flag travelling beside the state as swap_block moves them
+    persist_cptr const pp = dyn.pp;
+    const bool swap_inside = MULTI && pp->swap_inside != 0;
+    const int si_ = pp->si;
+    auto next_handoff = [&](int cur) {
+        if (TASK == TASK_REG) { const int c1 = cur > 1 ? cur : 1; return ((c1 + si_ - 1) / si_) * si_; }
+        return ((cur + si_) / si_) * si_ - 1;
+    };
+    int ho_next = swap_inside ? next_handoff(step_begin) : 0x7fffffff;
+    int nx = 0;                                             // swap rounds done inside this launch
     while (i < end && !failed) {
         if (MULTI) { epoch += 1; }
         if (i == p.switch_step) {
@@ -2477,6 +2654,7 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
         }
         int kt = min(KT, end - i);                          // steps of this round's window (all work-groups of the replica)
         if (p.switch_step > i) kt = min(kt, p.switch_step - i);
+        if (swap_inside && ho_next >= i) kt = min(kt, ho_next - i + 1);     // a window never crosses a hand-off
         const int k = MULTI ? max(0, min(PK_SLOTS, kt - s0)) : kt;   // ... of which this work-group computes slots s0 .. s0 + k - 1
         PTNN_DIAG(count_round);
         STAMP(0);
@@ -2682,6 +2860,69 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
         tpos0 += ncommit;
         if (tpos0 >= p.trace_cap) tpos0 -= p.trace_cap;
         STAMP(6);                                           // commit
+        if constexpr (MULTI) {
+            if (swap_inside && i == ho_next + 1 && ho_next < end) {
+                // ---- the swap round of this hand-off (REG:427-437 <-> 719-752) inside the launch: see segment_tree_body.  A row is
+                // {state (w, eta): PS | cached langevin_gradient(w): PS | its valid flag}
+                const int Rg = pp->sp.R, ROW = 2 * PS + 8;
+                const unsigned xtag = dyn.epoch_base + (unsigned)nx + 1u;
+                granule_t* const xl = p.xswap + (size_t)(nx & 1) * swap_xchg_granules(Rg, ROW);
+                granule_t* const xst = xl + ((Rg + 7) & ~7);
+                granule_t* const xsb = xst + (size_t)Rg * ROW + (size_t)gid * (ROW + 8);
+                auto gstore = [&](granule_t* g_, float v_) { if (xcd_local) granule_store_xcd(g_, xtag, v_); else granule_store(g_, xtag, v_); };
+                auto gwait = [&](const granule_t* g_, float& v_) { return xcd_local ? granule_wait_xcd(g_, xtag, v_) : granule_wait(g_, xtag, v_); };
+                auto row_value = [&](int j) { return (j < PS) ? ((j == P) ? eta : ((j < P) ? w_cur[j] : 0.0f)) : ((j < 2 * PS) ? w_gd[j - PS] : ((j == 2 * PS) ? (gd_valid ? 1.0f : 0.0f) : 0.0f)); };
+                auto row_take = [&](int j, float v) { if (j < PS) w_cur[j] = v; else if (j < 2 * PS) w_gd[j - PS] = v; else if (j == 2 * PS) red[1] = v; };
+                bool ok = true;
+                bool moved = false;
+                if (grp == 0) {
+                    if (tid == 0) granule_store(xl + gid, xtag, (TASK == TASK_REG) ? lik * T : lik);
+                    for (int j = tid; j <= 2 * PS; j += nthr) granule_store(xst + (size_t)gid * ROW + j, xtag, row_value(j));
+                    float* const sL = sl0;                   // the slots' proposals are dead between two rounds
+                    float* const sU = sl0 + Rg;
+                    int* const sSrc = reinterpret_cast<int*>(sl0 + 2 * Rg);
+                    for (int k_ = tid; k_ < Rg; k_ += nthr) { float v = 0.0f; ok = granule_wait(xl + k_, xtag, v) && ok; sL[k_] = v; }
+                    if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
+#if defined(__HIP_DEVICE_COMPILE__)
+                    const SwapParams sp = pp->sp;
+#else
+                    const SwapParams sp{};
+#endif
+                    const int round = pp->round0 + nx;
+                    const int nsw = cascade_lds(sp, round, sL, sU, sSrc, true);
+                    const int src = sSrc[gid];
+                    if (gid == sp.first_global) {            // replica 0's root keeps the books (swap_block: b == 0)
+                        if (sp.src_log && round < sp.log_capacity)
+                            for (int k_ = tid; k_ < Rg; k_ += nthr) sp.src_log[(size_t)round * Rg + k_] = sSrc[k_];
+                        if (tid == 0) { sp.counters[0] += nsw; sp.counters[1] += Rg - 1; }
+                    }
+                    __syncthreads();
+                    moved = src != gid;
+                    if (moved) {
+                        for (int j = tid; j <= 2 * PS; j += nthr) { float v = 0.0f; ok = granule_wait(xst + (size_t)src * ROW + j, xtag, v) && ok; row_take(j, v); }
+                        if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
+                        for (int j = tid; j <= 2 * PS; j += nthr) gstore(xsb + 8 + j, (j == 2 * PS) ? red[1] : ((j < PS) ? w_cur[j] : w_gd[j - PS]));
+                    }
+                    if (tid == 0) gstore(xsb, moved ? 1.0f : 0.0f);
+                } else {
+                    if (tid == 0) { float mv = 0.0f; ok = gwait(xsb, mv); red[0] = mv; }
+                    if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
+                    moved = red[0] != 0.0f;
+                    if (moved) {
+                        for (int j = tid; j <= 2 * PS; j += nthr) { float v = 0.0f; ok = gwait(xsb + 8 + j, v) && ok; row_take(j, v); }
+                        if (__syncthreads_or(ok ? 0 : 1)) { failed = true; break; }
+                    }
+                }
+                __syncthreads();
+                if (moved) {                                 // what arrived: eta and the gradient's flag travel with the state (REG:436-437)
+                    if (TASK == TASK_REG) eta = uni_f(w_cur[P]);
+                    gd_valid = (uni_f(red[1]) != 0.0f) ? 1 : 0;
+                }
+                __syncthreads();
+                nx += 1;
+                ho_next = next_handoff(i);
+            }
+        }
     }
     PTNN_DIAG(pack_flush);
 
@@ -2690,16 +2931,20 @@ __device__ __forceinline__ void segment_pack_body(const SegParams& p, const SegD
         return;
     }
     if (grp != 0) return;                                   // every work-group holds the same state: the first one writes it back
+    const int fl_end = (pp->flip0 + nx) & 1;               // every in-launch round flips the host's buffers
+    float* const gw_end = swap_inside ? pp->state[fl_end] + (size_t)r * PS : gw;
+    float* const gd_end = swap_inside ? pp->gd[fl_end] + (size_t)r * PS : dyn.gd_w + (size_t)r * PS;
+    int* const gdv_end = swap_inside ? pp->gd_valid[fl_end] : dyn.gd_valid;
     for (int j = tid; j < PS; j += nthr) {
-        gw[j] = (j == P) ? eta : w_cur[j];
+        gw_end[j] = (j == P) ? eta : w_cur[j];
         p.rec_w[(size_t)r * PS + j] = rec_w[j];
-        dyn.gd_w[(size_t)r * PS + j] = w_gd[j];
+        gd_end[j] = w_gd[j];
     }
     if (tid == 0) {
         sf[SF_LIK] = lik; sf[SF_PRIOR] = prior_cur; sf[SF_TAU_LAST] = tau_eta_last;
         sf[SF_REC_RMSE_TR] = rec_rmse_tr; sf[SF_REC_RMSE_TE] = rec_rmse_te;
         sf[SF_REC_ACC_TR] = rec_acc_tr; sf[SF_REC_ACC_TE] = rec_acc_te;
-        si[SI_NACC] = nacc; dyn.gd_valid[r] = gd_valid; si[SI_LG_COUNT] = lg_count; si[SI_LG_ACC] = lg_acc;
+        si[SI_NACC] = nacc; gdv_end[r] = gd_valid; si[SI_LG_COUNT] = lg_count; si[SI_LG_ACC] = lg_acc;
         p.L_handoff[gid] = (TASK == TASK_REG) ? lik * T : lik;
         p.L_final[gid] = lik;
         post_raw(p, gid, lik, prior_cur, T, step_begin + n_steps - 1);
@@ -3785,125 +4030,6 @@ __global__ void __launch_bounds__(MAX_THREADS) model_wide_kernel(const SegParams
 
 #pragma clang fp contract(off)
 
-// ------------------------------------------------------------------------------------------------
-// R12 swap cascade (REG:659-690, 741-748): one sequential bubble pass over the ladder.  Every block recomputes it
-// (R <= a few thousand scalars), then block b moves the (w, eta) row for local replica b.
-// ------------------------------------------------------------------------------------------------
-struct SwapParams {
-    int R, Rl, first_global, PS;
-    uint32_t seed_lo, seed_hi;
-    const float* L;            // [R] posted scalars
-    const float* cur;          // [Rl][PS]
-    float* next;               // [Rl][PS]
-    const float* gd_cur;       // [Rl][PS] cached langevin_gradient(w) rows, travel with w inside one GPU
-    float* gd_next;            // [Rl][PS]
-    const int* gd_valid_cur;   // [Rl]
-    int* gd_valid_next;        // [Rl]
-    int* src_out;              // [R] (may be null)
-    long long* counters;       // [0] num_swap, [1] total_swap_proposals
-    int* src_log;              // [max_rounds][R] (may be null)
-    int log_capacity;
-    // swap_rule 1: even/odd Metropolis exchange exp((1/T_k - 1/T_k+1)(L_k+1 - L_k)) on untempered log-likelihoods; the
-    // moved state brings its likelihood and prior along (no stale values), no phantom round
-    int rule, canonical;       // canonical: the chains are past the temperature switch (likelihoods untempered)
-    const float* L_raw;        // [R]
-    const float* prior_post;   // [R]
-    const float* temps_global; // [R]
-    float* st_f;               // [Rl][SF_COUNT]
-    // gathered exchange (ladder sharded over GPUs): every rank holds, after one all-gather, the exchange rows of ALL replicas
-    // xchg[R][XS] = { state row (PS) | cached-gradient row (PS) | gradient valid | posted L | pad }
-    float* xchg;               // null: single-GPU / point-to-point modes
-    int XS;
-    int L_stride;              // 1, or XS when L (and, swap_rule 1, L_raw / prior_post) are read from the exchange rows
-    // label swapping (SURVEY 8f-4, not in the reference): the chains stay where they are and the TEMPERATURES move.  label[slot] =
-    // temperature index the chain in that slot holds, slot_of[temperature] = its inverse, both over the whole ladder and replicated
-    // on every rank; the cascade runs over temperature indices, the round only rewrites the maps, the temperature of the local
-    // slots and (before the temperature switch) the tempering of their likelihoods.  Nothing but L crosses a GPU boundary.
-    int label_mode;
-    const int* label_cur;      // [R]
-    const int* slot_cur;       // [R]
-    int* label_next;           // [R]
-    int* slot_next;            // [R]
-    float* temps_local;        // [Rl] temperature of the local slots (what the segment kernels read)
-    int* progress;             // pinned host word (or null): block 0 stores round + 1 when the round is through -- what the bounded
-                               // waits of a communicator handle watch (ptnn.hip: wait_stream)
-};
-__host__ __device__ inline int xchg_row_floats(int PS) { return (2 * PS + 4 + 3) & ~3; }
-
-// sSrc has R + 1 ints: the last one carries the number of accepted swaps
-// have_L: sL already holds the R posted scalars (the tree's in-launch swap round reads them from granules)
-__device__ __forceinline__ int cascade_lds(const SwapParams& sp, int round, float* sL, float* sU, int* sSrc, bool have_L = false) {
-    const int R = sp.R;
-    for (int k = threadIdx.x; k < R; k += blockDim.x) {
-        if (!have_L) sL[k] = sp.L[(size_t)(sp.label_mode ? sp.slot_cur[k] : k) * sp.L_stride];    // k is a temperature index
-        if (k < R - 1) {
-            uint32_t x[4];
-            philox4x32_10((uint32_t)k, (uint32_t)round, 0u, STREAM_SWAP, sp.seed_lo, sp.seed_hi, x);
-            // rule 0 compares in the log domain (below): ln(2 u) is computed here, by all threads at once, instead of an exp inside
-            // the sequential chain
-            sU[k] = (sp.rule == 1) ? u23(x[0]) : logf_fast(2.0f * u23(x[0]));
-        }
-    }
-    __syncthreads();
-    if (sp.rule == 1) {
-        // independent pairs (k, k+1), k of the round's parity
-        for (int k = threadIdx.x; k < R; k += blockDim.x) sSrc[k] = k;
-        if (threadIdx.x == 0) sSrc[R] = 0;
-        __syncthreads();
-        for (int k = (round & 1) + 2 * threadIdx.x; k < R - 1; k += 2 * blockDim.x) {
-            const int s0 = sp.label_mode ? sp.slot_cur[k] : k, s1 = sp.label_mode ? sp.slot_cur[k + 1] : k + 1;
-            const float d = (1.0f / sp.temps_global[k] - 1.0f / sp.temps_global[k + 1]) *
-                            (sp.L_raw[(size_t)s1 * sp.L_stride] - sp.L_raw[(size_t)s0 * sp.L_stride]);
-            const float pr = (d != d) ? 1.0f : fminf(1.0f, expf_fast(fminf(d, 80.0f)));
-            if (sU[k] < pr) { sSrc[k] = k + 1; sSrc[k + 1] = k; atomicAdd(&sSrc[R], 1); }
-        }
-        __syncthreads();
-        return sSrc[R];
-    }
-    // REG:674-679: swap iff u < min(1, 0.5 exp(min(709, L[k+1] - L[c]))).  u < 1 always, so the outer min never binds, and with
-    // u > 0 the test is ln(2 u) < min(709, L[k+1] - L[c]) -- subtract, clamp, compare, no transcendental.
-    //
-    // The bubble pass is sequential only through WHICH state is being carried: while the carried state is c, the tests of the
-    // pairs ahead are all against the same L[c], i.e. independent.  Wave 0 takes the pairs 64 at a time (lane = pair), tests
-    // all of them against the current carried L with one compare, and a ballot finds the first pair where it fails: the
-    // carried state is dropped there (src[k] = c), the next state is picked up (its L comes from that lane's register) and
-    // the lanes behind it are re-tested -- one iteration per DROP, not per pair, plus one per 64 pairs.  Wave-uniform control
-    // throughout.  (Round 1 walked the pairs one by one in thread 0 of every block, with an exp, a branch and an LDS store per
-    // pair: 95 ns per pair -- 6.1 us per round at R = 64, 40 us at 256, 72 us at 1024; independent forward scans from every
-    // start + pointer doubling were tried and are worse, because the reference's rule accepts 60 - 98 % of the swaps and the runs
-    // are long.)
-    if (threadIdx.x < WAVE) {
-        const int lane = threadIdx.x;
-        int c = 0, nsw = 0;
-        float Lc = sL[0];
-        for (int k0 = 0; k0 < R - 1; k0 += WAVE) {
-            const int k = k0 + lane;
-            const bool valid = k < R - 1;
-            const float Ln = valid ? sL[k + 1] : 0.0f;
-            const float tk = valid ? sU[k] : 0.0f;
-            unsigned long long todo = __ballot(valid);
-            unsigned long long swapped = 0ull;
-            while (todo) {
-                float d = Ln - Lc;
-                d = (d < 709.0f) ? d : 709.0f;              // python min(709, nan) == 709
-                const unsigned long long fail = __ballot(!(tk < d)) & todo;
-                if (!fail) { swapped |= todo; break; }       // the carried state passes every remaining pair of this window
-                const int j = __ffsll((long long)fail) - 1;  // first pair where it is dropped
-                swapped |= todo & ((1ull << j) - 1ull);
-                if (lane == j) sSrc[k] = c;                  // slot k0 + j receives the carried state ...
-                c = k0 + j + 1;                              // ... and the state of the next slot is picked up
-                Lc = __shfl(Ln, j);
-                todo &= (j == 63) ? 0ull : ~((2ull << j) - 1ull);
-            }
-            if (valid && ((swapped >> lane) & 1ull)) sSrc[k] = k + 1;
-            nsw += __popcll(swapped);
-        }
-        if (lane == 0) { sSrc[R - 1] = c; sSrc[R] = nsw; }
-    }
-    __syncthreads();
-    return sSrc[R];
-}
-
 // One block's share of a swap round: the cascade (every block recomputes it in LDS), then block b's row.  mode bit 0: apply the
 // local moves; bit 1: count the round and log it (block 0); bit 2: the source rows come from the gathered exchange buffer.
 __device__ __forceinline__ void swap_block(const SwapParams& sp, const int round, const int mode, const int b, float* smem) {
@@ -4077,46 +4203,6 @@ __host__ __device__ inline size_t tree_lds_floats(int Nall, int IPY, int PS, int
            MAX_WAVES * 8 + (size_t)(TREE_MAX_NODES + 1) * TREE_REC;
 }
 
-// What a launch that spans several swap intervals needs to know (persistent_loop at the end of this file; the tree body runs its
-// own swap rounds and reads it too)
-struct PersistParams {
-    int end;                 // MH steps are run up to here (exclusive)
-    int swap_inside;         // 1: the swap rounds between the intervals run inside this launch
-    int task, si;            // hand-off rule (Q10): REG after step i when i % si == 0 and i != 0; CLS when (i + 1) % si == 0
-    int round0;              // index of the first swap round of this launch
-    int flip0, lflip0;       // which state / label-map buffers are current at entry
-    int nblocks;             // work-groups of the grid
-    unsigned* barrier;       // [nblocks] phase every work-group has reached, zero at launch
-    float* state[2];
-    float* gd[2];
-    int* gd_valid[2];
-    int* label[2];
-    int* slot_of[2];
-    SwapParams sp;           // everything of a round that does not flip
-};
-
-// The PersistParams of the launch, read from the kernel-argument segment where it lies (second argument, behind SegParams) through
-// a pointer the optimiser cannot see through: every use re-loads the few words it needs (scalar loads from the constant cache)
-// instead of keeping ~60 words of it live across the interval body -- hoisted out of the loop they were spilled into vector
-// registers and, in the two kernels closest to the register ceiling, on into scratch.
-typedef __attribute__((address_space(4))) const PersistParams* persist_cptr;
-__device__ __forceinline__ persist_cptr persist_args() {
-    constexpr size_t off = (sizeof(SegParams) + alignof(PersistParams) - 1) & ~(alignof(PersistParams) - 1);
-    unsigned long long a = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + off;
-    asm volatile("" : "+s"(a));
-    return (persist_cptr)(uintptr_t)a;
-}
-
-typedef __attribute__((address_space(4))) const SegParams* seg_cptr;
-__device__ __forceinline__ seg_cptr seg_args() {
-    unsigned long long a = (unsigned long long)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(a));
-    return (seg_cptr)(uintptr_t)a;
-}
-
-// Granules of the tree's in-launch swap round, per parity: R posted scalars (padded to 8), R state rows for the other replicas' root
-// groups, R rows {flag, new state} from every root to its own siblings
-__host__ __device__ inline size_t tree_xchg_granules(int R, int PS) { return (size_t)((R + 7) & ~7) + (size_t)R * PS + (size_t)R * (PS + 8); }
 constexpr int TREE_PERSIST_MAX_R = ((TREE_MAX_NODES + 1) * TREE_REC - 1) / 3;      // the cascade's 3 R + 1 floats live in the record area of LDS
 
 template <int TASK, int I, int O>
@@ -4214,7 +4300,7 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
     // One launch for several swap intervals (PersistParams::swap_inside; the host takes this shape when the whole grid is resident):
     // the swap round after a hand-off step runs inside the launch, below.  ho_next = the next hand-off step (Q10: REG after step i
     // when i % si == 0 and i != 0, CLS when (i + 1) % si == 0), as persistent_loop and ptnn_run find it.
-    persist_cptr const pp = persist_args();
+    persist_cptr const pp = dyn.pp;
     const bool swap_inside = pp->swap_inside != 0;
     const int si_ = pp->si;
     auto next_handoff = [&](int cur) {
@@ -4421,7 +4507,7 @@ __device__ __forceinline__ void segment_tree_body(const SegParams& p, const SegD
             // round k + 2 only after it has read every scalar of round k + 1, which their owners post after reading round k.
             const int Rg = pp->sp.R;
             const unsigned xtag = dyn.epoch_base + (unsigned)nx + 1u;
-            granule_t* const xl = p.xw + (size_t)(nx & 1) * tree_xchg_granules(Rg, PS);
+            granule_t* const xl = p.xswap + (size_t)(nx & 1) * swap_xchg_granules(Rg, PS);
             granule_t* const xst = xl + ((Rg + 7) & ~7);
             granule_t* const xsb = xst + (size_t)Rg * PS + (size_t)gid * (PS + 8);
             auto gstore = [&](granule_t* g_, float v_) { if (xcd_local) granule_store_xcd(g_, xtag, v_); else granule_store(g_, xtag, v_); };
@@ -4656,6 +4742,7 @@ __device__ __forceinline__ void persistent_loop(const SegParams& p0, const int s
         persist_cptr pp = persist_args();
         SegDyn dyn;
         const int flip = pp->flip0;
+        dyn.pp = pp;
         dyn.w_state = pp->state[flip]; dyn.gd_w = pp->gd[flip]; dyn.gd_valid = pp->gd_valid[flip];
         dyn.epoch_base = p.epoch_base;
         body(p, dyn, step_begin, pp->end - step_begin);
@@ -4690,6 +4777,7 @@ __device__ __forceinline__ void persistent_loop(const SegParams& p0, const int s
 #endif
         {
             SegDyn dyn;
+            dyn.pp = pp;
             dyn.w_state = pp->state[flip]; dyn.gd_w = pp->gd[flip]; dyn.gd_valid = pp->gd_valid[flip];
             dyn.epoch_base = p.epoch_base + epoch_add;
             body(p, dyn, cur, stop - cur);

@@ -799,7 +799,7 @@ def test_checkpoint_resume_continues_bit_for_bit(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["sunspot_packed", "iris_coop", "ions_coop", "wide_res_g2", "sunspot_labels", "sunspot_evenodd", "iris_tree", "cancer_tree_g7"])
+@pytest.mark.parametrize("case", ["sunspot_packed", "iris_coop", "ions_coop", "wide_res_g2", "sunspot_labels", "sunspot_evenodd", "iris_tree", "cancer_tree_g7", "mackey_packm", "manyclass_packm"])
 def test_one_launch_per_run_equals_one_launch_per_interval(case, monkeypatch):
     """The persistent launch (every segment kernel loops over the swap intervals, grid barriers and the swap round inside:
     persistent_loop) against the round-2 shape (one launch per interval + swap_kernel, $PTNN_PERSISTENT=0): traces, swap log,
@@ -819,9 +819,24 @@ def test_one_launch_per_run_equals_one_launch_per_interval(case, monkeypatch):
         task, topo, name, lg, lr, mt, R, S, si, kw = 1, (4, 12, 3), "iris", False, 0.01, 10, 16, 203, 25, dict(schedule=1)
     elif case == "ions_coop":
         task, topo, name, lg, lr, mt, R, S, si, kw = 1, (34, 50, 2), "ions", False, 0.01, 10, 12, 83, 20, dict(schedule=1)
+    elif case == "iris_tree":         # the tree runs its swap rounds inside the launch by itself (root groups exchange granules, no grid barrier)
+        task, topo, name, lg, lr, mt, R, S, si, kw = 1, (4, 12, 3), "iris", False, 0.01, 10, 16, 403, 25, dict(schedule=4)
+    elif case == "cancer_tree_g7":    # 7 groups per replica, intervals that are no multiple of the depth (the last round of an interval is cut at the hand-off)
+        task, topo, name, lg, lr, mt, R, S, si, kw = 1, (9, 12, 2), "cancer", False, 0.01, 10, 24, 205, 7, dict(schedule=4, groups=7)
+    elif case == "mackey_packm":      # the packed round over 4 CUs per replica runs its swap rounds inside the launch too (state + cached gradient + flag)
+        task, topo, name, lg, lr, mt, R, S, si, kw = 0, (4, 10, 1), "mackey", True, 0.1, 2, 16, 243, 20, {}
+    elif case == "manyclass_packm":   # a many-class head: the body of this kernel is NOT inlined (it must be handed the launch's PersistParams)
+        task, topo, name, lg, lr, mt, R, S, si, kw = 1, (6, 9, 18), "synth_6_18", True, 0.01, 10, 8, 67, 7, {}
     else:
+        assert case == "wide_res_g2", case
         task, topo, name, lg, lr, mt, R, S, si, kw = 0, (32, 96, 1), "synth32", True, 0.1, 2, 6, 53, 10, dict(groups=2)
-    train, test = d[name + "_train"], d[name + "_test"]
+    if name == "synth_6_18":          # 18 classes on 6 random inputs (no such data set ships)
+        rg = np.random.default_rng(18)
+        X = rg.standard_normal((91, 6))
+        data = np.hstack([X, np.argmax(X @ rg.standard_normal((6, 18)), axis=1).astype(np.float64)[:, None]])
+        train, test = data[:70], data[70:]
+    else:
+        train, test = d[name + "_train"], d[name + "_test"]
     Pw = topo[0] * topo[1] + topo[1] * topo[2] + topo[1] + topo[2]
     scale = 0.3 if topo[1] > 64 else 1.0
     w0 = scale * np.stack([philox.initial_weights(7, r, Pw) for r in range(R)])
@@ -832,6 +847,10 @@ def test_one_launch_per_run_equals_one_launch_per_interval(case, monkeypatch):
         s = parity.make_sampler(task, topo, train, test, R_local=R, R_global=R, first=0, S=S, si=si, use_lg=lg, lr=lr, seed=7, **kw)
         launches = s.describe()["launches"]
         assert launches.startswith("one per swap interval" if mode == "0" else "one per ptnn_run"), launches
+        if case.endswith("_packm"):
+            assert "segment_packm_kernel" in s.describe()["kernel"] and s.describe()["groups_per_replica"] == 4
+        if case.endswith("_tree") or "_tree_" in case:
+            assert "segment_tree_kernel" in s.describe()["kernel"]
         s.set_state(w0, T)
         if kw.get("swap_rule") or kw.get("label_swap"):
             s.set_ladder(T)
