@@ -664,6 +664,26 @@ def _run_dist_child(args, limit):
 
 
 @pytest.mark.gpu
+def test_rccl_probe_in_a_child_process():
+    """distributed.rccl_probe: the RCCL bring-up rehearsed in a throw-away child process (ptnn_comm_probe: unique id, ncclCommInitRank
+    per device, a 4-byte all-gather, destroy) -- what LadderGroup asks before its own process touches RCCL.  World size 1 on this
+    one-GPU box: it must come up; a device listed twice must be refused with the reason, an injected fault must be reported with its
+    stage, and in every case it is the CHILD that touched RCCL."""
+    import ptnn_amd  # noqa: F401
+    from ptnn_amd import distributed
+    ok, text = distributed.rccl_probe([0])
+    assert ok and "RCCL probe over devices [0]" in text, text
+    ok, text = distributed.rccl_probe([0, 0])
+    assert not ok and "distinct device" in text, text
+    os.environ["PTNN_COMM_FAULT"] = "ncclCommInitRank"
+    try:
+        ok, text = distributed.rccl_probe([0])
+    finally:
+        del os.environ["PTNN_COMM_FAULT"]
+    assert not ok and "ncclCommInitRank" in text and "injected" in text, text
+
+
+@pytest.mark.gpu
 def test_rccl_bring_up_is_bounded():
     """ptnn_comm_init for a world of two ranks of which one never joins must return error -7 naming ncclCommInitRank within
     PTNN_COMM_TIMEOUT_S instead of blocking for ever (the reference's parent polls is_alive(), REG:721-727)."""
