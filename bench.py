@@ -600,10 +600,13 @@ def main():
                                         "sampling_s": tm.get("sampling_s"), "trace_download_s": tm.get("fetch_s"),
                                         "files_and_results_s": tm.get("files_and_results_s"), "show_results_s": tm.get("show_results_s"),
                                         "files_queue_s": tm.get("chain_files_s"), "files_drain_s": tm.get("files_drain_s"),
-                                        "result_file_bytes": nbytes,
+                                        "result_file_bytes": nbytes, "overlapped": bool(tm.get("overlapped")),
+                                        "launches_per_run": tm.get("launches_per_run", 1), "rows_landed_s": tm.get("rows_landed_s"), "segment_kernel_ms": tm.get("segment_kernel_ms"),
                                         "pcie_inclusive_samples_per_s": R * (S - 1) / max((tm.get("sampling_s") or 0) + (tm.get("fetch_s") or 0), 1e-9),
                                         "note": "the drop-in ParallelTempering(...).run_chains() of this workload, files included; reported, "
-                                                "never `value`"}
+                                                "never `value`.  overlapped: the run is cut into launches_per_run launches and the trace "
+                                                "rows of each go to the host and into the files while the next samples; sampling_s then "
+                                                "ends when the last rows have landed (trace_download_s is inside it)"}
             except Exception as e:                              # noqa: BLE001  (a full /tmp must not cost the bench line)
                 extras["end_to_end"] = {"error": repr(e)}
 

@@ -250,6 +250,17 @@ int ptnn_get_traces(ptnn_handle *h, int step0, int nsteps, float *pos_w, float *
  * state here (the chain's eta after an accepted step; tests set the oracle's state from it).  Does not mark rows as
  * fetched.  Same range rules as ptnn_get_traces. */
 int ptnn_get_trace_rows(ptnn_handle *h, int step0, int nsteps, float *rows);
+/* Trace images: the trace download overlapped with sampling (the reference's chains write their files after their last step and
+ * the parent reads them back, REG:454-481, 775-871; here rows can leave while later steps are sampled).  ptnn_trace_image: pinned
+ * host copies owned by the handle, in the device's layout -- pos_w [R, n_samples, *row_floats] (the first n_param floats of a row
+ * are the vector), rows [R, n_samples, 8] as ptnn_get_trace_rows describes them; allocated on the first call; needs every row
+ * resident (trace_capacity 0) and non-compact traces.  ptnn_trace_image_fetch: behind everything queued on the handle so far
+ * (ptnn_run returns once the steps are queued), copies rows [step0, step0+nsteps) of every local replica into the images on a
+ * second stream and returns a ticket >= 0; marks the rows as fetched.  ptnn_trace_image_wait: blocks until that copy has landed.
+ * A run's errors surface at ptnn_sync as always.  ptnn_set_state (a restart) forgets all tickets. */
+int ptnn_trace_image(ptnn_handle *h, float **pos_w, int32_t *row_floats, float **rows);
+int ptnn_trace_image_fetch(ptnn_handle *h, int step0, int nsteps);
+int ptnn_trace_image_wait(ptnn_handle *h, int ticket);
 /* num_swap / total_swap_proposals (REG:501-502, 680-688) */
 int ptnn_get_swap_stats(ptnn_handle *h, int64_t *num_swap, int64_t *total_proposals, int32_t *rounds_done);
 /* src permutation of every completed round, [rounds, R_global] (tests) */
@@ -323,6 +334,10 @@ int ptnn_savetxt(const char *path, const double *data, int64_t rows, int64_t col
  * arithmetic (correctly rounded, ties to even, as glibc's printf), printf itself only for formats or magnitudes outside that
  * path, and a row identical to the one before it (a rejected MH step: pos_w[i+1] = pos_w[i], REG:417) reuses that row's text. */
 int ptnn_savetxt_f32(const char *path, const float *data, int64_t rows, int64_t cols, int64_t row_stride, const char *fmt, int append);
+/* n_files such files (the per-chain files of a window of trace rows, REG:454-481) by `threads` host threads, taken in the order
+ * given (put the large ones first); returns when all are written, < 0 with the first failure's message */
+int ptnn_savetxt_f32_batch(int n_files, const char *const *paths, const float *const *data, const int64_t *rows, const int64_t *cols,
+                           const int64_t *row_stride, const char *const *fmts, int append, int threads);
 
 /* in place: every value as np.loadtxt would read it back after np.savetxt(fmt=fmt) (show_results re-reads the per-chain
  * files, REG:795-831) */
@@ -330,8 +345,10 @@ int ptnn_text_round(double *values, int64_t n, const char *fmt);
 int ptnn_text_round_f32(const float *in, double *out, int64_t n, const char *fmt);
 /* out[p][c * m + t] = pos_w[c][first_row + t][p] with m = n_rows - first_row, as float64: the posterior matrix show_results
  * returns (REG:795-797, 848: every chain's pos_w file read back, burn-in cut, chains side by side, transposed).
- * pos_w [n_chains, n_rows, n_param] float32 as ptnn_get_traces delivers it; out [n_param, n_chains * m]; `threads` host threads. */
-int ptnn_posterior_matrix(const float *pos_w, int64_t n_chains, int64_t n_rows, int64_t n_param, int64_t first_row, double *out, int threads);
+ * pos_w [n_chains, n_rows, row_floats >= n_param] float32 (row_floats == n_param as ptnn_get_traces delivers it, the padded row of
+ * ptnn_trace_image); out [n_param, n_chains * m]; `threads` host threads. */
+int ptnn_posterior_matrix(const float *pos_w, int64_t n_chains, int64_t n_rows, int64_t n_param, int64_t row_floats, int64_t first_row,
+                          double *out, int threads);
 
 #ifdef __cplusplus
 }

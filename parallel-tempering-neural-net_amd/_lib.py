@@ -97,7 +97,12 @@ SYMBOLS = {
     "ptnn_savetxt": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_char_p]),
     "ptnn_savetxt_f32": (C.c_int, [C.c_char_p, _fp, C.c_int64, C.c_int64, C.c_int64, C.c_char_p, C.c_int]),
     "ptnn_text_round_f32": (C.c_int, [_fp, C.POINTER(C.c_double), C.c_int64, C.c_char_p]),
-    "ptnn_posterior_matrix": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_int]),
+    "ptnn_posterior_matrix": (C.c_int, [_fp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_int]),
+    "ptnn_savetxt_f32_batch": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(_fp), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                         C.POINTER(C.c_int64), C.POINTER(C.c_char_p), C.c_int, C.c_int]),
+    "ptnn_trace_image": (C.c_int, [C.c_void_p, C.POINTER(_fp), _ip, C.POINTER(_fp)]),
+    "ptnn_trace_image_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "ptnn_trace_image_wait": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 
@@ -343,6 +348,23 @@ class Sampler:
                                              _ptr(out["acc_test"]), _ptr(out["accept"], _ip)))
         return out
 
+    # ---- trace images: the download overlapped with sampling (ptnn_trace_image*) ----
+    def trace_image(self):
+        """(pos_w, rows): numpy views of the handle's pinned host images -- pos_w [R, S, P] float32 (rows strided by the device's
+        padded row), rows [R, S, 8] as trace_rows() describes them.  Valid until close(); filled by trace_fetch()."""
+        pw, rw, rf = _fp(), _fp(), C.c_int32()
+        self._check(self.lib.ptnn_trace_image(self.h, C.byref(pw), C.byref(rf), C.byref(rw)))
+        pos = np.ctypeslib.as_array(pw, shape=(self.R, self.S, rf.value))[:, :, :self.P]
+        rows = np.ctypeslib.as_array(rw, shape=(self.R, self.S, 8))
+        return pos, rows
+
+    def trace_fetch(self, row0, nrows):
+        """Queues the copy of trace rows [row0, row0 + nrows) into the images behind the steps queued so far; returns a ticket."""
+        return self._check(self.lib.ptnn_trace_image_fetch(self.h, int(row0), int(nrows)))
+
+    def trace_wait(self, ticket):
+        self._check(self.lib.ptnn_trace_image_wait(self.h, int(ticket)))
+
     def trace_rows(self, row0=0, nrows=None):
         """The scalar trace rows as the device keeps them (ptnn_get_trace_rows), [R, nrows, 8] float32."""
         n = self.S - row0 if nrows is None else nrows
@@ -474,6 +496,31 @@ def savetxt(path, array, fmt, append=False):
         raise PtnnError(lib.ptnn_last_error().decode())
 
 
+def savetxt_batch(jobs, append=False, threads=8):
+    """savetxt(path, array, fmt) for every (path, array, fmt) of `jobs` in ONE call into the C library, which spreads the files over
+    `threads` host threads in the order given.  float32 arrays (1-D, or 2-D with unit column stride) only: the per-chain files of a
+    window of trace rows."""
+    lib = load_library()
+    n = len(jobs)
+    if n == 0:
+        return
+    paths, data, fmts = (C.c_char_p * n)(), (_fp * n)(), (C.c_char_p * n)()
+    rows, cols, strides = (C.c_int64 * n)(), (C.c_int64 * n)(), (C.c_int64 * n)()
+    keep = []
+    for k, (path, array, fmt) in enumerate(jobs):
+        a = np.asarray(array)
+        if a.dtype != np.float32 or a.ndim not in (1, 2) or a.strides[-1] != 4 or (a.ndim == 2 and (a.strides[0] % 4 or a.strides[0] < 4 * a.shape[1])):
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if a.ndim not in (1, 2):
+                raise ValueError("savetxt handles 1-D and 2-D arrays")
+        keep.append(a)
+        paths[k], fmts[k] = os.fsencode(path), fmt.encode()
+        data[k] = a.ctypes.data_as(_fp)
+        rows[k], cols[k], strides[k] = (a.shape[0], 1, 1) if a.ndim == 1 else (a.shape[0], a.shape[1], a.strides[0] // 4)
+    if lib.ptnn_savetxt_f32_batch(n, paths, data, rows, cols, strides, fmts, int(bool(append)), int(threads)) < 0:
+        raise PtnnError(lib.ptnn_last_error().decode())
+
+
 def _chunks(n, threads, grain=65536):
     k = max(1, min(int(threads), n // grain + 1))
     b = np.linspace(0, n, k + 1).astype(np.int64)
@@ -516,9 +563,13 @@ def posterior_matrix(pos_w, first_row, threads=8):
     """pos_w float32 [R, S, P] -> float64 [P, R * (S - first_row)]: rows from first_row on, chains side by side, transposed
     (what show_results returns as pos_w, REG:795-797, 848)."""
     lib = load_library()
-    a = np.ascontiguousarray(pos_w, dtype=np.float32)
+    a = np.asarray(pos_w)
     R, S, P = a.shape
+    # the padded rows of a trace image are read in place; anything else is made dense first
+    if not (a.dtype == np.float32 and a.strides[2] == 4 and a.strides[1] % 4 == 0 and a.strides[1] >= 4 * P and a.strides[0] == S * a.strides[1]):
+        a = np.ascontiguousarray(a, dtype=np.float32)
     out = np.empty((P, R * (S - first_row)), dtype=np.float64)
-    if lib.ptnn_posterior_matrix(a.ctypes.data_as(_fp), R, S, P, int(first_row), out.ctypes.data_as(C.POINTER(C.c_double)), int(threads)) < 0:
+    if lib.ptnn_posterior_matrix(a.ctypes.data_as(_fp), R, S, P, a.strides[1] // 4, int(first_row), out.ctypes.data_as(C.POINTER(C.c_double)),
+                                 int(threads)) < 0:
         raise PtnnError(lib.ptnn_last_error().decode())
     return out

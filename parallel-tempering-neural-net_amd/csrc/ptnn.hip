@@ -9,11 +9,13 @@
 #include "../../include/ptnn.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <unordered_map>
 #include <mutex>
 #include <string>
@@ -131,6 +133,11 @@ struct ptnn_handle {
     // sharded ladder: transport and what a swap round moves through it
     Comm comm;
     std::vector<RowMsg> route;
+    // trace images on the host (ptnn_trace_image*): pinned copies of d_pos_w / d_scal that a second stream fills while the chains
+    // go on sampling
+    hipStream_t copy_stream = nullptr;
+    float *h_img_pos = nullptr, *h_img_rows = nullptr;
+    std::vector<hipEvent_t> img_events;                     // ticket k: the copy of its rows has landed
     // kernel timing (HIP events on our stream)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing;
     size_t timing_used = 0;
@@ -569,6 +576,10 @@ int ptnn_destroy(ptnn_handle* h) {
     if (h->d_stage) (void)hipFree(h->d_stage);
     if (h->d_xchg) (void)hipFree(h->d_xchg);
     for (auto& ev : h->timing) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    for (auto& ev : h->img_events) (void)hipEventDestroy(ev);
+    if (h->h_img_pos) (void)hipHostFree(h->h_img_pos);
+    if (h->h_img_rows) (void)hipHostFree(h->h_img_rows);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -939,6 +950,11 @@ int ptnn_set_state(ptnn_handle* h, const float* w0, const float* temperatures) {
     if (!h->have_data) return fail(-1, "call ptnn_set_data before ptnn_set_state");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     if (int rc = wait_stream(h)) return rc;                // a restart must not overtake a run still in flight (nor the staging buffer)
+    if (h->copy_stream) {                                   // ... nor the trace rows of the previous run on their way to the host
+        HIP_TRY(hipStreamSynchronize(h->copy_stream));
+        for (auto& ev : h->img_events) (void)hipEventDestroy(ev);
+        h->img_events.clear();
+    }
     const int Rl = h->cfg.n_replicas_local, P = h->P;
     // one pinned staging buffer, one asynchronous copy, one kernel -- all on the handle's stream (a whole-run restart is part of
     // the benchmark's timed region).  Trace rows 1 .. S-1 need no clearing: every one of them is written by the MH step it
@@ -1516,6 +1532,65 @@ int ptnn_get_trace_rows(ptnn_handle* h, int step0, int nsteps, float* rows) {
     return 0;
 }
 
+// ---- trace images: the download of the trace rows overlapped with sampling ----
+// The reference's chains write their files after their last step and the parent reads them back (REG:454-481, 775-871); here the
+// rows of the steps queued so far can leave for the host while the steps queued behind them are being sampled: a pinned host copy
+// of the device's trace arrays (same layout, so a range of rows is one strided copy per array) filled by a second stream behind an
+// event of the handle's stream.
+int ptnn_trace_image(ptnn_handle* h, float** pos_w, int32_t* row_floats, float** rows) {
+    if (int rc = check_ready(h)) return rc;
+    if (!pos_w || !row_floats || !rows) return fail(-1, "null argument");
+    const int S = h->cfg.n_samples, Rl = h->cfg.n_replicas_local;
+    if (h->cap != S) return fail(-1, "trace images need every row resident (trace_capacity 0 or >= n_samples; this handle keeps a ring of %d)", h->cap);
+    if (h->compact) return fail(-1, "trace images are not available with compact traces (wide nets): fetch with ptnn_get_traces");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    if (!h->h_img_pos) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_img_pos), (size_t)Rl * S * h->PW * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_img_rows), (size_t)Rl * S * TR_COUNT * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    }
+    *pos_w = h->h_img_pos; *row_floats = h->PW; *rows = h->h_img_rows;
+    return 0;
+}
+
+int ptnn_trace_image_fetch(ptnn_handle* h, int step0, int nsteps) {
+    if (int rc = check_ready(h)) return rc;
+    if (!h->h_img_pos) return fail(-1, "call ptnn_trace_image first");
+    if (h->failed) return fail(-5, "%s", h->failure.c_str());
+    const int S = h->cfg.n_samples, Rl = h->cfg.n_replicas_local;
+    if (step0 < 0 || nsteps < 1 || step0 + nsteps > S) return fail(-1, "trace range [%d, %d) outside [0, %d)", step0, step0 + nsteps, S);
+    if (step0 + nsteps > h->cur + 1) return fail(-1, "rows up to %d requested but only %d MH steps have been queued", step0 + nsteps - 1, h->cur);
+    if (step0 < h->first_row) return fail(-1, "rows below %d were produced before the checkpoint these chains were restored from", h->first_row);
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    hipEvent_t queued = nullptr, landed = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&queued, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(queued, h->stream);                         // everything queued so far: the steps that write these rows
+    if (e == hipSuccess) e = hipStreamWaitEvent(h->copy_stream, queued, 0);
+    (void)hipEventDestroy(queued);                                           // released once it has completed
+    HIP_TRY(e);
+    const size_t PWb = (size_t)h->PW * sizeof(float), RWb = (size_t)TR_COUNT * sizeof(float);
+    HIP_TRY(hipMemcpy2DAsync(reinterpret_cast<char*>(h->h_img_pos) + (size_t)step0 * PWb, (size_t)S * PWb,
+                             reinterpret_cast<const char*>(h->d_pos_w) + (size_t)step0 * PWb, (size_t)S * PWb, (size_t)nsteps * PWb, Rl,
+                             hipMemcpyDeviceToHost, h->copy_stream));
+    HIP_TRY(hipMemcpy2DAsync(reinterpret_cast<char*>(h->h_img_rows) + (size_t)step0 * RWb, (size_t)S * RWb,
+                             reinterpret_cast<const char*>(h->d_scal) + (size_t)step0 * RWb, (size_t)S * RWb, (size_t)nsteps * RWb, Rl,
+                             hipMemcpyDeviceToHost, h->copy_stream));
+    HIP_TRY(hipEventCreateWithFlags(&landed, hipEventDisableTiming));
+    e = hipEventRecord(landed, h->copy_stream);
+    if (e != hipSuccess) { (void)hipEventDestroy(landed); HIP_TRY(e); }
+    h->img_events.push_back(landed);
+    h->drained = std::max(h->drained, step0 + nsteps - 1);
+    return (int)h->img_events.size() - 1;
+}
+
+int ptnn_trace_image_wait(ptnn_handle* h, int ticket) {
+    if (!h) return fail(-1, "null handle");
+    if (ticket < 0 || ticket >= (int)h->img_events.size() || !h->img_events[(size_t)ticket]) return fail(-1, "no such ticket");
+    HIP_TRY(hipSetDevice(h->cfg.device_id));
+    HIP_TRY(hipEventSynchronize(h->img_events[(size_t)ticket]));
+    return 0;
+}
+
 int ptnn_get_swap_stats(ptnn_handle* h, int64_t* num_swap, int64_t* total_proposals, int32_t* rounds_done) {
     if (!h) return fail(-1, "null handle");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
@@ -1884,8 +1959,11 @@ static int write_text_rows(const char* path, int64_t rows, int64_t cols, const c
     if (!fp) return fail(-4, "cannot open %s for writing", path);
     std::setvbuf(fp, nullptr, _IONBF, 0);                      // the block below is the buffer
     const size_t line_cap = (size_t)cols * 401 + 2;
-    std::vector<char> buf(std::max<size_t>(4u << 20, 2 * line_cap));
-    std::vector<char> line(line_cap);
+    // no larger than the file can get, and not value-initialised: most of a run's files are a few KB
+    const size_t buf_size = std::max<size_t>(std::min<size_t>(4u << 20, (size_t)std::max<int64_t>(rows, 1) * line_cap), 2 * line_cap);
+    const std::unique_ptr<char[]> buf_mem(new char[buf_size]), line_mem(new char[line_cap]);
+    struct Span { char* p; size_t n; char* data() const { return p; } size_t size() const { return n; } };
+    const Span buf{buf_mem.get(), buf_size}, line{line_mem.get(), line_cap};
     size_t used = 0, line_len = 0;
     for (int64_t r = 0; r < rows; ++r) {
         if (r == 0 || !same_as_prev(r)) {
@@ -1925,22 +2003,47 @@ int ptnn_savetxt_f32(const char* path, const float* data, int64_t rows, int64_t 
                            [&](int64_t r) { return std::memcmp(data + r * row_stride, data + (r - 1) * row_stride, (size_t)cols * sizeof(float)) == 0; });
 }
 
-int ptnn_posterior_matrix(const float* pos_w, int64_t n_chains, int64_t n_rows, int64_t n_param, int64_t first_row, double* out, int threads) {
+int ptnn_savetxt_f32_batch(int n_files, const char* const* paths, const float* const* data, const int64_t* rows, const int64_t* cols,
+                           const int64_t* row_stride, const char* const* fmts, int append, int threads) {
+    if (n_files < 0 || (n_files && (!paths || !data || !rows || !cols || !row_stride || !fmts))) return fail(-1, "null argument");
+    const int T = std::max(1, std::min(threads, n_files));
+    std::atomic<int> next{0}, bad{-1};
+    std::mutex mu;
+    std::string why;
+    auto work = [&]() {
+        for (int k = next.fetch_add(1); k < n_files; k = next.fetch_add(1)) {
+            if (ptnn_savetxt_f32(paths[k], data[k], rows[k], cols[k], row_stride[k], fmts[k], append) < 0) {
+                std::lock_guard<std::mutex> lock(mu);
+                if (bad.load() < 0) { bad.store(k); why = g_err; }     // g_err is per thread: carry the first cause to the caller's
+            }
+        }
+    };
+    if (T == 1) work();
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back(work);
+        for (auto& x : th) x.join();
+    }
+    if (bad.load() >= 0) return fail(-4, "%s", why.c_str());
+    return 0;
+}
+
+int ptnn_posterior_matrix(const float* pos_w, int64_t n_chains, int64_t n_rows, int64_t n_param, int64_t row_floats, int64_t first_row, double* out, int threads) {
     // out[p][c * m + t] = pos_w[c][first_row + t][p], m = n_rows - first_row: the (P, R (S - b)) float64 matrix show_results
     // returns (REG:795-797, 848: np.loadtxt of every chain's pos_w file, burn-in cut, chains side by side, transposed)
-    if (!pos_w || !out || n_chains < 1 || n_param < 1 || first_row < 0 || first_row > n_rows) return fail(-1, "bad argument");
+    if (!pos_w || !out || n_chains < 1 || n_param < 1 || row_floats < n_param || first_row < 0 || first_row > n_rows) return fail(-1, "bad argument");
     const int64_t m = n_rows - first_row;
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n_chains));
     auto work = [&](int t) {
         for (int64_t c = t; c < n_chains; c += T) {
-            const float* src = pos_w + (c * n_rows + first_row) * n_param;
+            const float* src = pos_w + (c * n_rows + first_row) * row_floats;
             // blocks of rows: the block's source (bt x P floats) stays in cache while it is read P times with stride P
             for (int64_t t0 = 0; t0 < m; t0 += 256) {
                 const int64_t bt = std::min<int64_t>(256, m - t0);
                 for (int64_t p = 0; p < n_param; ++p) {
                     double* dst = out + p * (n_chains * m) + c * m + t0;
-                    const float* s = src + t0 * n_param + p;
-                    for (int64_t k = 0; k < bt; ++k) dst[k] = (double)s[k * n_param];
+                    const float* s = src + t0 * row_floats + p;
+                    for (int64_t k = 0; k < bt; ++k) dst[k] = (double)s[k * row_floats];
                 }
             }
         }

@@ -55,7 +55,7 @@ class ParallelTemperingBase:
     def __init__(self, use_langevin_gradients, learn_rate, traindata, testdata, topology, num_chains, maxtemp,
                  NumSample, swap_interval, langevin_prob, path, *, seed=None, device=None, devices=None, exchange="auto",
                  transport=None, waves_per_replica=0, schedule=0, groups_per_replica=0, trace_capacity=0, swap_rule=0,
-                 label_swap=False, shared_noise=True, write_files=True, io_threads=None, forward_bf16=0):
+                 label_swap=False, shared_noise=True, write_files=True, io_threads=None, forward_bf16=0, overlap_chunks=8):
         # FNN chain variables (REG:491-494)
         self.traindata = traindata
         self.testdata = testdata
@@ -110,6 +110,10 @@ class ParallelTemperingBase:
         self.trace_capacity = int(trace_capacity)   # rows per replica kept in HBM (0 = all); smaller = streamed to the host
         self.write_files = bool(write_files)
         self.io_threads = io_threads or min(16, os.cpu_count() or 1)
+        # run_chains() cuts the run into this many launches and lets the trace rows of each leave for the host -- and into the
+        # per-chain files -- while the next is being sampled (one GPU, every row resident); 0: download and write after the last step
+        self.overlap_chunks = int(overlap_chunks)
+        self._img = None
         self.timings = {}
         self._sampler = None
         self._w0 = None
@@ -179,6 +183,15 @@ class ParallelTemperingBase:
         self._sampler.set_state(self._w0, self.temperatures)
         if self.swap_rule == 1 or self.label_swap:
             self._sampler.set_ladder(self.temperatures)
+        self._img = None
+        # (the images are pinned host memory the size of the device's trace arrays: taken up to 1 GiB, above that the resident path)
+        image_bytes = self.num_chains * S * (self.num_param + 24) * 4
+        if (self.overlap_chunks > 1 and isinstance(self._sampler, _lib.Sampler) and not self.label_swap and not (0 < self.trace_capacity < S)
+                and image_bytes <= int(os.environ.get("PTNN_TRACE_IMAGE_MAX_BYTES", 1 << 30))):
+            try:
+                self._img = self._sampler.trace_image()      # pinned host images of the trace arrays, allocated here once
+            except _lib.PtnnError:
+                self._img = None                             # compact traces (wide nets): the resident path
 
     # ------------------------------------------------------------------ run_chains (REG:694-771)
     def run_chains(self, *, checkpoint_path=None, checkpoint_every=None, resume_from=None, max_steps=None):
@@ -235,6 +248,8 @@ class ParallelTemperingBase:
             t1 = time.perf_counter() - t_fetch
             t2 = t1 + t_fetch
             self.num_swap, self.total_swap_proposals, self.rounds = self._sampler.swap_stats()
+        elif self._img is not None:
+            return self._run_overlapped(t0)
         else:
             self._sampler.run(-1)
             self._sampler.sync()
@@ -254,14 +269,89 @@ class ParallelTemperingBase:
             for f in pending:
                 f.result()                                   # an I/O error of any file surfaces here
         t5 = time.perf_counter()
+        return self._finish_run(out, dict(sampling_s=t1 - t0, fetch_s=t2 - t1, chain_files_s=t3 - t2, show_results_s=t4 - t3, files_drain_s=t5 - t4,
+                                          files_and_results_s=t5 - t2, overlapped=False))
+
+    def _finish_run(self, out, timings):
         nlaunch, kms = self._sampler.kernel_time()
-        self.timings = dict(sampling_s=t1 - t0, fetch_s=t2 - t1, chain_files_s=t3 - t2, show_results_s=t4 - t3, files_drain_s=t5 - t4,
-                            files_and_results_s=t5 - t2, segment_launches=nlaunch, segment_kernel_ms=kms,
-                            samples_per_s=self.num_chains * (S - 1) / max(t1 - t0, 1e-12))
+        self.timings = dict(timings, segment_launches=nlaunch, segment_kernel_ms=kms,
+                            samples_per_s=self.num_chains * (self.NumSamples - 1) / max(timings["sampling_s"], 1e-12))
         pos_w, fx_train, fx_test, rmse_train, rmse_test, acc_train, acc_test, likelihood_vec, accept_vec, accept = out
         swap_perc = self.num_swap * 100 / self.total_swap_proposals            # ZeroDivisionError when no round ran (REG:769)
         return (pos_w, fx_train, fx_test, rmse_train, rmse_test, acc_train, acc_test, likelihood_vec, swap_perc,
                 accept_vec, accept)
+
+    # ------------------------------------------------------------------ run_chains with the download and the files behind the sampling
+    def _run_overlapped(self, t0):
+        """The run in `overlap_chunks` launches (whole swap intervals each; the chain does not depend on the cut: ptnn_run); the
+        trace rows of a launch are copied into the pinned images by a second stream as soon as it ends, and formatted into the
+        per-chain files (append mode) by the pool, while the next launch samples.  Same bytes in every file as the resident path."""
+        s, S, si = self._sampler, self.NumSamples, max(1, int(self.swap_interval))
+        pos_img, rows_img = self._img
+        n_int = max(1, (S - 1) // si)
+        K = max(1, min(self.overlap_chunks, n_int))
+        ends = sorted({min(S - 1, si * max(1, round(n_int * (c + 1) / K))) for c in range(K - 1)} | {S - 1})
+        tickets, done, row = [], 0, 0
+        for b in ends:
+            s.run(-1 if b == S - 1 else b - done)           # queued, not waited for
+            done = b
+            tickets.append((s.trace_fetch(row, b + 1 - row), row, b + 1))       # rows 0 .. b exist once step b - 1 has run
+            row = b + 1
+        # one writer thread takes the windows in order (a file's pieces must follow each other); each window is one call into the C
+        # library, which spreads its 7 R files over the I/O threads
+        with ThreadPoolExecutor(max_workers=self.io_threads) as ex, ThreadPoolExecutor(max_workers=1) as writer:
+            pending, landed = [], []
+            for tk, lo, hi in tickets:
+                s.trace_wait(tk)
+                landed.append(round(time.perf_counter() - t0, 6))
+                if self.write_files:
+                    pending.append(writer.submit(self._write_chain_rows, pos_img, rows_img, lo, hi))
+            s.sync()                                         # a failed run surfaces here
+            t1 = time.perf_counter()
+            self.num_swap, self.total_swap_proposals, self.rounds = s.swap_stats()
+            zeros = np.zeros((self.num_chains, S), np.float32)
+            tr = {"pos_w": pos_img, "likeh": rows_img[:, :, 0], "rmse_train": rows_img[:, :, 1], "rmse_test": rows_img[:, :, 2],
+                  "acc_train": zeros if self.task == TASK_REG else rows_img[:, :, 3],      # REG:403 (the slot carries eta, ptnn.h)
+                  "acc_test": rows_img[:, :, 4], "accept": rows_img[:, :, 5].view(np.int32)}
+            if self.write_files:
+                self._final_accepted = s.state()["num_accepted"]
+                for r, T in enumerate(self.temperatures):
+                    acc_ratio = int(self._final_accepted[r]) / (S * 1.0) * 100     # REG:447
+                    pending.append(ex.submit(_lib.savetxt, f'{self.path}/posterior/accept_list/chain_{T}_accept.txt', np.array([acc_ratio]), '%1.4f'))
+            t3 = time.perf_counter()
+            out = self.show_results(tr, _pool=ex, _pending=pending)
+            t4 = time.perf_counter()
+            for f in pending:
+                f.result()                                   # an I/O error of any file surfaces here
+        t5 = time.perf_counter()
+        return self._finish_run(out, dict(sampling_s=t1 - t0, fetch_s=0.0, chain_files_s=t3 - t1, show_results_s=t4 - t3, files_drain_s=t5 - t4,
+                                          files_and_results_s=t5 - t1, overlapped=True, launches_per_run=len(ends), rows_landed_s=landed))
+
+    def _write_chain_rows(self, pos_img, rows_img, lo, hi):
+        """Rows [lo, hi) of every per-chain trace file (REG:454-481): one call into the C library, which spreads the 7 R files over
+        the I/O threads (pieces of a file are written in order: the caller runs these calls one after the other)."""
+        n, R = hi - lo, self.num_chains
+        rows = rows_img[:, lo:hi]                                                 # [R, n, 8] view of the image
+        likeh = np.zeros((R, n, 2), dtype=np.float32)
+        likeh[:, :, 0] = rows[:, :, 0]
+        if lo == 0:
+            likeh[:, 0, 1] = -100.0                                               # row 0 = [-100, -100] (REG:293)
+        # accept_list[i+1] holds the count BEFORE step i (REG:380): small integers, exact in float32
+        accept = rows[:, :, 5].view(np.int32).astype(np.float32)
+        acc_tr = np.zeros((R, n, 1), np.float32) if self.task == TASK_REG else rows[:, :, 3:4]
+        big, small = [], []
+        for r, T in enumerate(self.temperatures):
+            tn = str(T)
+            big.append((f'{self.path}/posterior/pos_w/chain_{tn}.txt', pos_img[r, lo:hi], '%.18e'))
+            small += [
+                (f'{self.path}/predictions/rmse_test_chain_{tn}.txt', rows[r, :, 2:3], self.rmse_fmt),
+                (f'{self.path}/predictions/rmse_train_chain_{tn}.txt', rows[r, :, 1:2], self.rmse_fmt),
+                (f'{self.path}/predictions/acc_test_chain_{tn}.txt', rows[r, :, 4:5], '%1.2f'),
+                (f'{self.path}/predictions/acc_train_chain_{tn}.txt', acc_tr[r], '%1.2f'),
+                (f'{self.path}/posterior/pos_likelihood/chain_{tn}.txt', likeh[r], '%1.4f'),
+                (f'{self.path}/posterior/accept_list/chain_{tn}.txt', accept[r], '%1.4f'),
+            ]
+        _lib.savetxt_batch(big + small, append=lo > 0, threads=self.io_threads)   # the big files first
 
     # ------------------------------------------------------------------ label swapping: rows per chain slot -> rows per temperature
     def _handoff_steps(self):

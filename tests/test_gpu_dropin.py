@@ -184,6 +184,54 @@ def test_streaming_run_chains_equals_resident(tmp_path):
         assert np.array_equal(np.asarray(x), np.asarray(y))
 
 
+def _same_files(a, b):
+    n = 0
+    for root, _, files in os.walk(a):
+        for f in files:
+            pa = os.path.join(root, f)
+            assert open(pa, "rb").read() == open(pa.replace(str(a), str(b)), "rb").read(), f
+            n += 1
+    return n
+
+
+@pytest.mark.parametrize("key,chunks", [("reg", 8), ("cls", 8), ("reg_nophantom", 3), ("reg_sunspot5", 2)])
+def test_overlapped_run_chains_equals_resident(key, chunks, tmp_path):
+    """run_chains() by default cuts the run into `overlap_chunks` launches and lets the trace rows of each leave for the host (pinned
+    images, second stream) and into the per-chain files (append mode) while the next launch samples.  Same return tuple, same bytes in
+    every file, same swap statistics as the resident path (overlap_chunks=0: one launch, download and files after the last step)."""
+    os.makedirs(tmp_path / "a")
+    os.makedirs(tmp_path / "b")
+    a = _run(key, tmp_path / "a", overlap_chunks=0)
+    b = _run(key, tmp_path / "b", overlap_chunks=chunks)
+    assert a[1].timings["overlapped"] is False and b[1].timings["overlapped"] is True
+    assert b[1].timings["launches_per_run"] > 1
+    for x, y in zip(a[2], b[2]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    assert (a[1].num_swap, a[1].total_swap_proposals, a[1].rounds) == (b[1].num_swap, b[1].total_swap_proposals, b[1].rounds)
+    assert _same_files(tmp_path / "a", tmp_path / "b") >= 8 * int(a[0]["R"]) + 3
+
+
+def test_overlapped_run_at_the_headline_shape(tmp_path):
+    """The same at a size where the pieces really overlap: Sunspot 4-5-1, 16 chains x 3000 samples, Langevin, shared noise; and a
+    second run_chains() on a fresh object in the same process (the images are per handle)."""
+    from ptnn_amd.pt_timeseries_regression import ParallelTempering
+    d = parity.datasets()
+    res = {}
+    for name, oc in (("a", 0), ("b", 8), ("c", 5)):
+        path = str(tmp_path / name)
+        pt = ParallelTempering(True, 0.1, d["sunspot_train"], d["sunspot_test"], [4, 5, 1], 16, 2, 16 * 3000, 100, 0.5, path, seed=11, overlap_chunks=oc)
+        for sdir in SUBDIRS:
+            pt.make_directory(os.path.join(path, sdir))
+        pt.initialize_chains(0.5)
+        res[name] = (pt.run_chains(), pt.num_swap, pt.timings)
+    assert res["b"][2]["overlapped"] and res["b"][2]["launches_per_run"] == 8 and res["c"][2]["launches_per_run"] == 5
+    for other in "bc":
+        for x, y in zip(res["a"][0], res[other][0]):
+            assert np.array_equal(np.asarray(x), np.asarray(y))
+        assert res["a"][1] == res[other][1]
+        assert _same_files(tmp_path / "a", tmp_path / other) == 8 * 16 + 4
+
+
 @pytest.mark.parametrize("key", ["reg", "cls"])
 def test_run_chains_checkpoint_and_resume(key, tmp_path):
     """a run that is cut off after max_steps and resumed from its checkpoint file (in a new object: new

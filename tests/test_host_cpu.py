@@ -274,6 +274,15 @@ def test_fast_text_path_is_numpy_byte_for_byte(pt, tmp_path, fmt):
     _lib.savetxt(str(b), f32[150:151], fmt, append=True)
     _lib.savetxt(str(b), f32[151:], fmt, append=True)
     assert a.read_bytes() == b.read_bytes()
+    # a window of many files in one call (what run_chains() queues per launch of an overlapped run), in pieces
+    jobs = [(f32, "m"), (f32[:, :5], "s5"), (f32[::3, 2:9], "v"), (f32[:, 0], "c"), (f32[:, 3:4], "c1")]
+    for lo, hi in ((0, 77), (77, 78), (78, None)):
+        _lib.savetxt_batch([(str(tmp_path / f"batch_{n}.txt"), arr[lo:hi], fmt) for arr, n in jobs], append=lo > 0, threads=3)
+    for arr, n in jobs:
+        np.savetxt(a, arr, fmt=fmt)
+        assert a.read_bytes() == (tmp_path / f"batch_{n}.txt").read_bytes(), (fmt, n)
+    with pytest.raises(_lib.PtnnError, match="cannot open"):
+        _lib.savetxt_batch([(str(tmp_path / "ok.txt"), f32[:3], fmt), (str(tmp_path / "no_such_dir" / "x.txt"), f32[:3], fmt)], threads=2)
     # the value np.loadtxt reads back
     fin = f64[np.isfinite(f64)]
     for arr in (f32, fin):
@@ -289,8 +298,12 @@ def test_posterior_matrix_is_the_transposed_burn_in_cut(pt):
     for R, S, P, b in ((3, 50, 7, 25), (5, 1000, 31, 500), (2, 9, 4, 0), (1, 5, 3, 5)):
         pos_w = rng.normal(size=(R, S, P)).astype(np.float32)
         want = pos_w[:, b:, :].astype(np.float64).transpose(2, 0, 1).reshape(P, -1)
+        padded = np.zeros((R, S, P + 5), np.float32)         # the padded rows of a trace image are read in place
+        padded[:, :, :P] = pos_w
         for threads in (1, 4):
             assert np.array_equal(_lib.posterior_matrix(pos_w, b, threads), want)
+            assert np.array_equal(_lib.posterior_matrix(padded[:, :, :P], b, threads), want)
+        assert np.array_equal(_lib.posterior_matrix(pos_w.astype(np.float64), b, 2), want)
 
 
 def test_recorded_bf16_study_meets_its_stated_bounds():
