@@ -375,6 +375,23 @@ def test_bench_run_bare_starts_its_ranks_and_reports_what_the_communicator_saw(t
     assert out["scaling"] == "strong" and out["config"]["replicas"] == 64 and out["config"]["replicas_per_gpu"] == 32 and out["comm"]["nranks_seen"] == 2
 
 
+def test_bench_line_survives_an_rccl_bring_up_that_fails_half_way(tmp_path):
+    """bench.py's own ranks: rank 0 really creates the unique id (RCCL loaded, bootstrap listener up), then ncclCommInitRank fails
+    ($PTNN_COMM_FAULT).  Every rank moves to the host-staged transport, the line says so, and the process EXITS with status 0 (it
+    arms the hard exit: a half-initialised RCCL kept such a process alive before)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PTNN_COMM_FAULT="ncclCommInitRank", PTNN_COMM_TIMEOUT_S="60", MASTER_PORT="29641")
+    r = subprocess.run([sys.executable, os.path.join(parity.ROOT, "bench.py"), "--gpus", "1", "--force-comm", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=400, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["comm"]["transport"] == "host" and out["comm"]["nranks_seen"] == 1
+    assert "fallback after an RCCL failure" in out["config"]["transport_note"] and "ncclCommInitRank" in out["config"]["transport_note"]
+    assert out["value"] > 1e6
+
+
 _EXIT_CHILD = """
 import os, sys, warnings
 sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
