@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define PTNN_ABI_VERSION 3
+#define PTNN_ABI_VERSION 4
 
 #define PTNN_TASK_REG 0 /* Gaussian likelihood + eta = log tau^2 (REG) */
 #define PTNN_TASK_CLS 1 /* multinomial likelihood on softmax-of-sigmoid outputs (CLS) */

@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 3
+ABI_VERSION = 4
 TASK_REG, TASK_CLS = 0, 1
 
 

@@ -30,7 +30,7 @@ FUNC_CASES = {"reg_sunspot_4_5_1": "sunspot", "reg_mackey_4_10_1": "mackey", "cl
 def test_library_is_the_hip_build():
     import ptnn_amd
     lib = ptnn_amd.load_library()
-    assert lib.ptnn_abi_version() == 3
+    assert lib.ptnn_abi_version() == 4
     assert lib.ptnn_supports(0, 4, 5, 1) == 1 and lib.ptnn_supports(1, 34, 50, 2) == 1
     assert lib.ptnn_supports(0, 4, 65, 1) == 1 and lib.ptnn_supports(0, 32, 512, 1) == 1
     assert lib.ptnn_supports(0, 4, 513, 1) == 0 and lib.ptnn_supports(0, 7, 5, 1) == 0

@@ -29,7 +29,7 @@ def test_header_and_library_agree(pt):
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.ptnn_abi_version() == 3
+    assert lib.ptnn_abi_version() == 4
 
 
 def test_supports_table(pt):
