@@ -57,7 +57,7 @@ typedef struct ptnn_config {
                                    * chain; chosen automatically when replicas x 3 work-groups fit the GPU) */
     int32_t groups_per_replica;   /* speculative schedule: work-groups (CUs) cooperating on one replica; 0 = auto
                                    * (as many of 1, 2, 4 as keeps replicas x groups <= number of CUs).  Tree schedule: 3, 7, 15
-                                   * or 31 (0 = auto: the deepest tree up to 15 nodes that is resident).  Wide nets (n_hidden > 64):
+                                   * or 31 (0 = auto: the deepest tree that is resident).  Wide nets (n_hidden > 64):
                                    * 1, 2 or 4 work-groups speculating over windows of steps (0 = auto: 4 or 2 where resident).
                                    * Packed schedule: 1, 2 or 4 CUs, each running a packed round over its slots of one window
                                    * (0 = auto: 4 or 2 where resident for 9 <= n_hidden <= 16, whose lane groups leave 8 slots per

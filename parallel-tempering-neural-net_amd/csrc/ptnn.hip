@@ -871,7 +871,8 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
                                      !h->cfg.use_langevin && h->cfg.groups_per_replica == 0 && h->cfg.waves_per_replica == 0 &&
                                      !h->cfg.shared_device)) {
         // Prefetching tree: 2^D - 1 work-groups per replica, all of them resident (they wait for each other's records).
-        // Explicit: groups_per_replica = 3, 7, 15 or 31 (0: deepest that fits, up to 15); auto: deepest of 15 / 7 / 3 that fits,
+        // Explicit: groups_per_replica = 3, 7, 15 or 31 (0: deepest that fits); auto: deepest of 31 / 15 / 7 / 3 that fits (31 nodes:
+        // five steps per round; Iris 16 x 31 = 496 work-groups, two to a CU: 11.8 M against 11.4 M samples/s with 15),
         // none -> the cooperative schedule stays.
         const bool explicit_tree = sched == PTNN_SCHED_TREE;
         const int Rl = h->cfg.n_replicas_local;
@@ -900,7 +901,7 @@ int ptnn_set_data(ptnn_handle* h, const float* train, int ntr, const float* test
         size_t chosen_lds = 0;
         bool chosen_mfma = false;
         const void* fn = reinterpret_cast<const void*>(h->shape->tree);
-        for (int G = (explicit_tree && want) ? want : 15; G >= 3; G = (G - 1) / 2) {
+        for (int G = (explicit_tree && want) ? want : TREE_MAX_NODES; G >= 3; G = (G - 1) / 2) {
             const int Dp = tree_depth(G);
             // two sets of tapes (the next round's drawn while the records travel) when they fit
             const size_t ceiling = 152 * 1024;                  // dynamic-LDS ceilings just below 160 KiB are refused by the runtime
