@@ -3,7 +3,7 @@
 
 // ------------------------------------------------------------------------------------------------
 // Prefetching ("tree") schedule for random-walk classification chains, where half of the proposals are accepted and
-// speculating on rejections alone gains nothing: G = 2^D - 1 work-groups (one per CU) evaluate, at the same time, the
+// speculating on rejections alone gains nothing: G = 2^D - 1 work-groups (all resident; several may share a CU) evaluate, at the same time, the
 // proposals of ALL 2^D - 1 outcomes of the next D accept/reject decisions.  Work-group g is node g + 1 of a binary heap:
 // the root proposes step i from the current state; the left child of a node proposes the next step assuming the node's
 // proposal was rejected (same state), the right child assuming it was accepted (state = the node's proposal).  A random-walk
