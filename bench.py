@@ -494,7 +494,7 @@ def main():
                 lad = Ladder(wl, a, train, test, rank, N, device, shared_device=shared_dev)
                 s = lad.s
                 transport_used, transport_note = "host", "fallback after an RCCL failure: " + why[:600]
-                dm._arm_hard_exit()                             # an RCCL left half-initialised in this process may never let it exit
+                dm.arm_hard_exit()                             # an RCCL left half-initialised in this process may never let it exit
         if transport_used == "host":
             s.comm_init_host(rank, N, *dm.gloo_transport(dist))
             s.comm_set_mode(mode)

@@ -96,7 +96,7 @@ def rccl_probe(devices, timeout_s=None):
 _hard_exit_armed = False
 
 
-def _arm_hard_exit():
+def arm_hard_exit():
     """An RCCL bring-up failed INSIDE this process (after the child's probe had passed, or with the probe switched off): native
     threads RCCL started may never end, and the C runtime would wait for them in its own exit handlers for ever (seen on the
     test box: an ncclGetUniqueId that no ncclCommInitRank follows).  From here on the process leaves through os._exit: an
@@ -299,7 +299,7 @@ class LadderGroup:
                         self._each(lambda k: self.shards[k].comm_init(uid, k, n))
                     except _lib.PtnnError as e:
                         why = f"{e} (last stage: {_lib.comm_last_stage()})"
-                        _arm_hard_exit()                     # RCCL is partly up in this process: it may never let it exit
+                        arm_hard_exit()                     # RCCL is partly up in this process: it may never let it exit
                         if not fallback:
                             raise
                 if why is not None:
