@@ -42,7 +42,10 @@ int fail(int code, const char* fmt, ...) {
 #define HIP_TRY(expr)                                                                                      \
     do {                                                                                                   \
         hipError_t e_ = (expr);                                                                            \
-        if (e_ != hipSuccess) return fail(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+        if (e_ != hipSuccess) {                                                                            \
+            (void)hipGetLastError(); /* reported here: must not surface again at the next launch check */   \
+            return fail(-2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);    \
+        }                                                                                                  \
     } while (0)
 
 }  // namespace

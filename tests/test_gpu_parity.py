@@ -952,6 +952,28 @@ def test_random_configurations_commit_the_same_chain_under_every_schedule():
     assert mod.run(seed=303, ncase=24, verbose=False, shapes="all", oracle=True) == 0
 
 
+@pytest.mark.gpu
+def test_a_refused_configuration_leaves_no_error_behind():
+    """A configuration the runtime refuses (here: more dynamic LDS than a work-group can have -- eight waves per slot of a 16-40-10
+    Langevin net on the speculative schedule) fails with its own message, and the HIP error it raised must not surface again at the
+    launch check of an unrelated handle (it did: the sticky last error made the next sampler's ptnn_set_state fail with "invalid
+    argument"; found by the randomised schedule test, seed 22)."""
+    from ptnn_amd import _lib, ladder, philox
+    rng = np.random.default_rng(22)
+    topo = (16, 40, 10)
+    data = np.hstack([rng.uniform(0, 1, (98, 16)), rng.integers(0, 10, (98, 1)).astype(np.float64)])
+    train, test = data[:81], data[81:]
+    kw = dict(R_local=3, R_global=3, first=0, S=53, si=8, use_lg=True, lr=0.01, seed=641349)
+    with pytest.raises(_lib.PtnnError, match="hipFuncSetAttribute|LDS|shared"):
+        parity.make_sampler(1, topo, train, test, schedule=2, waves=8, groups=1, **kw)
+    s = parity.make_sampler(1, topo, train, test, schedule=2, waves=4, groups=4, **kw)
+    P = orc.num_param(topo)
+    s.set_state(np.stack([philox.initial_weights(5, r, P) for r in range(3)]), ladder.temperatures(3, 10))
+    s.run(-1); s.sync()
+    assert np.isfinite(s.traces()["likeh"][:, 1:]).all()
+    s.close()
+
+
 TREE_CASES = [("iris", (4, 12, 3), 6, 60, 10, 3), ("iris", (4, 12, 3), 6, 60, 10, 7), ("iris", (4, 12, 3), 4, 100, 7, 15),
               ("iris", (4, 5, 3), 3, 50, 10, 31), ("ions", (34, 50, 2), 4, 40, 10, 3), ("ions", (34, 50, 2), 4, 50, 10, 7),
               ("ions", (34, 50, 2), 2, 120, 40, 15), ("ions", (34, 20, 2), 5, 64, 8, 15), ("iris", (4, 12, 3), 8, 25, 5, 31),
