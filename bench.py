@@ -378,6 +378,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launched_by_env = "WORLD_SIZE" in os.environ             # a launcher (torch.distributed.run, or this script itself) set the rank variables
     if world != N:
         if "WORLD_SIZE" not in os.environ and N > 1:
             # bare `python3 bench.py --gpus N`: this process becomes the launcher -- nothing has touched the GPU yet
@@ -531,7 +532,7 @@ def main():
                 "nranks_seen": sorted({c["nranks"] for c in allc})[0] if len({c["nranks"] for c in allc}) == 1 else [c["nranks"] for c in allc],
                 "device_ids": [c["device"] for c in allc], "distinct_devices": len({c["device"] for c in allc}),
                 "exchange": allc[0]["mode"], "bytes_sent": [c["bytes_sent"] for c in allc], "bytes_received": [c["bytes_received"] for c in allc],
-                "rounds": allc[0]["rounds"], "launcher": "self" if os.environ.get("PTNN_BENCH_SELF_LAUNCHED") else "torch.distributed.run"}
+                "rounds": allc[0]["rounds"], "launcher": "self" if os.environ.get("PTNN_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if launched_by_env else "none (one process)")}
     nsw, tot, rounds = s.swap_stats()            # counters restart with every run: these are the last run's
     st = s.state()
     info = s.describe()
