@@ -48,6 +48,15 @@ def stitch_by_temperature(tr, swap_log, handoff_steps, S):
     return out, holder
 
 
+def overlap_cuts(S, swap_interval, chunks):
+    """MH-step counts at which an overlapped run_chains() ends its launches: at most `chunks` launches of whole swap intervals
+    (near-equal), strictly increasing, the last one at S - 1 (all steps; ptnn_run then also runs the phantom round if one is due)."""
+    si = max(1, int(swap_interval))
+    n_int = max(1, (S - 1) // si)
+    K = max(1, min(int(chunks), n_int))
+    return sorted({min(S - 1, si * max(1, round(n_int * (c + 1) / K))) for c in range(K - 1)} | {S - 1})
+
+
 class ParallelTemperingBase:
     task = None                       # set by the two drop-in subclasses
     rmse_fmt = None                   # REG '%1.8f' (REG:462-464), CLS '%1.2f' (CLS:473-475)
@@ -288,9 +297,7 @@ class ParallelTemperingBase:
         per-chain files (append mode) by the pool, while the next launch samples.  Same bytes in every file as the resident path."""
         s, S, si = self._sampler, self.NumSamples, max(1, int(self.swap_interval))
         pos_img, rows_img = self._img
-        n_int = max(1, (S - 1) // si)
-        K = max(1, min(self.overlap_chunks, n_int))
-        ends = sorted({min(S - 1, si * max(1, round(n_int * (c + 1) / K))) for c in range(K - 1)} | {S - 1})
+        ends = overlap_cuts(S, si, self.overlap_chunks)
         tickets, done, row = [], 0, 0
         for b in ends:
             s.run(-1 if b == S - 1 else b - done)           # queued, not waited for

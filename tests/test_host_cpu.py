@@ -292,6 +292,21 @@ def test_fast_text_path_is_numpy_byte_for_byte(pt, tmp_path, fmt):
         assert got.dtype == np.float64 and np.array_equal(back, got), fmt
 
 
+def test_overlapped_run_is_cut_at_whole_swap_intervals(pt):
+    """parallel_tempering.overlap_cuts: the launches of an overlapped run_chains() end after whole swap intervals, never more of them
+    than asked for or than there are intervals, and the last one ends the run."""
+    from ptnn_amd.parallel_tempering import overlap_cuts
+    assert overlap_cuts(10000, 100, 8) == [1200, 2500, 3700, 5000, 6200, 7400, 8700, 9999]
+    rng = np.random.default_rng(3)
+    for _ in range(2000):
+        S, si, K = int(rng.integers(2, 5000)), int(rng.integers(1, 600)), int(rng.integers(1, 20))
+        ends = overlap_cuts(S, si, K)
+        assert ends[-1] == S - 1 and ends == sorted(set(ends)) and ends[0] >= 1
+        assert len(ends) <= max(1, min(K, max(1, (S - 1) // si)))
+        assert all(e % si == 0 for e in ends[:-1])
+    assert overlap_cuts(50, 100, 8) == [49] and overlap_cuts(2, 1, 8) == [1]
+
+
 def test_posterior_matrix_is_the_transposed_burn_in_cut(pt):
     from ptnn_amd import _lib
     rng = np.random.default_rng(2)
