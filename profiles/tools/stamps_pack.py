@@ -6,7 +6,7 @@ os.environ["PTNN_LIBRARY"] = os.path.join(R, "profiles/tools/libptnn_stamps.so")
 sys.path.insert(0, R)
 import bench
 import argparse
-a = argparse.Namespace(waves=0, schedule=int(os.environ.get("SCHED", "3")), groups=0, bf16=False, shared_noise=1)
+a = argparse.Namespace(waves=0, schedule=int(os.environ.get("SCHED", "3")), groups=int(os.environ.get("GROUPS", "0")), bf16=False, shared_noise=1)
 wl = dict(bench.WORKLOADS[os.environ.get("WORKLOAD", "sunspot64")])
 train, test, _ = bench.load_data(wl["data"])
 lad = bench.Ladder(wl, a, train, test, 0, 1, 0)
