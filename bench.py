@@ -580,15 +580,22 @@ def main():
                                           "note": "shared_noise 1 = the reference's behaviour (its forked chains inherit one RNG state, "
                                                   "REG:709-712) and the drop-in's default; 0 = independent Philox streams per chain"}
             lad2.s.close()
+        if not a.rw and not a.replicas and R * S * (lad.P + 24) * 4 <= (1 << 30):
             # the whole drop-in call the reference's own figure is taken over (REG:1019-1022): run_chains() with the trace download
-            # over PCIe, the per-chain result files and show_results -- never `value` (which has its inputs and outputs in HBM)
+            # over PCIe, the per-chain result files and show_results -- never `value` (which has its inputs and outputs in HBM).
+            # For the workloads whose traces fit the drop-in's pinned images (1 GiB): Sunspot, Iris, Mackey-Glass
             try:
                 import shutil
                 import tempfile
-                from ptnn_amd.pt_timeseries_regression import ParallelTempering
                 tmp = tempfile.mkdtemp(prefix="ptnn_bench_")
-                pt = ParallelTempering(True, wl["lr"], train, test, list(wl["topo"]), R, wl["maxtemp"], R * S, si, 0.5, tmp, seed=SEED,
-                                       shared_noise=bool(a.shared_noise))
+                if wl["task"] == 0:
+                    from ptnn_amd.pt_timeseries_regression import ParallelTempering
+                    pt = ParallelTempering(bool(wl["lg"]), wl["lr"], train, test, list(wl["topo"]), R, wl["maxtemp"], R * S, si, 0.5, tmp, seed=SEED,
+                                           shared_noise=bool(a.shared_noise))
+                else:
+                    from ptnn_amd.pt_classification import ParallelTempering
+                    pt = ParallelTempering(bool(wl["lg"]), wl["lr"], train, test, list(wl["topo"]), R, wl["maxtemp"], R * S, si, tmp, seed=SEED,
+                                           shared_noise=bool(a.shared_noise))
                 for sub in ("predictions", "posterior", "posterior/pos_w", "posterior/pos_likelihood", "posterior/accept_list"):
                     pt.make_directory(os.path.join(tmp, sub))
                 pt.initialize_chains(0.5)
