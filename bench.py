@@ -207,7 +207,7 @@ def cpu_baseline(wl, train, test, n_steps=101):
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
         res = pool.map(_cpu_chain, jobs, chunksize=1)
-    src, nsw = orc.swap_cascade([L for _, L in res], orc.PhiloxTape(SEED).swap_uniforms(0, R - 1))
+    _, nsw = orc.swap_cascade([L for _, L in res], orc.PhiloxTape(SEED).swap_uniforms(0, R - 1))
     wall = time.perf_counter() - t0
     value = R * n_steps / wall
     # the plain-C restatement of the same oracle on the same cores, a whole run's worth of MH steps per replica (no swaps): what a compiled
@@ -509,7 +509,6 @@ def main():
     for _ in range(W):
         lad.whole_run()
     s.kernel_time(reset=True)
-    nsw0, tot0, _ = s.swap_stats()
     fence()
     t0 = time.perf_counter()
     for _ in range(K):

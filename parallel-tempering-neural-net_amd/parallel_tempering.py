@@ -415,7 +415,7 @@ class ParallelTemperingBase:
             tr = self._sampler.traces()
             if self.label_swap:
                 tr = self._stitch_by_temperature(tr)
-        S, R, P = self.NumSamples, self.num_chains, self.num_param
+        S, R = self.NumSamples, self.num_chains
         burnin = int(S * self.burn_in)
         th = self.io_threads
         # the reference re-reads the per-chain text files, so every value below has been through their format
