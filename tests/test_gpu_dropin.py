@@ -211,18 +211,21 @@ def test_overlapped_run_chains_equals_resident(key, chunks, tmp_path):
     assert _same_files(tmp_path / "a", tmp_path / "b") >= 8 * int(a[0]["R"]) + 3
 
 
-def test_overlapped_run_at_the_headline_shape(tmp_path):
-    """The same at a size where the pieces really overlap: Sunspot 4-5-1, 16 chains x 3000 samples, Langevin, shared noise; and a
-    second run_chains() on a fresh object in the same process (the images are per handle)."""
+@pytest.mark.parametrize("dname,topo,kernel", [("sunspot", [4, 5, 1], "segment_pack_kernel"), ("mackey", [4, 10, 1], "segment_packm_kernel")])
+def test_overlapped_run_at_the_headline_shape(dname, topo, kernel, tmp_path):
+    """The same at a size where the pieces really overlap: Sunspot 4-5-1 (packed schedule on one CU) and Mackey-Glass 4-10-1 (packed
+    over 4 CUs, its swap rounds inside every launch), 16 chains x 3000 samples, Langevin, shared noise; and further run_chains() on
+    fresh objects in the same process (the images are per handle)."""
     from ptnn_amd.pt_timeseries_regression import ParallelTempering
     d = parity.datasets()
     res = {}
     for name, oc in (("a", 0), ("b", 8), ("c", 5)):
         path = str(tmp_path / name)
-        pt = ParallelTempering(True, 0.1, d["sunspot_train"], d["sunspot_test"], [4, 5, 1], 16, 2, 16 * 3000, 100, 0.5, path, seed=11, overlap_chunks=oc)
+        pt = ParallelTempering(True, 0.1, d[dname + "_train"], d[dname + "_test"], topo, 16, 2, 16 * 3000, 100, 0.5, path, seed=11, overlap_chunks=oc)
         for sdir in SUBDIRS:
             pt.make_directory(os.path.join(path, sdir))
         pt.initialize_chains(0.5)
+        assert kernel in pt._sampler.describe()["kernel"]
         res[name] = (pt.run_chains(), pt.num_swap, pt.timings)
     assert res["b"][2]["overlapped"] and res["b"][2]["launches_per_run"] == 8 and res["c"][2]["launches_per_run"] == 5
     for other in "bc":
