@@ -1572,18 +1572,17 @@ int ptnn_trace_image_fetch(ptnn_handle* h, int step0, int nsteps) {
     if (e == hipSuccess) e = hipStreamWaitEvent(h->copy_stream, queued, 0);
     (void)hipEventDestroy(queued);                                           // released once it has completed
     HIP_TRY(e);
-    // one contiguous copy per replica and array (rows [step0, step0 + nsteps) of a replica are contiguous in both layouts): plain
-    // linear copies, the DMA engines' own shape.  Measured beside a run that fills every CU with work-groups waiting for each other
-    // (Mackey-Glass, packed over 4 CUs): 28.0 ms of kernel time with these copies in flight against 27.9 ms without
-    // (profiles/tools/chunk_probe.py)
+    // one strided copy per array (a replica's rows [step0, step0 + nsteps) are contiguous; replicas lie S rows apart in both layouts).
+    // Measured against one linear copy per replica and array (128 enqueues per window for 64 replicas): the rows land 1 ms earlier,
+    // and neither shape takes time from the kernels -- Mackey-Glass, every CU full of work-groups that wait for each other: 28.0 ms
+    // of kernel time with the copies in flight against 27.9 ms without (profiles/tools/chunk_probe.py)
     const size_t PWb = (size_t)h->PW * sizeof(float), RWb = (size_t)TR_COUNT * sizeof(float);
-    for (int r = 0; r < Rl; ++r) {
-        const size_t at = (size_t)r * S + (size_t)step0;
-        HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(h->h_img_pos) + at * PWb, reinterpret_cast<const char*>(h->d_pos_w) + at * PWb,
-                               (size_t)nsteps * PWb, hipMemcpyDeviceToHost, h->copy_stream));
-        HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(h->h_img_rows) + at * RWb, reinterpret_cast<const char*>(h->d_scal) + at * RWb,
-                               (size_t)nsteps * RWb, hipMemcpyDeviceToHost, h->copy_stream));
-    }
+    HIP_TRY(hipMemcpy2DAsync(reinterpret_cast<char*>(h->h_img_pos) + (size_t)step0 * PWb, (size_t)S * PWb,
+                             reinterpret_cast<const char*>(h->d_pos_w) + (size_t)step0 * PWb, (size_t)S * PWb, (size_t)nsteps * PWb, Rl,
+                             hipMemcpyDeviceToHost, h->copy_stream));
+    HIP_TRY(hipMemcpy2DAsync(reinterpret_cast<char*>(h->h_img_rows) + (size_t)step0 * RWb, (size_t)S * RWb,
+                             reinterpret_cast<const char*>(h->d_scal) + (size_t)step0 * RWb, (size_t)S * RWb, (size_t)nsteps * RWb, Rl,
+                             hipMemcpyDeviceToHost, h->copy_stream));
     HIP_TRY(hipEventCreateWithFlags(&landed, hipEventDisableTiming));
     e = hipEventRecord(landed, h->copy_stream);
     if (e != hipSuccess) { (void)hipEventDestroy(landed); HIP_TRY(e); }
