@@ -1549,9 +1549,19 @@ int ptnn_trace_image(ptnn_handle* h, float** pos_w, int32_t* row_floats, float**
     if (h->compact) return fail(-1, "trace images are not available with compact traces (wide nets): fetch with ptnn_get_traces");
     HIP_TRY(hipSetDevice(h->cfg.device_id));
     if (!h->h_img_pos) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_img_pos), (size_t)Rl * S * h->PW * sizeof(float), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->h_img_rows), (size_t)Rl * S * TR_COUNT * sizeof(float), hipHostMallocDefault));
-        HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        // all three or none: a half-made set must not be handed out by the next call
+        float *pos = nullptr, *rws = nullptr;
+        hipStream_t st = nullptr;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&pos), (size_t)Rl * S * h->PW * sizeof(float), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&rws), (size_t)Rl * S * TR_COUNT * sizeof(float), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            if (pos) (void)hipHostFree(pos);
+            if (rws) (void)hipHostFree(rws);
+            (void)hipGetLastError();
+            return fail(-2, "pinned trace images of %zu MB: %s", ((size_t)Rl * S * (h->PW + TR_COUNT) * sizeof(float)) >> 20, hipGetErrorString(e));
+        }
+        h->h_img_pos = pos; h->h_img_rows = rws; h->copy_stream = st;
     }
     *pos_w = h->h_img_pos; *row_floats = h->PW; *rows = h->h_img_rows;
     return 0;
