@@ -46,10 +46,24 @@ __host__ __device__ inline size_t wide_img_floats(int H, int FWS, int PS) {
 // two waves per SIMD the row loop is mostly issue-bound, not latency-bound), and pairing the Langevin steps of a window in
 // segment_wide_body bought 3 % against 4 % lost to the extra registers of the step loop (profiles/r03_wide_pair.json).  Kept
 // for the timer (model_wide_kernel mode 3), as the record of that experiment.
-template <int TASK, int I, int O, int NE>
+// The epoch of a Langevin PROPOSAL is needed for two things: |w - epoch(w')|^2 in the proposal ratio (REG:336-340), always, and the
+// vector itself -- the cached langevin_gradient of the next state -- only if the step is accepted (1 - 5 % of the steps of a wide net).
+// With a SweepDecide the sweep takes the Metropolis-Hastings decision itself, from the registers its result lives in, and writes the
+// 70 KB vector out only for an accepted step: everything else the decision needs (likelihood and prior of the proposal, the step's
+// uniform) is known before the epoch starts when the forward pass runs first.  Same operations in the same order as the caller's
+// own decision (segment_wide_body), so the chain does not change.
+struct SweepDecide {
+    float base;                      // (lik_prop - lik) + (prior_prop - prior_cur)
+    float d2, step_w, adapttemp, u;  // |noise|^2, proposal step, temperature of the step, its uniform
+    float* red;                      // scratch of block_sum
+    float logalpha;                  // out (uniform)
+    bool accept;                     // out (uniform)
+};
+
+template <int TASK, int I, int O, int NE, bool DECIDE = false>
 __device__ __forceinline__ void sgd_sweep_wide_n(const float* const (&w_in)[NE], float* const (&w_out)[NE], const float* __restrict__ data,
                                                  int IPY, int Ntr, int H, float lr, float* __restrict__ part, const float* w_ref,
-                                                 float (&d1_out)[NE]) {
+                                                 float (&d1_out)[NE], SweepDecide* dec = nullptr) {
     constexpr float C = -LOG2E, IC = -LN2;
     constexpr int OP = (O + 3) & ~3;
     constexpr int IP = (I + 1) / 2;                                   // input pairs (an odd I is padded with a zero weight)
@@ -116,7 +130,11 @@ __device__ __forceinline__ void sgd_sweep_wide_n(const float* const (&w_in)[NE],
     load_row(1, xz);
     // the row loop is one latency-bound dependent chain with three synchronisation points per row: where its head falls in an
     // instruction-cache line decided 8 % of the epoch (472 vs 512 us for the same instructions), so it is pinned
-    asm volatile(".p2align 8");
+    // (the pin sits some forty instructions ahead of the loop's top, which the compiler places: the top of the deciding variant
+    // comes out 8 bytes earlier than the plain one's -- 24 instead of 32 bytes into its 64-byte line, 4 % of the epoch -- and is put
+    // back where the plain one's is; checked in the code object: llvm-objdump, the s_or_b64 behind the loop's entry branch)
+    if constexpr (DECIDE) asm volatile(".p2align 8\n\ts_nop 0\n\ts_nop 0");
+    else asm volatile(".p2align 8");
     for (int n = 0; n < ntr; ++n) {
         const cfloat* row = cdata + (size_t)n * ipy;
         const float yn = row[I], dn = row[I + 1];
@@ -220,20 +238,51 @@ __device__ __forceinline__ void sgd_sweep_wide_n(const float* const (&w_in)[NE],
         }
         float d1 = 0.0f;
         float* wo = w_out[e];
-        auto put = [&](int idx, float v) {
-            wo[idx] = v;
-            if (w_ref) { const float d = w_ref[idx] - v; d1 = fmaf(d, d, d1); }
+        // every element of the result, in the order the squared distance is summed in: f(index, value)
+        auto each = [&](auto f) {
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < I; ++i) f(i * H + t, IC * w1[e][i >> 1][i & 1]);
+#pragma unroll
+                for (int o = 0; o < O; ++o) f(oW2 + t * O + o, IC * w2[e][o]);
+                f(oB1 + t, -IC * nb1[e]);
+            }
+            if (t == 0) {
+#pragma unroll
+                for (int o = 0; o < O; ++o) f(oB2 + o, -IC * cl[e][o]);
+            }
         };
-        if (act) {
-#pragma unroll
-            for (int i = 0; i < I; ++i) put(i * H + t, IC * w1[e][i >> 1][i & 1]);
-#pragma unroll
-            for (int o = 0; o < O; ++o) put(oW2 + t * O + o, IC * w2[e][o]);
-            put(oB1 + t, -IC * nb1[e]);
-        }
-        if (t == 0) {
-#pragma unroll
-            for (int o = 0; o < O; ++o) put(oB2 + o, -IC * cl[e][o]);
+        if (dec == nullptr) {
+            each([&](int idx, float v) {
+                wo[idx] = v;
+                if (w_ref) { const float d = w_ref[idx] - v; d1 = fmaf(d, d, d1); }
+            });
+        } else {
+            // (in groups of eight: left to itself the scheduler forms all 34 addresses and issues all 34 loads at once -- 248 VGPRs
+            // clobbered by this function instead of ~100, and the kernel spills what it holds around the call)
+            int k8 = 0;
+            each([&](int idx, float v) {
+                const float d = w_ref[idx] - v;
+                d1 = fmaf(d, d, d1);
+                if ((++k8 & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+            });
+            const float d1_all = block_sum(d1, dec->red);
+            const float diff_prop = langevin_ratio(d1_all, dec->d2, dec->step_w, dec->adapttemp);
+            dec->logalpha = dec->base + diff_prop;
+            const float mh = (dec->logalpha != dec->logalpha) ? 1.0f : fminf(1.0f, expf_fast(dec->logalpha));
+            dec->accept = dec->u < mh;
+            if (dec->accept) {
+                // the destination as a value the compiler knows nothing about: the addresses of this (rare) pass are formed here, not
+                // ahead of the reduction above, where 34 of them per thread stayed live across it (248 VGPRs clobbered by this
+                // function instead of ~100, and the kernel spilled everything it holds around the call)
+                float* wo2 = wo;
+                asm volatile("" : "+v"(wo2));
+                int j8 = 0;
+                each([&](int idx, float v) {
+                    wo2[idx] = v;
+                    if ((++j8 & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+                });
+            }
         }
         d1_out[e] = d1;
     }
@@ -249,6 +298,22 @@ __device__ __attribute__((noinline, aligned(256))) float sgd_sweep_wide(const fl
     float d1[1];
     sgd_sweep_wide_n<TASK, I, O, 1>(wi, wo, data, IPY, Ntr, H, lr, part, w_ref, d1);
     return d1[0];
+}
+// the epoch of a Langevin proposal that decides its own step (SweepDecide): everything by value, the verdict in registers
+struct SweepVerdict { float logalpha; int accept; };
+template <int TASK, int I, int O>
+__device__ __attribute__((noinline, aligned(256))) SweepVerdict sgd_sweep_wide_decide(const float* __restrict__ w_in, float* __restrict__ w_out,
+                                                                       const float* __restrict__ data, int IPY, int Ntr, int H, float lr,
+                                                                       float* __restrict__ part, const float* w_ref, float* red,
+                                                                       float base, float d2, float step_w, float adapttemp, float u) {
+    const float* const wi[1] = {w_in};
+    float* const wo[1] = {w_out};
+    float d1[1];
+    SweepDecide dec;
+    dec.base = base; dec.d2 = d2; dec.step_w = step_w; dec.adapttemp = adapttemp; dec.u = u; dec.red = red;
+    dec.logalpha = 0.0f; dec.accept = false;
+    sgd_sweep_wide_n<TASK, I, O, 1, true>(wi, wo, data, IPY, Ntr, H, lr, part, w_ref, d1, &dec);
+    return SweepVerdict{dec.logalpha, dec.accept ? 1 : 0};
 }
 // the pair: epoch A from w_inA (the proposal in LDS), epoch B from w_inB (a proposal parked in global memory)
 template <int TASK, int I, int O>
@@ -790,7 +855,10 @@ __device__ __forceinline__ void segment_wide_body(const SegParams& p, const SegD
             const float u = s_u[s_], n_eta = s_ne[s_];
             float diff_prop = 0.0f;
             if (lg && !gd_valid) {
-                sgd_sweep_wide<TASK, I, O>(w_cur, w_gd, xy, p.IPY, p.Ntr, H, p.lr, part);
+                // (RES: through the one out-of-line copy of the row loop this kernel has -- a uniform of -1 makes it write its result
+                // whatever the ratio)
+                if constexpr (RES) (void)sgd_sweep_wide_decide<TASK, I, O>(w_cur, w_gd, xy, p.IPY, p.Ntr, H, p.lr, part, w_cur, red, 0.0f, 0.0f, p.step_w, 1.0f, -1.0f);
+                else sgd_sweep_wide<TASK, I, O>(w_cur, w_gd, xy, p.IPY, p.Ntr, H, p.lr, part);
                 gd_valid = 1;
             }
             // ONE pass over the weights: draw the noise (4 normals per Philox call), form the proposal from w (random walk) or
@@ -836,13 +904,9 @@ __device__ __forceinline__ void segment_wide_body(const SegParams& p, const SegD
             if (lg) propose(w_gd);
             else propose(w_cur);
             __syncthreads();
-            if (lg) {
-                float d1;
-                if constexpr (RES) d1 = block_sum(sgd_sweep_wide<TASK, I, O>(w_prop, w_pgd, xy, p.IPY, p.Ntr, H, p.lr, part, w_cur), red);
-                else {
-                    sgd_sweep_wide<TASK, I, O>(w_prop, w_pgd, xy, p.IPY, p.Ntr, H, p.lr, part);
-                    d1 = block_sumsq_diff(w_cur, w_pgd, P, red);
-                }
+            if (lg && !RES) {
+                sgd_sweep_wide<TASK, I, O>(w_prop, w_pgd, xy, p.IPY, p.Ntr, H, p.lr, part);
+                const float d1 = block_sumsq_diff(w_cur, w_pgd, P, red);
                 const float d2 = block_sum(nsq_part, red);
                 diff_prop = langevin_ratio(d1, d2, p.step_w, adapttemp);
             }
@@ -854,9 +918,20 @@ __device__ __forceinline__ void segment_wide_body(const SegParams& p, const SegD
             const float lik_prop = ll / adapttemp;
             const float ssq = block_sum(ssq_part, red);
             const float prior_prop = prior_value<TASK>(p, ssq, eta_pro);
-            const float logalpha = (lik_prop - lik) + (prior_prop - prior_cur) + diff_prop;
-            const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
-            const bool accept = u < mh;
+            float logalpha;
+            bool accept;
+            if (lg && RES) {
+                // the proposal is still in LDS (the forward pass only read it): its epoch runs last, decides, and writes its 70 KB
+                // out only when the step is accepted (SweepDecide)
+                const float d2 = block_sum(nsq_part, red);
+                const SweepVerdict v = sgd_sweep_wide_decide<TASK, I, O>(w_prop, w_pgd, xy, p.IPY, p.Ntr, H, p.lr, part, w_cur, red,
+                                                                         (lik_prop - lik) + (prior_prop - prior_cur), d2, p.step_w, adapttemp, u);
+                logalpha = v.logalpha; accept = v.accept != 0;
+            } else {
+                logalpha = (lik_prop - lik) + (prior_prop - prior_cur) + diff_prop;
+                const float mh = (logalpha != logalpha) ? 1.0f : fminf(1.0f, expf_fast(logalpha));
+                accept = u < mh;
+            }
             if (tid == 0) { s_lik[s_] = lik_prop; s_la[s_] = logalpha; }
             if (accept) {
                 my_acc = s_; stopped = true;
